@@ -1,0 +1,543 @@
+"""CPU oracle for the DDMI generation path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain, functional, fp32 restatement (torch CPU ops + numpy) of the reference
+algorithms on the hot path.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this module; `ddmi_amd/` never does.
+
+Pinning: every function here is checked against golden vectors captured by
+importing the reference itself in the build container (`oracle/gen_golden.py`
+-> `tests/golden/*.npz`, `tests/test_oracle_golden.py`).  The reference ships no
+known-answer tests of its own, so those captured vectors are the pin.
+
+All citations are relative to the reference tree (mlvlab/DDMI):
+  ddpm      = diffusion/ddpm.py
+  openai    = models/ldm/modules/diffusionmodules/openaimodel.py
+  util      = models/ldm/modules/diffusionmodules/util.py
+  ae        = models/d2c_vae/autoencoder_unet.py
+  mlp       = models/d2c_vae/mlp.py
+  blocks    = models/d2c_vae/blocks.py
+  gu        = utils/general_utils.py
+  fba       = models/d2c_vae/op/fused_bias_act_kernel.cu
+
+Third-party arithmetic that the reference delegates to torch (conv2d, group_norm,
+softmax, linear) is delegated to the same torch CPU ops here; everything the
+reference itself spells out (schedules, mixing, posterior, attention layouts,
+bilinear plane sampling, weight modulation) is restated explicitly.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+State = Mapping[str, Tensor]
+
+
+def _t(x) -> Tensor:
+    if isinstance(x, Tensor):
+        return x.detach().to(torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(x)).to(torch.float32)
+
+
+def to_state(d: Mapping[str, "np.ndarray"], prefix: str = "") -> Dict[str, Tensor]:
+    """numpy/torch mapping -> fp32 torch mapping, optionally keeping only `prefix`ed keys (prefix stripped)."""
+    out = {}
+    for k, v in d.items():
+        if prefix and not k.startswith(prefix):
+            continue
+        out[k[len(prefix):]] = _t(v)
+    return out
+
+
+# ======================================================================================
+# a1/a2  schedules
+# ======================================================================================
+
+def linspace_f64(start: float, end: float, steps: int) -> np.ndarray:
+    """torch.linspace(dtype=float64) as ATen computes it (symmetric around the midpoint):
+    i < steps//2 : start + step*i ; else end - step*(steps-1-i)."""
+    if steps == 1:
+        return np.array([start], dtype=np.float64)
+    step = (np.float64(end) - np.float64(start)) / np.float64(steps - 1)
+    i = np.arange(steps, dtype=np.float64)
+    lo = np.float64(start) + step * i
+    hi = np.float64(end) - step * (np.float64(steps - 1) - i)
+    return np.where(np.arange(steps) < steps // 2, lo, hi)
+
+
+def linspace_f32(start: float, end: float, steps: int) -> np.ndarray:
+    """Same formula evaluated in float32 (what `torch.linspace(-1, T-1, S+1)` does, ddpm:338)."""
+    if steps == 1:
+        return np.array([start], dtype=np.float32)
+    s, e = np.float32(start), np.float32(end)
+    step = np.float32((e - s) / np.float32(steps - 1))
+    i = np.arange(steps, dtype=np.float32)
+    lo = (s + step * i).astype(np.float32)
+    hi = (e - step * (np.float32(steps - 1) - i)).astype(np.float32)
+    return np.where(np.arange(steps) < steps // 2, lo, hi).astype(np.float32)
+
+
+def make_schedule(timesteps: int = 1000, linear_start: float = 0.0015, linear_end: float = 0.0195,
+                  v_posterior: float = 0.0) -> Dict[str, np.ndarray]:
+    """ddpm:37-41 (linear betas) + ddpm:163-203 (register_schedule): fp64 math, fp32 buffers."""
+    betas = linspace_f64(linear_start ** 0.5, linear_end ** 0.5, timesteps) ** 2
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    post_var = (1 - v_posterior) * betas * (1.0 - ac_prev) / (1.0 - ac) + v_posterior * betas
+    f = lambda a: np.asarray(a, dtype=np.float64).astype(np.float32)
+    return {
+        "betas": f(betas),
+        "alphas_cumprod": f(ac),
+        "alphas_cumprod_prev": f(ac_prev),
+        "sqrt_alphas_cumprod": f(np.sqrt(ac)),
+        "sqrt_one_minus_alphas_cumprod": f(np.sqrt(1.0 - ac)),
+        "log_one_minus_alphas_cumprod": f(np.log(1.0 - ac)),
+        "sqrt_recip_alphas_cumprod": f(np.sqrt(1.0 / ac)),
+        "sqrt_recipm1_alphas_cumprod": f(np.sqrt(1.0 / ac - 1)),
+        "posterior_variance": f(post_var),
+        "posterior_log_variance_clipped": f(np.log(np.maximum(post_var, 1e-20))),
+        "posterior_mean_coef1": f(betas * np.sqrt(ac_prev) / (1.0 - ac)),
+        "posterior_mean_coef2": f((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac)),
+    }
+
+
+def ddim_time_pairs(timesteps: int, sampling_timesteps: int) -> List[Tuple[int, int]]:
+    """ddpm:338-340: fp32 linspace(-1, T-1, S+1) -> trunc to int -> reversed -> consecutive pairs."""
+    times = linspace_f32(-1.0, float(timesteps - 1), sampling_timesteps + 1)
+    times = [int(v) for v in np.trunc(times).astype(np.int64)][::-1]
+    return list(zip(times[:-1], times[1:]))
+
+
+# ======================================================================================
+# a3-a6  per-step arithmetic (all fp32, same operation order as the reference)
+# ======================================================================================
+
+def mixed_eps(sched, x: Tensor, model_out: Tensor, t: int, mixing_logit: Optional[Tensor]) -> Tensor:
+    """ddpm:469-477: eps = (1-c)*sqrt(1-abar_t)*x + c*model_out, c = sigmoid(mixing_logit)."""
+    if mixing_logit is None:
+        return model_out
+    mixing_component = float(sched["sqrt_one_minus_alphas_cumprod"][t]) * x
+    coeff = torch.sigmoid(_t(mixing_logit))
+    return (1 - coeff) * mixing_component + coeff * model_out
+
+
+def predict_x0(sched, x: Tensor, t: int, eps: Tensor) -> Tensor:
+    """ddpm:236-240."""
+    return float(sched["sqrt_recip_alphas_cumprod"][t]) * x - float(sched["sqrt_recipm1_alphas_cumprod"][t]) * eps
+
+
+def p_sample_step(sched, x: Tensor, model_out: Tensor, t: int, noise: Tensor,
+                  mixing_logit: Optional[Tensor], clip_denoised: bool = False) -> Tensor:
+    """One ancestral step given the UNet output: ddpm:257-281."""
+    eps = mixed_eps(sched, x, model_out, t, mixing_logit)
+    x0 = predict_x0(sched, x, t, eps)
+    if clip_denoised:
+        x0 = x0.clamp(-1.0, 1.0)
+    mean = float(sched["posterior_mean_coef1"][t]) * x0 + float(sched["posterior_mean_coef2"][t]) * x
+    logvar = torch.tensor(sched["posterior_log_variance_clipped"][t])
+    nonzero = 0.0 if t == 0 else 1.0
+    return mean + nonzero * (0.5 * logvar).exp() * noise
+
+
+def ddim_coefs(sched, t: int, t_next: int, eta: float) -> Tuple[float, float, float]:
+    """ddpm:357-361 evaluated with fp32 scalars exactly like the 0-dim tensors there.
+    Returns (sqrt(alpha_next), c, sigma) as python floats holding fp32 values."""
+    alpha = torch.tensor(sched["alphas_cumprod"][t])
+    alpha_next = torch.tensor(sched["alphas_cumprod"][t_next])
+    sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+    c = (1 - alpha_next - sigma ** 2).sqrt()
+    return float(alpha_next.sqrt()), float(c), float(sigma)
+
+
+def ddim_step(sched, x: Tensor, model_out: Tensor, t: int, t_next: int, eta: float, noise: Optional[Tensor],
+              mixing_logit: Optional[Tensor], clip_denoised: bool = False) -> Tensor:
+    """ddpm:303-332 (cond=None branch) + ddpm:353-368."""
+    eps = mixed_eps(sched, x, model_out, t, mixing_logit)
+    x0 = predict_x0(sched, x, t, eps)
+    if clip_denoised:
+        x0 = x0.clamp(-1.0, 1.0)
+    if t_next < 0:
+        return x0
+    san, c, sigma = ddim_coefs(sched, t, t_next, eta)
+    return x0 * san + c * eps + sigma * noise
+
+
+def sample_chain(unet_fn, sched, x_T: Tensor, noises: Sequence[Tensor], timesteps: int, sampling_timesteps: int,
+                 eta: float, mixing_logit: Optional[Tensor], clip_denoised: bool = False) -> Tensor:
+    """ddpm:371-381 dispatch + ddpm:283-300 (p_sample_loop) / ddpm:334-369 (ddim_sample).
+    `noises[i]` is the i-th `randn` the reference would draw after x_T: one per step for the
+    ancestral loop (including t=0, ddpm:278) and one per non-final step for DDIM (ddpm:363)."""
+    x = _t(x_T)
+    B = x.shape[0]
+    if sampling_timesteps < timesteps:
+        for i, (t, t_next) in enumerate(ddim_time_pairs(timesteps, sampling_timesteps)):
+            out = unet_fn(x, torch.full((B,), t, dtype=torch.long))
+            nz = None if t_next < 0 else _t(noises[i])
+            x = ddim_step(sched, x, out, t, t_next, eta, nz, mixing_logit, clip_denoised)
+    else:
+        for i, t in enumerate(reversed(range(timesteps))):
+            out = unet_fn(x, torch.full((B,), t, dtype=torch.long))
+            x = p_sample_step(sched, x, out, t, _t(noises[i]), mixing_logit, clip_denoised)
+    return x
+
+
+# ======================================================================================
+# a8-a13  UNet
+# ======================================================================================
+
+def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tensor:
+    """util:150-170: cat(cos, sin) of t * exp(-ln(max_period) * k / half)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def silu(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)
+
+
+def group_norm(x: Tensor, w: Tensor, b: Tensor, eps: float, groups: int = 32) -> Tensor:
+    """util:198-215 (eps 1e-5) and ae:46-47 (eps 1e-6); fp32 statistics over (C/groups, spatial)."""
+    return F.group_norm(x.float(), groups, w, b, eps)
+
+
+def group_norm_explicit(x: Tensor, w: Tensor, b: Tensor, eps: float, groups: int = 32) -> Tensor:
+    """Spelled-out GroupNorm (biased variance), used to cross-check the torch op in the tests."""
+    B, C = x.shape[:2]
+    xg = x.reshape(B, groups, -1).double()
+    mean = xg.mean(-1, keepdim=True)
+    var = ((xg - mean) ** 2).mean(-1, keepdim=True)
+    y = ((xg - mean) / torch.sqrt(var + eps)).reshape(x.shape).float()
+    shape = (1, C) + (1,) * (x.dim() - 2)
+    return y * w.reshape(shape) + b.reshape(shape)
+
+
+def qkv_attention_legacy(qkv: Tensor, n_heads: int) -> Tensor:
+    """openai:397-422. qkv [B, H*3*ch, T] with per-head interleaved [q;k;v] channels."""
+    bs, width, length = qkv.shape
+    ch = width // (3 * n_heads)
+    q, k, v = qkv.reshape(bs * n_heads, ch * 3, length).split(ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    w = torch.softmax(w.float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v)
+    return a.reshape(bs, -1, length)
+
+
+def unet_resblock(p: State, pre: str, x: Tensor, emb: Tensor) -> Tensor:
+    """openai:244-276 (use_scale_shift_norm=False, no up/down, dropout 0)."""
+    h = F.conv2d(silu(group_norm(x, p[pre + "in_layers.0.weight"], p[pre + "in_layers.0.bias"], 1e-5)),
+                 p[pre + "in_layers.2.weight"], p[pre + "in_layers.2.bias"], padding=1)
+    e = F.linear(silu(emb), p[pre + "emb_layers.1.weight"], p[pre + "emb_layers.1.bias"])
+    h = h + e[:, :, None, None]
+    h = F.conv2d(silu(group_norm(h, p[pre + "out_layers.0.weight"], p[pre + "out_layers.0.bias"], 1e-5)),
+                 p[pre + "out_layers.3.weight"], p[pre + "out_layers.3.bias"], padding=1)
+    if (pre + "skip_connection.weight") in p:
+        x = F.conv2d(x, p[pre + "skip_connection.weight"], p[pre + "skip_connection.bias"])
+    return x + h
+
+
+def unet_attnblock(p: State, pre: str, x: Tensor, num_head_channels: int) -> Tensor:
+    """openai:319-325."""
+    b, c = x.shape[:2]
+    xf = x.reshape(b, c, -1)
+    qkv = F.conv1d(group_norm(xf, p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5),
+                   p[pre + "qkv.weight"], p[pre + "qkv.bias"])
+    h = qkv_attention_legacy(qkv, c // num_head_channels)
+    h = F.conv1d(h, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
+    return (xf + h).reshape(x.shape)
+
+
+def unet_topology(cfg: Mapping) -> Tuple[List[List[Tuple[str, int, int]]], List[List[Tuple[str, int, int]]], int]:
+    """Block lists that openai:567-743 constructs: for each input / output block a list of
+    (kind, cin, cout) with kind in {conv_in, res, attn, down, up}.  Returns (inputs, outputs, mid_ch)."""
+    mc = cfg["model_channels"]
+    mult = list(cfg.get("channel_mult", (1, 2, 4, 8)))
+    nrb = cfg["num_res_blocks"]
+    attn_res = set(cfg["attention_resolutions"])
+    inputs = [[("conv_in", cfg["in_channels"], mc)]]
+    chans = [mc]
+    ch, ds = mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nrb):
+            layers = [("res", ch, m * mc)]
+            ch = m * mc
+            if ds in attn_res:
+                layers.append(("attn", ch, ch))
+            inputs.append(layers)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inputs.append([("down", ch, ch)])
+            chans.append(ch)
+            ds *= 2
+    mid_ch = ch
+    outputs = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nrb + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, mc * m)]
+            ch = mc * m
+            if ds in attn_res:
+                layers.append(("attn", ch, ch))
+            if level and i == nrb:
+                layers.append(("up", ch, ch))
+                ds //= 2
+            outputs.append(layers)
+    return inputs, outputs, mid_ch
+
+
+def unet_forward(p: State, cfg: Mapping, x: Tensor, t: Tensor) -> Tensor:
+    """openai:761-793 for the configurations the DDMI yaml files use: 2-D, AttentionBlock with
+    QKVAttentionLegacy and num_head_channels, conv_resample=True, resblock_updown=False,
+    no class / context conditioning."""
+    x = _t(x)
+    nhc = cfg["num_head_channels"]
+    inputs, outputs, _ = unet_topology(cfg)
+    emb = timestep_embedding(t, cfg["model_channels"])
+    emb = F.linear(silu(F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])),
+                   p["time_embed.2.weight"], p["time_embed.2.bias"])
+
+    def run(layers, pre, h):
+        for j, (kind, cin, cout) in enumerate(layers):
+            q = f"{pre}{j}."
+            if kind == "conv_in":
+                h = F.conv2d(h, p[q + "weight"], p[q + "bias"], padding=1)
+            elif kind == "res":
+                h = unet_resblock(p, q, h, emb)
+            elif kind == "attn":
+                h = unet_attnblock(p, q, h, nhc)
+            elif kind == "down":  # openai:135-161
+                h = F.conv2d(h, p[q + "op.weight"], p[q + "op.bias"], stride=2, padding=1)
+            elif kind == "up":  # openai:110-120
+                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                h = F.conv2d(h, p[q + "conv.weight"], p[q + "conv.bias"], padding=1)
+        return h
+
+    hs = []
+    h = x
+    for i, layers in enumerate(inputs):
+        h = run(layers, f"input_blocks.{i}.", h)
+        hs.append(h)
+    h = run([("res", 0, 0), ("attn", 0, 0), ("res", 0, 0)], "middle_block.", h)
+    for i, layers in enumerate(outputs):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = run(layers, f"output_blocks.{i}.", h)
+    h = silu(group_norm(h, p["out.0.weight"], p["out.0.bias"], 1e-5))
+    return F.conv2d(h, p["out.2.weight"], p["out.2.bias"], padding=1)
+
+
+# ======================================================================================
+# a15  D2C-VAE image decoder
+# ======================================================================================
+
+def vae_resnet_block(p: State, pre: str, x: Tensor) -> Tensor:
+    """ae:129-149 with temb=None, dropout 0."""
+    h = F.conv2d(silu(group_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-6)),
+                 p[pre + "conv1.weight"], p[pre + "conv1.bias"], padding=1)
+    h = F.conv2d(silu(group_norm(h, p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-6)),
+                 p[pre + "conv2.weight"], p[pre + "conv2.bias"], padding=1)
+    if (pre + "nin_shortcut.weight") in p:
+        x = F.conv2d(x, p[pre + "nin_shortcut.weight"], p[pre + "nin_shortcut.bias"])
+    return x + h
+
+
+def vae_attn_block(p: State, pre: str, x: Tensor) -> Tensor:
+    """ae:187-215 with num_heads=1 (make_attn 'vanilla', ae:561-567): softmax over keys of q.k / sqrt(C)."""
+    b, c, hh, ww = x.shape
+    hn = group_norm(x, p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-6)
+    q = F.conv2d(hn, p[pre + "q.weight"], p[pre + "q.bias"]).reshape(b, c, -1)
+    k = F.conv2d(hn, p[pre + "k.weight"], p[pre + "k.bias"]).reshape(b, c, -1)
+    v = F.conv2d(hn, p[pre + "v.weight"], p[pre + "v.bias"]).reshape(b, c, -1)
+    w = torch.bmm(q.permute(0, 2, 1), k) * (int(c) ** (-0.5))  # [b, query, key]
+    w = torch.softmax(w, dim=2)
+    h = torch.bmm(v, w.permute(0, 2, 1)).reshape(b, c, hh, ww)  # h[c, query] = sum_key v[c,key] w[query,key]
+    h = F.conv2d(h, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
+    return x + h
+
+
+def vae_decode(p: State, ddconfig: Mapping, z: Tensor) -> List[Tensor]:
+    """Autoencoder.decode ae:855-858 + Decoder.forward ae:790-829 (attn_resolutions empty or not,
+    tanh_out False).  `p` holds the `Autoencoder` state dict (keys `post_quant_conv.*`, `decoder.*`).
+    Returns the HDBF plane list, coarse -> fine."""
+    z = _t(z)
+    ch_mult = list(ddconfig["ch_mult"])
+    nres = len(ch_mult)
+    nrb = ddconfig["num_res_blocks"]
+    attn_resolutions = set(ddconfig.get("attn_resolutions", []))
+    hdbf_resolutions = set(ddconfig["hdbf_resolutions"])
+    curr_res = ddconfig["resolution"] // 2 ** (nres - 1)
+    d = "decoder."
+    h = F.conv2d(z, p["post_quant_conv.weight"], p["post_quant_conv.bias"])
+    h = F.conv2d(h, p[d + "conv_in.weight"], p[d + "conv_in.bias"], padding=1)
+    h = vae_resnet_block(p, d + "mid.block_1.", h)
+    h = vae_attn_block(p, d + "mid.attn_1.", h)
+    h = vae_resnet_block(p, d + "mid.block_2.", h)
+    planes = []
+    for lvl in reversed(range(nres)):
+        for ib in range(nrb + 1):
+            h = vae_resnet_block(p, f"{d}up.{lvl}.block.{ib}.", h)
+            if curr_res in attn_resolutions:
+                h = vae_attn_block(p, f"{d}up.{lvl}.attn.{ib}.", h)
+        if curr_res in hdbf_resolutions:
+            planes.append(F.conv2d(h, p[f"{d}up.{lvl}.hdbf.0.weight"], p[f"{d}up.{lvl}.hdbf.0.bias"]))
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, p[f"{d}up.{lvl}.upsample.conv.weight"], p[f"{d}up.{lvl}.upsample.conv.bias"], padding=1)
+            curr_res *= 2
+    h = silu(group_norm(h, p[d + "norm_out.weight"], p[d + "norm_out.bias"], 1e-6))
+    planes.append(F.conv2d(h, p[d + "conv_out.weight"], p[d + "conv_out.bias"], padding=1))
+    return planes
+
+
+# ======================================================================================
+# a18-a20  coordinates, plane sampling, image coordinate-MLP
+# ======================================================================================
+
+def coord_grid_2d(h: int, w: int, hstart=-1.0, hend=1.0, wstart=-1.0, wend=1.0) -> Tensor:
+    """gu:27-35 for b=1 (square grids): channel 0 = x (varies along W), channel 1 = y."""
+    xs = torch.from_numpy(linspace_f32(wstart, wend, w)).view(1, 1, 1, -1).repeat(1, 1, w, 1)
+    ys = torch.from_numpy(linspace_f32(hstart, hend, h)).view(1, 1, -1, 1).repeat(1, 1, 1, h)
+    return torch.cat((xs, ys), dim=1)
+
+
+def generate_coords(res: int) -> Tensor:
+    """The grid `generate()` builds: tools/ldm/image.py:227-233."""
+    e = (res - 1) / res
+    return coord_grid_2d(res, res, -e, e, -e, e)
+
+
+def scale_injection(res: int, anchor: int = 256) -> float:
+    """gu:204-206."""
+    return anchor / res
+
+
+def bilinear_border(plane: Tensor, gx: Tensor, gy: Tensor, align_corners: bool) -> Tensor:
+    """F.grid_sample(plane, grid, mode='bilinear', padding_mode='border') restated.
+    plane [B,C,H,W]; gx, gy [B,N] normalised coords in [-1,1] -> [B,C,N]."""
+    B, C, H, W = plane.shape
+
+    def unnorm(g, size):
+        if align_corners:
+            return (g + 1) / 2 * (size - 1)
+        return ((g + 1) * size - 1) / 2
+
+    ix = unnorm(gx.float(), W).clamp(0, W - 1)
+    iy = unnorm(gy.float(), H).clamp(0, H - 1)
+    x0 = torch.floor(ix)
+    y0 = torch.floor(iy)
+    wx1 = ix - x0
+    wy1 = iy - y0
+    wx0 = 1 - wx1
+    wy0 = 1 - wy1
+    x0i = x0.long()
+    y0i = y0.long()
+    x1i = (x0i + 1).clamp(max=W - 1)
+    y1i = (y0i + 1).clamp(max=H - 1)
+    flat = plane.reshape(B, C, H * W)
+
+    def gather(yy, xx):
+        idx = (yy * W + xx)[:, None, :].expand(B, C, -1)
+        return torch.gather(flat, 2, idx)
+
+    return (gather(y0i, x0i) * (wy0 * wx0)[:, None] + gather(y0i, x1i) * (wy0 * wx1)[:, None]
+            + gather(y1i, x0i) * (wy1 * wx0)[:, None] + gather(y1i, x1i) * (wy1 * wx1)[:, None])
+
+
+def sinusoidal_pos_emb(x: Tensor, dim: int) -> Tensor:
+    """blocks:11-23: cat(sin, cos), divisor half-1."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half) * -e)
+    e = x[:, None] * e[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def mlp_style(p: State, si: float, ch: int = 256) -> Tensor:
+    """mlp:46-47 + mlp:18-25 for one sample: style = Linear(GELU(Linear(sinusoid(si))))."""
+    s = sinusoidal_pos_emb(torch.ones(1) * si, ch // 4)
+    s = F.gelu(F.linear(s, p["time_mlp.1.weight"], p["time_mlp.1.bias"]))
+    return F.linear(s, p["time_mlp.3.weight"], p["time_mlp.3.bias"])  # [1, ch]
+
+
+def modulated_weight(p: State, pre: str, style: Tensor, demodulate: bool) -> Tensor:
+    """blocks:242-250 for kernel_size 1 and one sample: returns W' [out, in]."""
+    w = p[pre + "weight"][0, :, :, 0, 0]  # [out, in]
+    out_ch, in_ch = w.shape
+    mw, mb = p[pre + "modulation.weight"], p[pre + "modulation.bias"]
+    s = F.linear(style, mw * (1 / math.sqrt(mw.shape[1])), mb)  # EqualLinear, lr_mul 1 (blocks:158-166)
+    wm = (1 / math.sqrt(in_ch)) * w * s.reshape(1, in_ch)
+    if demodulate:
+        wm = wm * torch.rsqrt(wm.pow(2).sum(1, keepdim=True) + 1e-8)
+    return wm
+
+
+def fused_lrelu(x: Tensor, bias: Tensor) -> Tensor:
+    """fba:26-47 with act=3 (leaky relu), grad=0, alpha 0.2, scale sqrt(2)."""
+    return F.leaky_relu(x + bias[None, :], 0.2) * math.sqrt(2)
+
+
+def styled_res_block(p: State, pre: str, x: Tensor, style: Tensor, noise: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """blocks:626-638 on per-point rows x [N, in]; noise[i] is the [N] NoiseInjection draw of conv i."""
+    out = x
+    for i, name in enumerate(("conv1.", "conv2.", "conv3.")):
+        w = modulated_weight(p, pre + name + "conv.", style, True)
+        out = out @ w.t()
+        nw = p[pre + name + "noise.weight"]
+        if noise is not None:
+            out = out + nw * noise[i][:, None]
+        out = fused_lrelu(out, p[pre + name + "activate.bias"])
+    if (pre + "skip.0.weight") in p:
+        ws = p[pre + "skip.0.weight"][:, :, 0, 0]
+        skip = x @ (ws * (1 / math.sqrt(ws.shape[1]))).t()  # EqualConv2d, bias=False (blocks:122-130, 544-546)
+    else:
+        skip = x
+    return (out + skip) / math.sqrt(2)
+
+
+def image_mlp(p: State, coords: Tensor, planes: Sequence[Tensor], si: float,
+              noise: Optional[Tensor] = None) -> Tensor:
+    """MLP.forward mlp:34-66 restated per query point with pre-folded modulated weights.
+    coords [1,2,R,R]; planes: 3 x [B,64,P,P]; noise optional [12,B,R*R] (the NoiseInjection draws in
+    call order, only matters when `noise.weight` != 0).  Returns [B,3,R,R]."""
+    coords = _t(coords)
+    B = planes[0].shape[0]
+    R_h, R_w = coords.shape[2:]
+    N = R_h * R_w
+    gx = coords[0, 0].reshape(1, N).expand(B, N)
+    gy = coords[0, 1].reshape(1, N).expand(B, N)
+    style = mlp_style(p, si)
+    feats = []
+    for pl in planes:
+        f = bilinear_border(_t(pl), gx, gy, align_corners=False)  # gu:122-123
+        f = f.permute(0, 2, 1).reshape(B * N, -1)
+        feats.append(torch.cat((f, torch.full((B * N, 2), float(si))), dim=1))  # mlp:44,51
+    nz = (lambda k: None) if noise is None else (lambda k: [_t(noise[3 * k + i]).reshape(B * N) for i in range(3)])
+    x = styled_res_block(p, "net_res1.", feats[0], style, nz(0))
+    x = styled_res_block(p, "net_res2.", torch.cat((x, feats[1]), dim=1), style, nz(1))
+    x = styled_res_block(p, "net_res3.", torch.cat((x, feats[2]), dim=1), style, nz(2))
+    x = styled_res_block(p, "net_res4.", x, style, nz(3))
+    w = modulated_weight(p, "torgb.conv.", style, False)  # blocks:398 demodulate=False
+    x = x @ w.t() + p["torgb.bias"].reshape(1, -1)
+    return x.reshape(B, R_h, R_w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# ======================================================================================
+# generate(): tools/ldm/image.py:225-249
+# ======================================================================================
+
+def generate(unet_p: State, unet_cfg: Mapping, vae_p: State, ddconfig: Mapping, mlp_p: State, sched,
+             mixing_logit, x_T, noises, timesteps: int, sampling_timesteps: int, eta: float, res: int) -> Dict[str, Tensor]:
+    z = sample_chain(lambda x, t: unet_forward(unet_p, unet_cfg, x, t), sched, x_T, noises,
+                     timesteps, sampling_timesteps, eta, mixing_logit)
+    planes = vae_decode(vae_p, ddconfig, z)
+    img = image_mlp(mlp_p, generate_coords(res), planes, scale_injection(res))
+    return {"z": z, "planes": planes, "img": img.clamp(-1.0, 1.0)}

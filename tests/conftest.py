@@ -1,0 +1,34 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    class G:
+        def npz(self, name):
+            return dict(np.load(os.path.join(GOLDEN, name)))
+
+        def json(self, name):
+            with open(os.path.join(GOLDEN, name)) as f:
+                return json.load(f)
+    return G()
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  -- the 'relative fp32 tolerance' used by every parity test."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

@@ -1,0 +1,158 @@
+"""The CPU oracle (oracle/ddmi_oracle.py) against vectors captured from the real reference
+(oracle/gen_golden.py -> tests/golden).  This is what pins the oracle; see SURVEY.md 8(c)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from ddmi_amd import initweights as iw
+from oracle import ddmi_oracle as O
+
+TOL = 2e-5  # fp32 re-association noise between two CPU implementations of the same math
+
+
+def state(golden, name, tag=None, overrides=None):
+    man = golden.json("manifests.json")[name]
+    st = iw.fill_state(tag or name, [(k, tuple(v)) for k, v in man.items()])
+    return O.to_state(st)
+
+
+def test_schedule_buffers_bitexact(golden):
+    s1 = golden.npz("S1_schedule.npz")
+    for T in (1000, 250, 10):
+        sched = O.make_schedule(T)
+        for k, v in sched.items():
+            ref = s1[f"T{T}.{k}"]
+            assert v.dtype == np.float32
+            # fp64 -> fp32 of identical formulae: identical bit patterns
+            assert np.array_equal(v.view(np.uint32), ref.view(np.uint32)), (T, k)
+
+
+def test_ddim_time_pairs_bitexact(golden):
+    pairs = golden.json("S1_time_pairs.json")
+    for key, ref in pairs.items():
+        T, S = map(int, key.split("_"))
+        assert [list(p) for p in O.ddim_time_pairs(T, S)] == ref, key
+
+
+def test_time_pairs_match_torch_linspace_everywhere():
+    # every S for T=1000 and a few other T: the integer schedule must be bit-exact (north star)
+    for T in (1000, 250, 100):
+        for S in range(1, T):
+            times = torch.linspace(-1, T - 1, steps=S + 1)
+            times = list(reversed(times.int().tolist()))
+            assert O.ddim_time_pairs(T, S) == list(zip(times[:-1], times[1:])), (T, S)
+
+
+def test_step_arithmetic(golden):
+    k1 = golden.npz("K1_step.npz")
+    x, mo, nz = (torch.from_numpy(k1[k]) for k in ("x", "model_out", "noise"))
+    logit = torch.from_numpy(k1["mixing_logit"])
+    for T in (1000, 250):
+        sched = O.make_schedule(T)
+        for t in (0, 1, T // 2, T - 2, T - 1):
+            out = O.p_sample_step(sched, x, mo, t, nz, logit)
+            assert rel_err(out, k1[f"anc.T{T}.t{t}"]) < 1e-6, (T, t)
+    sched = O.make_schedule(1000)
+    out = O.p_sample_step(sched, x, mo, 500, nz, logit, clip_denoised=True)
+    assert rel_err(out, k1["anc_clip.T1000.t500"]) < 1e-6
+    for eta in (0.0, 1.0, 0.5):
+        out = O.sample_chain(lambda xx, tt: mo, sched, x, [k1["ddim_n1"], k1["ddim_n2"]], 1000, 3, eta, logit)
+        assert rel_err(out, k1[f"ddim3.eta{eta}"]) < 1e-6, eta
+
+
+def test_unet_ops(golden):
+    u1 = golden.npz("U1_unet_ops.npz")
+    tt = torch.tensor([0, 1, 500, 999])
+    for dim in (224, 32):
+        assert rel_err(O.timestep_embedding(tt, dim), u1[f"temb{dim}"]) < 1e-6
+    x = torch.from_numpy(u1["x"])
+    p = state(golden, "U1.gn")
+    assert rel_err(O.group_norm(x, p["weight"], p["bias"], 1e-5), u1["gn"]) < TOL
+    assert rel_err(O.group_norm_explicit(x, p["weight"], p["bias"], 1e-5), u1["gn"]) < TOL
+    assert rel_err(O.silu(O.group_norm(x, p["weight"], p["bias"], 1e-5)), u1["gn_silu"]) < TOL
+    assert rel_err(O.qkv_attention_legacy(torch.from_numpy(u1["qkv"]), 2), u1["attn_legacy"]) < TOL
+    emb = torch.from_numpy(u1["emb"])
+    assert rel_err(O.unet_resblock(state(golden, "U1.res"), "", x, emb), u1["res"]) < TOL
+    assert rel_err(O.unet_resblock(state(golden, "U1.res_same"), "", x, emb), u1["res_same"]) < TOL
+    assert rel_err(O.unet_attnblock(state(golden, "U1.attn"), "", x, 32), u1["attn"]) < TOL
+    p = state(golden, "U1.down")
+    assert rel_err(torch.nn.functional.conv2d(x, p["op.weight"], p["op.bias"], stride=2, padding=1), u1["down"]) < TOL
+    p = state(golden, "U1.up")
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    assert rel_err(torch.nn.functional.conv2d(up, p["conv.weight"], p["conv.bias"], padding=1), u1["up"]) < TOL
+
+
+@pytest.mark.parametrize("name,cfgname", [("a", "TOY_UNET"), ("b", "TOY_UNET_B")])
+def test_unet_forward(golden, name, cfgname):
+    u2 = golden.npz("U2_unet.npz")
+    cfg = golden.json("configs.json")[cfgname]
+    p = state(golden, f"U2{name}.unet")
+    eps = O.unet_forward(p, cfg, torch.from_numpy(u2[f"{name}.x"]), torch.from_numpy(u2[f"{name}.t"]))
+    assert np.abs(u2[f"{name}.eps"]).max() > 0.1  # not the zero-init trap
+    assert rel_err(eps, u2[f"{name}.eps"]) < TOL
+
+
+def test_decoder(golden):
+    d1 = golden.npz("D1_decoder.npz")
+    cfg = golden.json("configs.json")["TOY_DD"]
+    planes = O.vae_decode(state(golden, "D1.vae"), cfg, torch.from_numpy(d1["z"]))
+    assert [tuple(p.shape[2:]) for p in planes] == [(8, 8), (16, 16), (32, 32)]
+    for i, pl in enumerate(planes):
+        assert rel_err(pl, d1[f"plane{i}"]) < TOL, i
+
+
+def test_plane_sampling_and_mlp(golden):
+    d1 = golden.npz("D1_decoder.npz")
+    m1 = golden.npz("M1_mlp.npz")
+    planes = [torch.from_numpy(d1[f"plane{i}"]) for i in range(3)]
+    g = torch.from_numpy(m1["grid"])
+    assert (g.abs() > 1).any()  # border clamp exercised
+    for i, pl in enumerate(planes):
+        got = O.bilinear_border(pl, g[..., 0].reshape(2, -1), g[..., 1].reshape(2, -1), align_corners=False)
+        assert rel_err(got.reshape(2, 64, 5, 7), m1[f"sample{i}"]) < TOL
+    p = state(golden, "M1.mlp")
+    for R in (32, 48, 8):
+        rgb = O.image_mlp(p, torch.from_numpy(m1[f"coords{R}"]), planes, float(m1[f"si{R}"]))
+        assert rel_err(rgb, m1[f"rgb{R}"]) < TOL, R
+        assert rel_err(O.generate_coords(R), m1[f"coords{R}"]) < 2e-7  # torch.linspace is SIMD-width dependent at 1 ulp
+        assert O.scale_injection(R) == float(m1[f"si{R}"])
+    # NoiseInjection with non-zero weights and explicit draws
+    man = golden.json("manifests.json")["M1n.mlp"]
+    st = iw.fill_state("M1n.mlp", [(k, tuple(v)) for k, v in man.items()])
+    for k in st:
+        if k.endswith("noise.weight"):
+            st[k] = iw.normal("M1n.mlp", k, st[k].shape, 0.0, 0.1)
+    draws = np.stack([iw.normal("M1n", f"draw{i}", (2, 1, 32, 32)).reshape(2, 32 * 32) for i in range(12)])
+    rgb = O.image_mlp(O.to_state(st), torch.from_numpy(m1["coords32"]), planes, float(m1["si32"]), noise=draws)
+    assert rel_err(rgb, m1["rgb32_noise"]) < TOL
+    assert rel_err(m1["rgb32_noise"], m1["rgb32"]) > 1e-3  # the noise path really changes the output
+
+
+def test_coords(golden):
+    c1 = golden.npz("C1_coords.npz")
+    # ATen's vectorised linspace evaluates base + lane*step per SIMD chunk, so the reference's own grid
+    # depends on the host's vector width at the 1-ulp level; the oracle uses the scalar formula.
+    for R in (4, 64, 256):
+        assert rel_err(O.generate_coords(R).numpy(), c1[f"grid{R}"]) < 2e-7
+    assert rel_err(O.coord_grid_2d(5, 5).numpy(), c1["grid5_default"]) < 2e-7
+
+
+@pytest.mark.parametrize("name,T,S,eta", [("ddim_eta0", 1000, 10, 0.0), ("ddim_eta1", 1000, 10, 1.0),
+                                          ("anc", 10, 10, 1.0), ("anc250", 250, 250, 1.0)])
+def test_generate_chain(golden, name, T, S, eta):
+    g1 = golden.npz("G1_generate.npz")
+    cfgs = golden.json("configs.json")
+    unet_p = state(golden, "U2a.unet")
+    logit = torch.from_numpy(iw.fill_state("G1.ddpm", [("mixing_logit", (1, 64, 1, 1))])["mixing_logit"])
+    shape = g1["x_T"].shape
+    ndraw = S - 1 if S < T else T
+    noises = [iw.normal("G1", f"{name}.n{i}", shape) for i in range(ndraw)]
+    sched = O.make_schedule(T)
+    z = O.sample_chain(lambda x, t: O.unet_forward(unet_p, cfgs["TOY_UNET"], x, t), sched, g1["x_T"], noises, T, S, eta, logit)
+    assert rel_err(z, g1[f"{name}.z"]) < 1e-4, name
+    if name == "anc250":
+        return
+    planes = O.vae_decode(state(golden, "D1.vae"), cfgs["TOY_DD"], z)
+    img = O.image_mlp(state(golden, "M1.mlp"), O.generate_coords(32), planes, O.scale_injection(32)).clamp(-1, 1)
+    assert rel_err(img, g1[f"{name}.img"]) < 1e-4
