@@ -1,0 +1,135 @@
+"""ctypes binding of libddmi_hip.so (include/ddmi_hip.h).  The product path has NO fallback:
+if the HIP library is missing or fails to load, importing a model class raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libddmi_hip.so")
+
+PARITY_FP32, PERF_BF16 = 0, 1
+LAYOUT_NCHW_F32, LAYOUT_NHWC_NATIVE = 0, 1
+STEP_ANCESTRAL, STEP_DDIM, STEP_DDIM_LAST = 0, 1, 2
+
+
+def numerics_code(name) -> int:
+    if name in (PARITY_FP32, "fp32", "parity", "PARITY_FP32"):
+        return PARITY_FP32
+    if name in (PERF_BF16, "bf16", "perf", "PERF_BF16"):
+        return PERF_BF16
+    raise ValueError(f"numerics must be 'fp32' (parity) or 'bf16' (perf), got {name!r}")
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("in_channels", C.c_int), ("model_channels", C.c_int),
+                ("out_channels", C.c_int), ("num_res_blocks", C.c_int), ("n_mult", C.c_int),
+                ("channel_mult", C.c_int * 8), ("n_attn", C.c_int), ("attention_resolutions", C.c_int * 8),
+                ("num_head_channels", C.c_int), ("max_batch", C.c_int), ("numerics", C.c_int)]
+
+
+class Decoder2dCfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("z_channels", C.c_int), ("resolution", C.c_int), ("out_ch", C.c_int),
+                ("ch", C.c_int), ("num_res_blocks", C.c_int), ("n_mult", C.c_int), ("ch_mult", C.c_int * 8),
+                ("n_attn", C.c_int), ("attn_resolutions", C.c_int * 8), ("n_hdbf", C.c_int),
+                ("hdbf_resolutions", C.c_int * 8), ("latent_size", C.c_int), ("max_batch", C.c_int),
+                ("numerics", C.c_int)]
+
+
+class Mlp2dCfg(C.Structure):
+    _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("ch", C.c_int), ("latent_dim", C.c_int),
+                ("numerics", C.c_int)]
+
+
+class StepCoefs(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("sqrt_one_minus_ac", "sqrt_recip_ac", "sqrt_recipm1_ac", "coef1", "coef2",
+                                         "noise_scale", "sqrt_ac_next", "c_dir", "sigma")]
+
+
+# every symbol include/ddmi_hip.h declares: name -> (restype, argtypes)
+_VP, _I, _F = C.c_void_p, C.c_int, C.c_float
+_I64P = C.POINTER(C.c_int64)
+SYMBOLS = {
+    "ddmi_init": (_I, [_I]),
+    "ddmi_last_error": (C.c_char_p, []),
+    "ddmi_version": (C.c_char_p, []),
+    "ddmi_unet_create": (_I, [C.POINTER(UnetCfg), C.POINTER(_VP)]),
+    "ddmi_unet_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_unet_finalize": (_I, [_VP]),
+    "ddmi_unet_forward": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    "ddmi_unet_destroy": (_I, [_VP]),
+    "ddmi_unet_memory": (_I, [_VP, C.POINTER(C.c_uint64 * 3)]),
+    "ddmi_ddpm_step": (_I, [_VP, _VP, _VP, _VP, C.POINTER(StepCoefs), _I, _I, _VP, _VP, _I, _I, _I, _VP]),
+    "ddmi_decoder2d_create": (_I, [C.POINTER(Decoder2dCfg), C.POINTER(_VP)]),
+    "ddmi_decoder2d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_decoder2d_finalize": (_I, [_VP]),
+    "ddmi_decoder2d_num_planes": (_I, [_VP, C.POINTER(_I), C.POINTER(_I * 8)]),
+    "ddmi_decoder2d_forward": (_I, [_VP, _VP, C.POINTER(_VP), _I, _I, _VP]),
+    "ddmi_decoder2d_destroy": (_I, [_VP]),
+    "ddmi_mlp2d_create": (_I, [C.POINTER(Mlp2dCfg), C.POINTER(_VP)]),
+    "ddmi_mlp2d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_mlp2d_finalize": (_I, [_VP]),
+    "ddmi_hdpe_mlp2d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _F, _VP, _VP, _I, _I, _VP]),
+    "ddmi_mlp2d_destroy": (_I, [_VP]),
+    "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),
+    "ddmi_op_attention_legacy": (_I, [_VP, _VP, _I, _I, _I, _I]),
+    "ddmi_op_timestep_embedding": (_I, [_VP, _VP, _I, _I]),
+}
+
+_lib: Optional[C.CDLL] = None
+_inited_devices = set()
+
+
+class DdmiError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises (loudly) when it has not been built - there is no CPU/torch fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DdmiError(f"{LIB_PATH} is missing: build it with `python -m ddmi_amd.build` "
+                            "(hipcc --offload-arch=gfx950); ddmi_amd has no fallback path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().ddmi_last_error()
+        raise DdmiError(f"ddmi_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def init_device(index: int) -> None:
+    if index not in _inited_devices:
+        check(lib().ddmi_init(index))
+        _inited_devices.add(index)
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def load_weights(load_fn, handle, state, prefix_strip: str = "", only_prefixes=None) -> int:
+    """Hands every fp32 tensor of a state-dict-like mapping to `load_fn(handle, key, ptr, shape, ndim)`."""
+    import numpy as np
+    n = 0
+    for key, val in state.items():
+        if only_prefixes is not None and not any(key.startswith(p) for p in only_prefixes):
+            continue
+        k = key[len(prefix_strip):] if prefix_strip and key.startswith(prefix_strip) else key
+        if hasattr(val, "detach"):
+            val = val.detach().float().cpu().numpy()
+        arr = np.ascontiguousarray(np.asarray(val, dtype=np.float32))
+        shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+        check(load_fn(handle, k.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+        n += 1
+    return n

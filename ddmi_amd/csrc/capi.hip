@@ -1,0 +1,263 @@
+// extern "C" surface of libddmi_hip.so (declared in include/ddmi_hip.h).
+#include <cstring>
+#include <new>
+#include "models.h"
+
+const char* ddmi_error_cstr();
+
+struct ddmi_unet { UNet u; };
+struct ddmi_decoder2d { Decoder2d d; };
+struct ddmi_mlp2d { Mlp2d m; };
+
+static int numerics_to_dt(int numerics, int* dt) {
+  if (numerics == DDMI_PARITY_FP32) { *dt = DT_F32; return DDMI_OK; }
+  if (numerics == DDMI_PERF_BF16) { *dt = DT_BF16; return DDMI_OK; }
+  return ddmi_fail(DDMI_ERR_INVALID, "numerics must be DDMI_PARITY_FP32 (0) or DDMI_PERF_BF16 (1)");
+}
+
+extern "C" {
+
+const char* ddmi_last_error(void) { return ddmi_error_cstr(); }
+const char* ddmi_version(void) { return "ddmi_hip 0.1 (gfx950)"; }
+
+int ddmi_init(int device) {
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  DDMI_REQUIRE(device >= 0 && device < n, "ddmi_init: no such device");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+    return ddmi_fail(DDMI_ERR_INVALID, std::string("ddmi_init: this library is built for gfx950 only, device is ") + p.gcnArchName);
+  return DDMI_OK;
+}
+
+// ---- UNet -----------------------------------------------------------------------------------------------
+int ddmi_unet_create(const ddmi_unet_cfg* cfg, ddmi_unet** out) {
+  DDMI_REQUIRE(cfg && out, "unet_create: null argument");
+  DDMI_REQUIRE(cfg->max_batch >= 1, "unet_create: max_batch must be >= 1");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_unet* h = new (std::nothrow) ddmi_unet();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->u.cfg = *cfg;
+  h->u.net.dt = dt;
+  h->u.net.max_batch = cfg->max_batch;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_unet_load_weight(ddmi_unet* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h, "null handle");
+  return h->u.net.add_host(key, data, shape, ndim);
+}
+int ddmi_unet_finalize(ddmi_unet* h) {
+  DDMI_REQUIRE(h, "null handle");
+  if (h->u.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "already finalized");
+  return unet_finalize(h->u);
+}
+int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps_out, int B, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return unet_forward(h->u, x, t, eps_out, B, (hipStream_t)stream);
+}
+int ddmi_unet_destroy(ddmi_unet* h) {
+  delete h;
+  return DDMI_OK;
+}
+int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]) {
+  DDMI_REQUIRE(h && out, "null argument");
+  out[0] = h->u.net.weight_bytes;
+  out[1] = h->u.net.arena_bytes;
+  out[2] = h->u.net.splitk_bytes;
+  return DDMI_OK;
+}
+
+// ---- sampler step ---------------------------------------------------------------------------------------
+int ddmi_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
+                   const ddmi_step_coefs* c, int mode, int clip_denoised, float* x_out, float* x0_out, int B, int C,
+                   int HW, void* stream) {
+  DDMI_REQUIRE(c, "ddpm_step: null coefs");
+  StepCoefs k;
+  k.sqrt_one_minus_ac = c->sqrt_one_minus_ac;
+  k.sqrt_recip_ac = c->sqrt_recip_ac;
+  k.sqrt_recipm1_ac = c->sqrt_recipm1_ac;
+  k.coef1 = c->coef1;
+  k.coef2 = c->coef2;
+  k.noise_scale = c->noise_scale;
+  k.sqrt_ac_next = c->sqrt_ac_next;
+  k.c_dir = c->c_dir;
+  k.sigma = c->sigma;
+  return launch_ddpm_step(x, model_out, noise, mixing_logit, k, mode, clip_denoised, x_out, x0_out, B, C, HW,
+                          (hipStream_t)stream);
+}
+
+// ---- decoder ----------------------------------------------------------------------------------------------
+int ddmi_decoder2d_create(const ddmi_decoder2d_cfg* cfg, ddmi_decoder2d** out) {
+  DDMI_REQUIRE(cfg && out, "decoder2d_create: null argument");
+  DDMI_REQUIRE(cfg->max_batch >= 1, "decoder2d_create: max_batch must be >= 1");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_decoder2d* h = new (std::nothrow) ddmi_decoder2d();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->d.cfg = *cfg;
+  h->d.net.dt = dt;
+  h->d.net.max_batch = cfg->max_batch;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_decoder2d_load_weight(ddmi_decoder2d* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h, "null handle");
+  return h->d.net.add_host(key, data, shape, ndim);
+}
+int ddmi_decoder2d_finalize(ddmi_decoder2d* h) {
+  DDMI_REQUIRE(h, "null handle");
+  if (h->d.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "already finalized");
+  return decoder2d_finalize(h->d);
+}
+int ddmi_decoder2d_num_planes(ddmi_decoder2d* h, int* n, int plane_hw[8]) {
+  DDMI_REQUIRE(h && n && plane_hw, "null argument");
+  if (!h->d.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "decoder not finalized");
+  *n = h->d.n_planes;
+  for (int i = 0; i < h->d.n_planes; ++i) plane_hw[i] = h->d.plane_hw[i];
+  return DDMI_OK;
+}
+int ddmi_decoder2d_forward(ddmi_decoder2d* h, const float* z, void* const* planes, int layout, int B, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return decoder2d_forward(h->d, z, planes, layout, B, (hipStream_t)stream);
+}
+int ddmi_decoder2d_destroy(ddmi_decoder2d* h) {
+  delete h;
+  return DDMI_OK;
+}
+
+// ---- fused plane sampling + MLP ---------------------------------------------------------------------------
+int ddmi_mlp2d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp2d** out) {
+  DDMI_REQUIRE(cfg && out, "mlp2d_create: null argument");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_mlp2d* h = new (std::nothrow) ddmi_mlp2d();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->m.cfg = *cfg;
+  h->m.dt = dt;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_mlp2d_load_weight(ddmi_mlp2d* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h && key && data && ndim >= 0 && ndim <= 8, "mlp2d_load_weight: bad arguments");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  h->m.host[key] = std::move(t);
+  h->m.have_cache = false;
+  return DDMI_OK;
+}
+int ddmi_mlp2d_finalize(ddmi_mlp2d* h) {
+  DDMI_REQUIRE(h, "null handle");
+  return mlp2d_finalize(h->m);
+}
+int ddmi_hdpe_mlp2d(ddmi_mlp2d* h, const void* const* planes, const int* plane_hw, int layout, const float* coords,
+                    float si, const float* noise, float* rgb_out, int B, int N, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return mlp2d_forward(h->m, planes, plane_hw, layout, coords, si, noise, rgb_out, B, N, (hipStream_t)stream);
+}
+int ddmi_mlp2d_destroy(ddmi_mlp2d* h) {
+  delete h;
+  return DDMI_OK;
+}
+
+// ---- diagnostic single-op entry points ----------------------------------------------------------------------
+struct Scratch {
+  std::vector<void*> p;
+  ~Scratch() {
+    for (void* q : p) (void)hipFree(q);
+  }
+  int get(size_t bytes, void** out) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, bytes ? bytes : 16));
+    p.push_back(q);
+    *out = q;
+    return DDMI_OK;
+  }
+};
+
+int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                   int k, int stride, int upsample, int numerics, int splitk) {
+  int dt;
+  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  DDMI_REQUIRE(x && w && y, "op_conv2d: null tensor");
+  Scratch sc;
+  void *xn, *wp, *yn, *ws = nullptr;
+  int hin = upsample ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
+  int Ho = (hin + 2 * pad - k) / stride + 1, Wo = (win + 2 * pad - k) / stride + 1;
+  DDMI_TRY(sc.get((size_t)B * Cin * H * W * dt_size(dt), &xn));
+  DDMI_TRY(sc.get((size_t)Cout * Cin * k * k * dt_size(dt), &wp));
+  DDMI_TRY(sc.get((size_t)B * Cout * Ho * Wo * dt_size(dt), &yn));
+  DDMI_TRY(launch_nchw_to_nhwc(x, xn, dt, B, Cin, H * W, 0));
+  DDMI_TRY(launch_pack_conv_weight(w, wp, dt, Cout, Cin, k, k, 0));
+  ConvArgs a{};
+  a.x = xn; a.w = wp; a.bias = bias; a.y = yn;
+  a.B = B; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout;
+  a.KH = a.KW = k; a.stride = stride; a.pad = pad; a.ups = upsample; a.out_scale = 1.f;
+  a.splitk = splitk > 0 ? splitk : conv_pick_splitk(a, dt);
+  if (a.splitk > 1) {
+    DDMI_TRY(sc.get((size_t)a.splitk * B * Ho * Wo * Cout * sizeof(float), &ws));
+    a.splitk_ws = (float*)ws;
+  }
+  DDMI_TRY(launch_conv(a, dt, 0));
+  DDMI_TRY(launch_nhwc_to_nchw(yn, dt, y, B, Cout, Ho * Wo, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
+int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
+                      int silu, int numerics) {
+  int dt;
+  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  Scratch sc;
+  void *xn, *yn, *st;
+  DDMI_TRY(sc.get((size_t)B * C * HW * dt_size(dt), &xn));
+  DDMI_TRY(sc.get((size_t)B * C * HW * dt_size(dt), &yn));
+  DDMI_TRY(sc.get((size_t)B * 64 * sizeof(double), &st));
+  DDMI_TRY(launch_nchw_to_nhwc(x, xn, dt, B, C, HW, 0));
+  HIP_TRY(hipMemsetAsync(st, 0, (size_t)B * 64 * sizeof(double), 0));
+  DDMI_TRY(launch_gn_stats(xn, dt, (double*)st, B, HW, C, 0));
+  DDMI_TRY(launch_gn_apply(xn, yn, dt, (const double*)st, gamma, beta, eps, silu, B, HW, C, 0));
+  DDMI_TRY(launch_nhwc_to_nchw(yn, dt, y, B, C, HW, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
+int ddmi_op_attention_legacy(const float* qkv, float* out, int B, int heads, int T, int numerics) {
+  int dt;
+  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  Scratch sc;
+  void *qn, *on;
+  int C3 = heads * 96, C = heads * 32;
+  DDMI_TRY(sc.get((size_t)B * C3 * T * dt_size(dt), &qn));
+  DDMI_TRY(sc.get((size_t)B * C * T * dt_size(dt), &on));
+  DDMI_TRY(launch_nchw_to_nhwc(qkv, qn, dt, B, C3, T, 0));
+  DDMI_TRY(launch_attention_legacy(qn, on, dt, B, T, heads, 0));
+  DDMI_TRY(launch_nhwc_to_nchw(on, dt, out, B, C, T, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
+int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim) {
+  DDMI_REQUIRE(dim >= 2, "timestep_embedding: dim too small");
+  int half = dim / 2;
+  std::vector<float> fr(half);
+  const float neg_log = (float)(-std::log(10000.0));
+  for (int i = 0; i < half; ++i) {
+    volatile float a = neg_log * (float)i;
+    volatile float q = a / (float)half;
+    fr[i] = std::exp((float)q);
+  }
+  Scratch sc;
+  void* f;
+  DDMI_TRY(sc.get(half * sizeof(float), &f));
+  HIP_TRY(hipMemcpy(f, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  DDMI_TRY(launch_timestep_embedding(t, (const float*)f, out, B, dim, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
+}  // extern "C"

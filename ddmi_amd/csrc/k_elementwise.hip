@@ -1,0 +1,324 @@
+// HBM-bound elementwise / layout kernels: fused DDPM-DDIM step, NCHW<->NHWC, concat, weight packing,
+// timestep embedding and the small fp32 dense layers of the time-embedding path.
+#include "kernels.h"
+
+// =====================================================================================================
+// Fused eps-mix -> x0 -> x_{t-1} step.  Replaces diffusion/ddpm.py:257-281 (p_mean_variance + p_sample) and
+// ddpm.py:303-332,353-368 (model_predictions + DDIM update) with one pass: reads x, model_out, noise (16 B/elem
+// algorithmic traffic with the write), keeps everything in registers.
+// Layout NCHW fp32 (the sampler state keeps the reference's layout); mixing_logit is [C].
+// =====================================================================================================
+template <int VEC>
+__global__ void __launch_bounds__(256) ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ mo,
+                                                        const float* __restrict__ noise,
+                                                        const float* __restrict__ logit, StepCoefs k, int mode, int clip,
+                                                        float* __restrict__ out, float* __restrict__ x0_out, int C, int HW,
+                                                        int64_t nvec) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    int64_t e0 = i * VEC;
+    float xv[VEC], mv[VEC], nv[VEC], ov[VEC], zv[VEC];
+    if (VEC == 4) {
+      float4 a = *reinterpret_cast<const float4*>(x + e0);
+      float4 b = *reinterpret_cast<const float4*>(mo + e0);
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+      mv[0] = b.x; mv[1] = b.y; mv[2] = b.z; mv[3] = b.w;
+      if (noise != nullptr && mode != STEP_DDIM_LAST) {
+        float4 c = *reinterpret_cast<const float4*>(noise + e0);
+        nv[0] = c.x; nv[1] = c.y; nv[2] = c.z; nv[3] = c.w;
+      } else {
+        nv[0] = nv[1] = nv[2] = nv[3] = 0.f;
+      }
+    } else {
+      xv[0] = x[e0];
+      mv[0] = mo[e0];
+      nv[0] = (noise != nullptr && mode != STEP_DDIM_LAST) ? noise[e0] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float eps = mv[j];
+      if (logit != nullptr) {
+        int c = (int)(((e0 + j) / HW) % C);
+        float coeff = 1.0f / (1.0f + expf(-logit[c]));
+        float mix = k.sqrt_one_minus_ac * xv[j];
+        eps = (1.0f - coeff) * mix + coeff * mv[j];
+      }
+      float x0 = k.sqrt_recip_ac * xv[j] - k.sqrt_recipm1_ac * eps;
+      if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      float r;
+      if (mode == STEP_ANCESTRAL) {
+        float mean = k.coef1 * x0 + k.coef2 * xv[j];
+        r = mean + k.noise_scale * nv[j];
+      } else if (mode == STEP_DDIM) {
+        r = x0 * k.sqrt_ac_next + k.c_dir * eps + k.sigma * nv[j];
+      } else {
+        r = x0;
+      }
+      ov[j] = r;
+      zv[j] = x0;
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      if (x0_out) *reinterpret_cast<float4*>(x0_out + e0) = make_float4(zv[0], zv[1], zv[2], zv[3]);
+    } else {
+      out[e0] = ov[0];
+      if (x0_out) x0_out[e0] = zv[0];
+    }
+  }
+}
+
+int launch_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
+                     StepCoefs k, int mode, int clip, float* x_out, float* x0_out, int B, int C, int HW,
+                     hipStream_t stream) {
+  DDMI_REQUIRE(x && model_out && x_out, "ddpm_step: null tensor");
+  DDMI_REQUIRE(mode >= 0 && mode <= 2, "ddpm_step: bad mode");
+  DDMI_REQUIRE(B > 0 && C > 0 && HW > 0, "ddpm_step: bad shape");
+  int64_t n = (int64_t)B * C * HW;
+  bool vec4 = (HW % 4 == 0) && (((uintptr_t)x | (uintptr_t)model_out | (uintptr_t)noise | (uintptr_t)x_out |
+                                 (uintptr_t)x0_out) % 16 == 0);
+  int64_t nvec = vec4 ? n / 4 : n;
+  int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 8);
+  if (vec4)
+    hipLaunchKernelGGL(ddpm_step_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, mixing_logit, k,
+                       mode, clip, x_out, x0_out, C, HW, nvec);
+  else
+    hipLaunchKernelGGL(ddpm_step_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, mixing_logit, k,
+                       mode, clip, x_out, x0_out, C, HW, nvec);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// =====================================================================================================
+// NCHW fp32 <-> NHWC T through a 32x32 LDS tile (both sides coalesced)
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C,
+                                                           int HW) {
+  __shared__ float tile[32][33];
+  int b = blockIdx.z;
+  int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* s = src + (int64_t)b * C * HW;
+  T* d = dst + (int64_t)b * C * HW;
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, p = p0 + tx;
+    tile[i][tx] = (c < C && p < HW) ? s[(int64_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int p = p0 + i, c = c0 + tx;
+    if (p < HW && c < C) d[(int64_t)p * C + c] = from_f32<T>(tile[tx][i]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int HW) {
+  __shared__ float tile[32][33];
+  int b = blockIdx.z;
+  int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const T* s = src + (int64_t)b * C * HW;
+  float* d = dst + (int64_t)b * C * HW;
+  for (int i = ty; i < 32; i += 8) {
+    int p = p0 + i, c = c0 + tx;
+    tile[i][tx] = (c < C && p < HW) ? to_f32(s[(int64_t)p * C + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, p = p0 + tx;
+    if (p < HW && c < C) d[(int64_t)c * HW + p] = tile[tx][i];
+  }
+}
+
+int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int HW, hipStream_t s) {
+  dim3 g(cdiv(HW, 32), cdiv(C, 32), B);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, dim3(256), 0, s, src, (float*)dst, C, HW);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, dim3(256), 0, s, src, (bf16_t*)dst, C, HW);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s) {
+  dim3 g(cdiv(HW, 32), cdiv(C, 32), B);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, dim3(256), 0, s, (const float*)src, dst, C, HW);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, dst, C, HW);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// =====================================================================================================
+// channel concat of two NHWC tensors: out[p][0:Ca] = a[p], out[p][Ca:Ca+Cb] = b[p]   (16-byte vectors)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) concat_kernel(const uint4* __restrict__ a, int va, const uint4* __restrict__ b,
+                                                     int vb, uint4* __restrict__ out, int64_t nvec) {
+  int vo = va + vb;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    int64_t p = i / vo;
+    int v = (int)(i - p * vo);
+    out[i] = v < va ? a[p * va + v] : b[p * vb + (v - va)];
+  }
+}
+
+int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int dt, int64_t npix, hipStream_t s) {
+  int per = dt == DT_F32 ? 4 : 8;
+  DDMI_REQUIRE(Ca % per == 0 && Cb % per == 0, "concat: channels must be multiples of the 16-byte vector");
+  int va = Ca / per, vb = Cb / per;
+  int64_t nvec = npix * (va + vb);
+  int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 16);
+  hipLaunchKernelGGL(concat_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)a, va, (const uint4*)b, vb,
+                     (uint4*)out, nvec);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// =====================================================================================================
+// conv weight packing: [Cout][Cin][KH][KW] fp32 -> [Cout][(kh*KW+kw)*Cin + ci] T   (done once at finalize)
+// =====================================================================================================
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
+                                        int KW) {
+  int64_t n = (int64_t)Cout * Cin * KH * KW;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int taps = KH * KW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int ci = (int)(i % Cin);
+    int64_t r = i / Cin;
+    int tap = (int)(r % taps);
+    int co = (int)(r / taps);
+    out[i] = from_f32<T>(w[((int64_t)co * Cin + ci) * taps + tap]);
+  }
+}
+
+int launch_pack_conv_weight(const float* w, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s) {
+  int64_t n = (int64_t)Cout * Cin * KH * KW;
+  int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)packed, Cout, Cin, KH, KW);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)packed, Cout, Cin, KH, KW);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = from_f32<T>(src[i]);
+}
+
+int launch_cast_f32(const float* src, void* dst, int dt, int64_t n, hipStream_t s) {
+  int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, n);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// =====================================================================================================
+// timestep embedding (util.py:150-170): out[b] = [cos(t*f_k) | sin(t*f_k)], f_k precomputed on the host
+// =====================================================================================================
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
+                                          float* __restrict__ out, int dim) {
+  int b = blockIdx.x;
+  int half = dim / 2;
+  float tv = (float)t[b];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    float a = tv * freqs[i];
+    out[(int64_t)b * dim + i] = cosf(a);
+    out[(int64_t)b * dim + half + i] = sinf(a);
+  }
+  if ((dim & 1) && threadIdx.x == 0) out[(int64_t)b * dim + dim - 1] = 0.f;
+}
+
+int launch_timestep_embedding(const int64_t* t, const float* freqs, float* out, int B, int dim, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(128), 0, s, t, freqs, out, dim);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// =====================================================================================================
+// small dense layer, M = batch rows (<= 64): one wave per output feature streams W[n][:] once (coalesced,
+// weight-read bound) and keeps the B activations rows in LDS.  fp32 throughout.
+// =====================================================================================================
+#define LIN_MAXB 8
+__global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ x, int x_stride,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int y_stride, int B, int K, int N,
+                                                           int silu_in) {
+  extern __shared__ float xs[];  // [bb][K]
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < B; b0 += LIN_MAXB) {
+    int nb = min(LIN_MAXB, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * K; i += blockDim.x) {
+      int bb = i / K, kk = i - bb * K;
+      float v = x[(int64_t)(b0 + bb) * x_stride + kk];
+      xs[i] = silu_in ? silu_precise(v) : v;
+    }
+    __syncthreads();
+    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+      float acc[LIN_MAXB];
+#pragma unroll
+      for (int j = 0; j < LIN_MAXB; ++j) acc[j] = 0.f;
+      const float* wr = W + (int64_t)n * K;
+      for (int kk = lane; kk < K; kk += 64) {
+        float wv = wr[kk];
+#pragma unroll
+        for (int j = 0; j < LIN_MAXB; ++j)
+          if (j < nb) acc[j] += wv * xs[j * K + kk];
+      }
+#pragma unroll
+      for (int j = 0; j < LIN_MAXB; ++j) {
+        float v = acc[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && j < nb) y[(int64_t)(b0 + j) * y_stride + n] = v + (bias ? bias[n] : 0.f);
+      }
+    }
+  }
+}
+
+int launch_linear_small(const float* x, int x_stride, const float* W, const float* bias, float* y, int y_stride, int B,
+                        int K, int N, int silu_in, hipStream_t s) {
+  DDMI_REQUIRE(K * LIN_MAXB * 4 <= 64 * 1024, "linear_small: K too large for LDS staging");
+  int blocks = std::min(cdiv(N, 4), 2048);
+  size_t lds = (size_t)std::min(B, LIN_MAXB) * K * sizeof(float);
+  hipLaunchKernelGGL(linear_small_kernel, dim3(blocks), dim3(256), lds, s, x, x_stride, W, bias, y, y_stride, B, K, N,
+                     silu_in);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// =====================================================================================================
+// nearest x2 upsample (only used by the diagnostic op API; the networks fuse it into the conv gather)
+// =====================================================================================================
+__global__ void upsample2x_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int H, int W, int vc) {
+  int64_t n = (int64_t)B * 2 * H * 2 * W * vc;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int v = (int)(i % vc);
+    int64_t p = i / vc;
+    int ow = (int)(p % (2 * W));
+    int64_t q = p / (2 * W);
+    int oh = (int)(q % (2 * H));
+    int b = (int)(q / (2 * H));
+    dst[i] = src[(((int64_t)b * H + (oh >> 1)) * W + (ow >> 1)) * vc + v];
+  }
+}
+
+int launch_upsample2x(const void* src, void* dst, int dt, int B, int H, int W, int C, hipStream_t s) {
+  int per = dt == DT_F32 ? 4 : 8;
+  DDMI_REQUIRE(C % per == 0, "upsample2x: channels must be a multiple of the 16-byte vector");
+  int64_t n = (int64_t)B * 4 * H * W * (C / per);
+  int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, B, H, W, C / per);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

@@ -1,0 +1,393 @@
+// Fused HDPE plane sampling + image coordinate-MLP (replaces models/d2c_vae/mlp.py:34-66 at inference).
+//
+// One workgroup = 4 waves = a tile of P query points that never leaves the CU:
+//   gather   : bilinear (align_corners=False, border) sample of the three 64-channel planes (NHWC, so one texel is one
+//              contiguous 128/256-byte row: coalesced 16-byte loads, 8 or 16 lanes per texel) -> LDS feature tiles
+//   15 dense layers of width 256 on MFMA, activations ping-ponging between two LDS buffers [P][256];
+//              the StyleGAN2 modulation/demodulation is pre-folded into the weights on the host because the style
+//              depends only on the scalar scale-injection `si` (mlp.py:46-47), and the two constant `si` input
+//              channels are folded into the biases;
+//              FusedLeakyReLU (op/fused_bias_act_kernel.cu:19-49: lrelu(x+b, 0.2)*sqrt2), NoiseInjection
+//              (blocks.py:286-297) and the (out+skip)/sqrt2 residual are epilogues on the accumulators;
+//   ToRGB    : 256 -> 3 on MFMA (rows padded to 16), written straight to the [B,3,N] output.
+// Wave w owns output channels [64w, 64w+64) of every layer for all P points, so its weight fragments are private and
+// stream straight from L2 into registers (all folded weights are 1.9 MB bf16: L2-resident), while the activations
+// are shared through LDS.  The skip path of a block (a second GEMM on the block input) accumulates in registers
+// next to conv1 and is merged in the conv3 epilogue; for block 4 (identity skip) the same registers carry x3.
+#include "kernels.h"
+
+#define MLP_CH 256
+#define MLP_F 64
+
+// packed weight matrices, in execution order; K (input width) per matrix
+//  0 b1.conv1(64) 1 b1.skip(64) 2 b1.conv2 3 b1.conv3 | 4 b2.conv1(320) 5 b2.skip(320) 6 b2.conv2 7 b2.conv3
+//  8 b3.conv1(320) 9 b3.skip(320) 10 b3.conv2 11 b3.conv3 | 12 b4.conv1 13 b4.conv2 14 b4.conv3 | 15 torgb (16 rows)
+__host__ __device__ constexpr int mlp_w_k(int i) {
+  return (i == 0 || i == 1) ? 64 : (i == 4 || i == 5 || i == 8 || i == 9) ? 320 : 256;
+}
+__host__ __device__ constexpr int mlp_w_rows(int i) { return i == 15 ? 16 : 256; }
+__host__ __device__ constexpr int mlp_w_off(int i) {
+  int o = 0;
+  for (int j = 0; j < i; ++j) o += mlp_w_rows(j) * mlp_w_k(j);
+  return o;
+}
+size_t mlp2d_weight_elems() { return (size_t)mlp_w_off(16); }
+// fp32 constants: 12 activation biases [256] (conv order b1.c1,c2,c3,b2.c1,...), 3 skip constants [256], rgb bias [4]
+#define MLP_FB_BIAS(i) ((i) * 256)
+#define MLP_FB_SKIP(k) (12 * 256 + (k) * 256)
+#define MLP_FB_RGB (15 * 256)
+size_t mlp2d_fb_elems() { return 15 * 256 + 4; }
+
+template <typename T> struct MlpL;
+template <> struct MlpL<bf16_t> {
+  static constexpr int P = 64;
+  static constexpr int XP = 272;  // X row pitch in elements (544 B): ds_read_b128 fragment reads are conflict-free
+  static constexpr int FP = 72;
+};
+template <> struct MlpL<float> {
+  static constexpr int P = 64;
+  static constexpr int XP = 260;
+  static constexpr int FP = 68;
+};
+
+struct MlpK {
+  const void* planes[3];
+  int hw[3];
+  const float* coords;
+  const void* w;
+  const float* fb;
+  const float* noise;
+  const float* noise_w;
+  float* rgb;
+  int B, N;
+  int64_t total;  // B*N
+};
+
+// ---- bilinear gather of one plane into F[P][FP] ---------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void gather_plane(const MlpK& a, int pl, int64_t tile0, T* F) {
+  constexpr int P = MlpL<T>::P, FP = MlpL<T>::FP;
+  constexpr int EPS = sizeof(T) == 2 ? 8 : 4;
+  constexpr int CG = MLP_F / EPS;  // channel groups per point
+  const int S = a.hw[pl];
+  const T* plane = (const T*)a.planes[pl];
+  for (int it = threadIdx.x; it < P * CG; it += 256) {
+    int pi = it / CG, cg = it - pi * CG;
+    int64_t gp = tile0 + pi;
+    float v[EPS];
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) v[e] = 0.f;
+    if (gp < a.total) {
+      int b = (int)(gp / a.N);
+      int p = (int)(gp - (int64_t)b * a.N);
+      float gx = a.coords[2 * p], gy = a.coords[2 * p + 1];
+      // F.grid_sample: unnormalise (align_corners=False), clip to border, bilinear corners
+      float ix = ((gx + 1.f) * S - 1.f) * 0.5f, iy = ((gy + 1.f) * S - 1.f) * 0.5f;
+      ix = fminf(fmaxf(ix, 0.f), (float)(S - 1));
+      iy = fminf(fmaxf(iy, 0.f), (float)(S - 1));
+      float x0f = floorf(ix), y0f = floorf(iy);
+      float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      int x0 = (int)x0f, y0 = (int)y0f;
+      int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);
+      const T* base = plane + (int64_t)b * S * S * MLP_F + cg * EPS;
+      const T* p00 = base + ((int64_t)y0 * S + x0) * MLP_F;
+      const T* p01 = base + ((int64_t)y0 * S + x1) * MLP_F;
+      const T* p10 = base + ((int64_t)y1 * S + x0) * MLP_F;
+      const T* p11 = base + ((int64_t)y1 * S + x1) * MLP_F;
+      float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 t00 = *reinterpret_cast<const bf16x8*>(p00), t01 = *reinterpret_cast<const bf16x8*>(p01);
+        bf16x8 t10 = *reinterpret_cast<const bf16x8*>(p10), t11 = *reinterpret_cast<const bf16x8*>(p11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = (float)t00[e] * w00 + (float)t01[e] * w01 + (float)t10[e] * w10 + (float)t11[e] * w11;
+      } else {
+        f32x4 t00 = *reinterpret_cast<const f32x4*>(p00), t01 = *reinterpret_cast<const f32x4*>(p01);
+        f32x4 t10 = *reinterpret_cast<const f32x4*>(p10), t11 = *reinterpret_cast<const f32x4*>(p11);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t00[e] * w00 + t01[e] * w01 + t10[e] * w10 + t11[e] * w11;
+      }
+    }
+    T* dst = F + pi * FP + cg * EPS;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(dst) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+// ---- one GEMM pass: acc[mf][nf] (+)= W[n][k] * IN[m][k], k over KX channels of X then KF channels of F ----
+//   wave-private weight rows n = nbase + 16*nf + (lane&15); optional second matrix W2 -> acc2 (skip path)
+template <typename T, int MF, int NF, int KX, int KF, bool DUAL>
+__device__ __forceinline__ void gemm_pass(const T* __restrict__ X, const T* __restrict__ F, const T* __restrict__ W,
+                                          const T* __restrict__ W2, int nbase, int m_first, f32x4 (&acc)[MF][NF],
+                                          f32x4 (&acc2)[MF][NF]) {
+  constexpr int XP = MlpL<T>::XP, FP = MlpL<T>::FP;
+  constexpr int K = KX + KF;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+#pragma unroll 2
+  for (int ks = 0; ks < K / 32; ++ks) {
+    const int k0 = ks * 32;
+    const bool fromF = k0 >= KX;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 wf[NF], wf2[NF], xf[MF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        int64_t off = (int64_t)(nbase + 16 * nf + lr) * K + k0 + 8 * lg;
+        wf[nf] = *reinterpret_cast<const bf16x8*>(W + off);
+        if (DUAL) wf2[nf] = *reinterpret_cast<const bf16x8*>(W2 + off);
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        int row = 16 * (m_first + mf) + lr;
+        const T* p = fromF ? F + row * FP + (k0 - KX) + 8 * lg : X + row * XP + k0 + 8 * lg;
+        xf[mf] = *reinterpret_cast<const bf16x8*>(p);
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[mf][nf], 0, 0, 0);
+          if (DUAL) acc2[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[nf], xf[mf], acc2[mf][nf], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 wf[NF], wf2[NF], xf[MF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          int64_t off = (int64_t)(nbase + 16 * nf + lr) * K + k0 + 16 * h + 4 * lg;
+          wf[nf] = *reinterpret_cast<const f32x4*>(W + off);
+          if (DUAL) wf2[nf] = *reinterpret_cast<const f32x4*>(W2 + off);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          int row = 16 * (m_first + mf) + lr;
+          const T* p = fromF ? F + row * FP + (k0 - KX) + 16 * h + 4 * lg : X + row * XP + k0 + 16 * h + 4 * lg;
+          xf[mf] = *reinterpret_cast<const f32x4*>(p);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nf][e], xf[mf][e], acc[mf][nf], 0, 0, 0);
+              if (DUAL) acc2[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[nf][e], xf[mf][e], acc2[mf][nf], 0, 0, 0);
+            }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) mlp2d_kernel(MlpK a) {
+  constexpr int P = MlpL<T>::P, XP = MlpL<T>::XP, FP = MlpL<T>::FP;
+  constexpr int MF = P / 16, NF = 4;
+  constexpr float SQRT2 = 1.41421356237309515f, RSQRT2 = 0.70710678118654752f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* XA = (T*)smem;
+  T* XB = XA + P * XP;
+  T* F = XB + P * XP;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int nbase = 64 * wave;
+  const int64_t tile0 = (int64_t)blockIdx.x * P;
+  const T* Wall = (const T*)a.w;
+
+  f32x4 acc[MF][NF], skp[MF][NF];
+  auto zero = [&](f32x4(&r)[MF][NF]) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) r[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // epilogue of a StyledConv: +noise, FusedLeakyReLU -> write bf16/fp32 activations to Xout
+  auto act_store = [&](int conv_idx, T* Xout) {
+    const float* bias = a.fb + MLP_FB_BIAS(conv_idx);
+    float nw = a.noise ? a.noise_w[conv_idx] : 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int row = 16 * mf + lr;
+      float nz = 0.f;
+      if (a.noise) {
+        int64_t gp = tile0 + row;
+        if (gp < a.total) nz = nw * a.noise[(int64_t)conv_idx * a.total + gp];
+      }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        int n = nbase + 16 * nf + 4 * lg;
+        f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n);
+        f32x4 v = acc[mf][nf];
+        T* dst = Xout + row * XP + n;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e] + nz + b4[e];
+          o[e] = (t > 0.f ? t : 0.2f * t) * SQRT2;
+        }
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = (bf16_t)o[e];
+          *reinterpret_cast<bf16x4*>(dst) = q;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        }
+      }
+    }
+  };
+  // epilogue of a block: x = (act(acc) + skip [+ skip_const]) / sqrt2 -> Xout, and keep x in skp (for block 4)
+  auto block_out = [&](int conv_idx, int skip_const_idx, T* Xout) {
+    const float* bias = a.fb + MLP_FB_BIAS(conv_idx);
+    float nw = a.noise ? a.noise_w[conv_idx] : 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int row = 16 * mf + lr;
+      float nz = 0.f;
+      if (a.noise) {
+        int64_t gp = tile0 + row;
+        if (gp < a.total) nz = nw * a.noise[(int64_t)conv_idx * a.total + gp];
+      }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        int n = nbase + 16 * nf + 4 * lg;
+        f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n);
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (skip_const_idx >= 0) sc = *reinterpret_cast<const f32x4*>(a.fb + MLP_FB_SKIP(skip_const_idx) + n);
+        f32x4 v = acc[mf][nf];
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e] + nz + b4[e];
+          t = (t > 0.f ? t : 0.2f * t) * SQRT2;
+          o[e] = (t + skp[mf][nf][e] + sc[e]) * RSQRT2;
+        }
+        skp[mf][nf] = f32x4{o[0], o[1], o[2], o[3]};
+        T* dst = Xout + row * XP + n;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = (bf16_t)o[e];
+          *reinterpret_cast<bf16x4*>(dst) = q;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        }
+      }
+    }
+  };
+
+  // ================= block 1: input f0 (64) ==================================================================
+  gather_plane<T>(a, 0, tile0, F);
+  __syncthreads();
+  zero(acc); zero(skp);
+  gemm_pass<T, MF, NF, 0, 64, true>(XA, F, Wall + mlp_w_off(0), Wall + mlp_w_off(1), nbase, 0, acc, skp);
+  act_store(0, XA);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XA, F, Wall + mlp_w_off(2), nullptr, nbase, 0, acc, acc);
+  act_store(1, XB);
+  gather_plane<T>(a, 1, tile0, F);  // f0 no longer needed: all waves passed the barrier after the first pass
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XB, F, Wall + mlp_w_off(3), nullptr, nbase, 0, acc, acc);
+  block_out(2, 0, XA);
+  __syncthreads();
+  // ================= block 2: input [x1 (256) | f1 (64)] ====================================================
+  zero(acc); zero(skp);
+  gemm_pass<T, MF, NF, 256, 64, true>(XA, F, Wall + mlp_w_off(4), Wall + mlp_w_off(5), nbase, 0, acc, skp);
+  act_store(3, XB);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XB, F, Wall + mlp_w_off(6), nullptr, nbase, 0, acc, acc);
+  act_store(4, XA);
+  gather_plane<T>(a, 2, tile0, F);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XA, F, Wall + mlp_w_off(7), nullptr, nbase, 0, acc, acc);
+  block_out(5, 1, XB);
+  __syncthreads();
+  // ================= block 3: input [x2 | f2] ===============================================================
+  zero(acc); zero(skp);
+  gemm_pass<T, MF, NF, 256, 64, true>(XB, F, Wall + mlp_w_off(8), Wall + mlp_w_off(9), nbase, 0, acc, skp);
+  act_store(6, XA);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XA, F, Wall + mlp_w_off(10), nullptr, nbase, 0, acc, acc);
+  act_store(7, XB);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XB, F, Wall + mlp_w_off(11), nullptr, nbase, 0, acc, acc);
+  block_out(8, 2, XA);  // skp now holds x3
+  __syncthreads();
+  // ================= block 4: identity skip (x3 stays in skp) ===============================================
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XA, F, Wall + mlp_w_off(12), nullptr, nbase, 0, acc, acc);
+  act_store(9, XB);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XB, F, Wall + mlp_w_off(13), nullptr, nbase, 0, acc, acc);
+  act_store(10, XA);
+  __syncthreads();
+  zero(acc);
+  gemm_pass<T, MF, NF, 256, 0, false>(XA, F, Wall + mlp_w_off(14), nullptr, nbase, 0, acc, acc);
+  block_out(11, -1, XB);
+  __syncthreads();
+  // ================= ToRGB: 256 -> 3 (rows padded to 16), points split over the waves =====================
+  {
+    constexpr int MFW = MF / 4;  // m-fragments per wave
+    f32x4 r[MFW][1], dummy[MFW][1];
+#pragma unroll
+    for (int i = 0; i < MFW; ++i) r[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_pass<T, MFW, 1, 256, 0, false>(XB, F, Wall + mlp_w_off(15), nullptr, 0, wave * MFW, r, dummy);
+    if (lg == 0) {
+      f32x4 rb = *reinterpret_cast<const f32x4*>(a.fb + MLP_FB_RGB);
+#pragma unroll
+      for (int i = 0; i < MFW; ++i) {
+        int64_t gp = tile0 + 16 * (wave * MFW + i) + lr;
+        if (gp < a.total) {
+          int b = (int)(gp / a.N);
+          int p = (int)(gp - (int64_t)b * a.N);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a.rgb[((int64_t)b * 3 + c) * a.N + p] = r[i][0][c] + rb[c];
+        }
+      }
+    }
+  }
+}
+
+int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s) {
+  MlpK k{};
+  for (int i = 0; i < 3; ++i) {
+    k.planes[i] = a.planes[i];
+    k.hw[i] = a.plane_hw[i];
+  }
+  k.coords = a.coords; k.w = a.w; k.fb = a.fb; k.noise = a.noise; k.noise_w = a.noise_w; k.rgb = a.rgb;
+  k.B = a.B; k.N = a.N; k.total = (int64_t)a.B * a.N;
+  if (dt == DT_BF16) {
+    using L = MlpL<bf16_t>;
+    size_t lds = (size_t)(2 * L::P * L::XP + L::P * L::FP) * sizeof(bf16_t);
+    static bool set = false;
+    if (!set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2d_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set = true;
+    }
+    hipLaunchKernelGGL(mlp2d_kernel<bf16_t>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+  } else {
+    using L = MlpL<float>;
+    size_t lds = (size_t)(2 * L::P * L::XP + L::P * L::FP) * sizeof(float);
+    static bool set = false;
+    if (!set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2d_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set = true;
+    }
+    hipLaunchKernelGGL(mlp2d_kernel<float>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

@@ -1,0 +1,90 @@
+// Host-callable launchers of the HIP kernels (all asynchronous on `stream`, no allocation, graph-capturable).
+#pragma once
+#include "common.h"
+
+// ---- fused DDPM / DDIM step (a3-a6) -------------------------------------------------------------
+struct StepCoefs {
+  float sqrt_one_minus_ac;  // sqrt(1 - abar_t)            -> mixing component scale (ddpm.py:476-477)
+  float sqrt_recip_ac;      // sqrt(1 / abar_t)            (ddpm.py:238)
+  float sqrt_recipm1_ac;    // sqrt(1 / abar_t - 1)        (ddpm.py:239)
+  float coef1, coef2;       // posterior_mean_coef1/2[t]   (ddpm.py:250-251)            ANCESTRAL
+  float noise_scale;        // [t != 0] * exp(0.5 * posterior_log_variance_clipped[t])  ANCESTRAL (ddpm.py:280-281)
+  float sqrt_ac_next;       // sqrt(abar_next)             (ddpm.py:366)                DDIM
+  float c_dir;              // sqrt(1 - abar_next - sigma^2) (ddpm.py:361)              DDIM
+  float sigma;              // eta * sqrt(...)             (ddpm.py:360)                DDIM
+};
+enum { STEP_ANCESTRAL = 0, STEP_DDIM = 1, STEP_DDIM_LAST = 2 };
+
+int launch_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
+                     StepCoefs k, int mode, int clip, float* x_out, float* x0_out, int B, int C, int HW,
+                     hipStream_t stream);
+
+// ---- layout / packing -----------------------------------------------------------------------------
+int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int HW, hipStream_t s);
+int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s);
+int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int dt, int64_t npix, hipStream_t s);
+int launch_pack_conv_weight(const float* w_oihw, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s);
+int launch_cast_f32(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
+int launch_upsample2x(const void* src, void* dst, int dt, int B, int H, int W, int C, hipStream_t s);
+
+// ---- time embedding + small dense layers (fp32) ----------------------------------------------------
+int launch_timestep_embedding(const int64_t* t, const float* freqs, float* out, int B, int dim, hipStream_t s);
+// y[b][n] = bias[n] + sum_k act(x[b][k]) * W[n][k];  act = SiLU when silu_in
+int launch_linear_small(const float* x, int x_stride, const float* W, const float* bias, float* y, int y_stride,
+                        int B, int K, int N, int silu_in, hipStream_t s);
+
+// ---- GroupNorm(32) ----------------------------------------------------------------------------------
+// stats: [B][32][2] doubles (sum, sum of squares), must be zero before launch_gn_stats
+int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s);
+int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
+                    float eps, int silu, int B, int HW, int C, hipStream_t s);
+
+// ---- implicit-GEMM convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 upsample) ------
+struct ConvArgs {
+  const void* x;      // [B, Hin, Win, Cin]   NHWC, dtype dt
+  const void* w;      // [Cout][KH*KW*Cin]    packed (tap-major, channel-minor), dtype dt
+  const float* bias;  // [Cout] or null
+  const float* emb;   // [B][emb_stride] per-(sample, channel) addend or null (time-embedding projection)
+  const void* res;    // [B, Hout, Wout, Cout] residual (dtype dt) or null
+  void* y;            // [B, Hout, Wout, Cout] (dtype dt) or null when y_nchw is used
+  float* y_nchw;      // optional fp32 NCHW output (model boundary)
+  float* splitk_ws;   // fp32 [splitk][M][Cout] partial slabs when splitk > 1
+  int B, Hin, Win, Cin, Hout, Wout, Cout;
+  int KH, KW, stride, pad, ups;
+  int emb_stride;
+  int splitk;
+  float out_scale;    // y = (acc + bias + emb + res) * out_scale
+};
+int launch_conv(const ConvArgs& a, int dt, hipStream_t s);
+// split-K finish: y = (ws + bias + emb + res) * scale
+int launch_splitk_finish(const ConvArgs& a, int dt, hipStream_t s);
+int conv_pick_splitk(const ConvArgs& a, int dt);
+
+// batched plain GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * Bm[b][n][k]  (both K-contiguous), dtype dt in/out
+int launch_gemm_nt(const void* A, const void* Bm, void* C, int dt, int batch, int M, int N, int K, int64_t strideA,
+                   int64_t strideB, int64_t strideC, float alpha, hipStream_t s);
+// row softmax in place over the last dim, fp32 math
+int launch_softmax_rows(void* x, int dt, int64_t rows, int cols, hipStream_t s);
+// dst[b][c][r] = src[b][r][c]
+int launch_transpose_2d(const void* src, void* dst, int dt, int batch, int R, int Cc, hipStream_t s);
+
+// ---- attention (QKVAttentionLegacy layout, head dim 32) -------------------------------------------------
+// qkv [B, T, heads*3*32] (token-major, per-head [q|k|v] channel interleave) -> out [B, T, heads*32]; out += nothing
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, hipStream_t s);
+
+// ---- fused plane sampling + coordinate MLP (image) ------------------------------------------------------
+struct Mlp2dLayer { const void* w; const float* bias; int K; };  // w [256][K] dtype dt (folded), bias [256] fp32
+struct Mlp2dArgs {
+  const float* planes[3];  // [B,64,P,P] NCHW fp32 (as returned by decode)
+  int plane_hw[3];
+  const float* coords;     // [N,2] (x,y) normalised
+  const void* w;           // packed folded weights, see mlp2d.hip
+  const float* fb;         // packed fp32 biases / folded constants
+  const float* noise;      // [12][B][N] or null
+  const float* noise_w;    // [12]
+  float* rgb;              // [B,3,N]
+  int B, N;
+};
+int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s);
+size_t mlp2d_weight_elems();
+size_t mlp2d_fb_elems();

@@ -1,0 +1,334 @@
+// Graph builders for the two conv networks on the path:
+//   * LDM UNet            - models/ldm/modules/diffusionmodules/openaimodel.py:463-793 (UNetModel)
+//   * D2C-VAE image decoder - models/d2c_vae/autoencoder_unet.py:702-829 (Decoder) + :855-858 (Autoencoder.decode)
+// Weight names are the reference's state-dict keys, so `ldm-last.pt` tensors can be handed over unchanged.
+#include "models.h"
+#include <cmath>
+
+// =====================================================================================================
+// UNet
+// =====================================================================================================
+static bool in_list(const int* v, int n, int x) {
+  for (int i = 0; i < n; ++i)
+    if (v[i] == x) return true;
+  return false;
+}
+
+// one ResBlock (openaimodel.py:244-276, no up/down, use_scale_shift_norm=False):
+//   h = conv3(SiLU(GN(x))) + emb_proj ; h = conv3(SiLU(GN(h))) ; out = skip(x) + h
+static int build_resblock(UNet& u, const std::string& pre, int x, int cout, int* out) {
+  Net& n = u.net;
+  int cin = n.tensors[x].C;
+  int gn1, gn2, c1, c2;
+  DDMI_TRY(n.make_gn(pre + "in_layers.0.", &gn1));
+  DDMI_TRY(n.make_conv(pre + "in_layers.2.weight", pre + "in_layers.2.bias", &c1));
+  DDMI_REQUIRE(n.convs[c1].Cin == cin && n.convs[c1].Cout == cout, "resblock conv shape mismatch at " + pre);
+  // time-embedding projection rows are appended to one big [Etot, emb_dim] matrix
+  const HostTensor* ew = n.find(pre + "emb_layers.1.weight");
+  const HostTensor* eb = n.find(pre + "emb_layers.1.bias");
+  if (!ew || !eb) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + pre + "emb_layers.1.*'");
+  DDMI_REQUIRE(ew->shape.size() == 2 && ew->shape[0] == cout && ew->shape[1] == u.emb_dim, "emb_layers shape mismatch at " + pre);
+  int emb_off = (int)u.emb_b_host.size();
+  u.emb_w_host.insert(u.emb_w_host.end(), ew->data.begin(), ew->data.end());
+  u.emb_b_host.insert(u.emb_b_host.end(), eb->data.begin(), eb->data.end());
+  DDMI_TRY(n.make_gn(pre + "out_layers.0.", &gn2));
+  DDMI_TRY(n.make_conv(pre + "out_layers.3.weight", pre + "out_layers.3.bias", &c2));
+  int skip = x;
+  if (cin != cout) {
+    int cs;
+    DDMI_TRY(n.make_conv(pre + "skip_connection.weight", pre + "skip_connection.bias", &cs));
+    DDMI_REQUIRE(n.convs[cs].K == 1, "only 1x1 skip connections are supported (use_conv=False)");
+    skip = n.op_conv(x, cs, 1, 0, -1, -1);
+  }
+  int a = n.op_gn(x, gn1, 1, 1e-5f);
+  int h = n.op_conv(a, c1, 1, 0, -1, emb_off);
+  int b = n.op_gn(h, gn2, 1, 1e-5f);
+  *out = n.op_conv(b, c2, 1, 0, skip, -1);
+  return DDMI_OK;
+}
+
+// AttentionBlock (openaimodel.py:319-325) with QKVAttentionLegacy, head dim = num_head_channels (must be 32)
+static int build_attnblock(UNet& u, const std::string& pre, int x, int* out) {
+  Net& n = u.net;
+  const TensorDesc t = n.tensors[x];
+  int gn, cq, cp;
+  DDMI_TRY(n.make_gn(pre + "norm.", &gn));
+  DDMI_TRY(n.make_conv(pre + "qkv.weight", pre + "qkv.bias", &cq));
+  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &cp));
+  DDMI_REQUIRE(n.convs[cq].Cout == 3 * t.C && n.convs[cq].Cin == t.C, "qkv shape mismatch at " + pre);
+  int a = n.op_gn(x, gn, 0, 1e-5f);
+  int qkv = n.op_conv(a, cq, 1, 0, -1, -1);
+  Op o;
+  o.kind = OP_ATTN_LEGACY;
+  o.in = qkv;
+  o.out = n.new_tensor(t.C, t.H, t.W);
+  o.heads = t.C / u.cfg.num_head_channels;
+  n.ops.push_back(o);
+  *out = n.op_conv(o.out, cp, 1, 0, x, -1);
+  return DDMI_OK;
+}
+
+int unet_finalize(UNet& u) {
+  Net& n = u.net;
+  const ddmi_unet_cfg& c = u.cfg;
+  DDMI_REQUIRE(c.num_head_channels == 32, "only num_head_channels == 32 is supported by the fused attention kernel");
+  DDMI_REQUIRE(c.n_mult >= 1 && c.n_mult <= 8 && c.n_attn >= 0 && c.n_attn <= 8, "bad channel_mult / attention_resolutions");
+  DDMI_REQUIRE(c.model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm32)");
+  const int mc = c.model_channels;
+  u.emb_dim = 4 * mc;
+
+  // ---- time embedding MLP (openaimodel.py:557-562) -------------------------------------------------
+  {
+    int half = mc / 2;
+    std::vector<float> fr(half);
+    const float neg_log = (float)(-std::log(10000.0));
+    for (int i = 0; i < half; ++i) {
+      volatile float a = neg_log * (float)i;  // fp32 product, then fp32 division, as torch evaluates util.py:161-163
+      volatile float q = a / (float)half;
+      fr[i] = std::exp((float)q);
+    }
+    DDMI_TRY(n.dev_upload(fr.data(), half, &u.freqs));
+    const char* keys[4] = {"time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"};
+    float** dst[4] = {&u.te_w0, &u.te_b0, &u.te_w1, &u.te_b1};
+    for (int i = 0; i < 4; ++i) {
+      const HostTensor* t = n.find(keys[i]);
+      if (!t) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, std::string("missing weight '") + keys[i] + "'");
+      DDMI_TRY(n.dev_upload(t->data.data(), t->numel(), dst[i]));
+    }
+    DDMI_REQUIRE(n.find(keys[0])->shape[0] == u.emb_dim && n.find(keys[0])->shape[1] == mc, "time_embed.0 shape mismatch");
+  }
+
+  // ---- topology (openaimodel.py:567-743) -------------------------------------------------------------
+  const int S = c.image_size;
+  Op in;
+  in.kind = OP_NCHW_IN;
+  in.ext = 0;
+  in.out = n.new_tensor(c.in_channels, S, S);
+  n.ops.push_back(in);
+  int ci;
+  DDMI_TRY(n.make_conv("input_blocks.0.0.weight", "input_blocks.0.0.bias", &ci));
+  int h = n.op_conv(in.out, ci, 1, 0, -1, -1);
+  std::vector<int> hs{h};
+  int ch = mc, ds = 1, blk = 1;
+  for (int level = 0; level < c.n_mult; ++level) {
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      std::string pre = "input_blocks." + std::to_string(blk) + ".";
+      DDMI_TRY(build_resblock(u, pre + "0.", h, c.channel_mult[level] * mc, &h));
+      ch = c.channel_mult[level] * mc;
+      if (in_list(c.attention_resolutions, c.n_attn, ds)) DDMI_TRY(build_attnblock(u, pre + "1.", h, &h));
+      hs.push_back(h);
+      ++blk;
+    }
+    if (level != c.n_mult - 1) {
+      std::string pre = "input_blocks." + std::to_string(blk) + ".0.";
+      int cd;
+      DDMI_TRY(n.make_conv(pre + "op.weight", pre + "op.bias", &cd));  // Downsample: conv3x3 stride 2 (openaimodel.py:152-154)
+      h = n.op_conv(h, cd, 2, 0, -1, -1);
+      hs.push_back(h);
+      ds *= 2;
+      ++blk;
+    }
+  }
+  DDMI_TRY(build_resblock(u, "middle_block.0.", h, ch, &h));
+  DDMI_TRY(build_attnblock(u, "middle_block.1.", h, &h));
+  DDMI_TRY(build_resblock(u, "middle_block.2.", h, ch, &h));
+  blk = 0;
+  for (int level = c.n_mult - 1; level >= 0; --level) {
+    for (int i = 0; i <= c.num_res_blocks; ++i) {
+      std::string pre = "output_blocks." + std::to_string(blk) + ".";
+      int skip = hs.back();
+      hs.pop_back();
+      const TensorDesc ta = n.tensors[h], tb = n.tensors[skip];
+      DDMI_REQUIRE(ta.H == tb.H && ta.W == tb.W, "skip connection spatial mismatch");
+      Op cat;
+      cat.kind = OP_CONCAT;
+      cat.in = h;
+      cat.in2 = skip;
+      cat.out = n.new_tensor(ta.C + tb.C, ta.H, ta.W);
+      n.ops.push_back(cat);
+      DDMI_TRY(build_resblock(u, pre + "0.", cat.out, mc * c.channel_mult[level], &h));
+      int sub = 1;
+      if (in_list(c.attention_resolutions, c.n_attn, ds)) {
+        DDMI_TRY(build_attnblock(u, pre + std::to_string(sub) + ".", h, &h));
+        ++sub;
+      }
+      if (level && i == c.num_res_blocks) {
+        int cu;
+        std::string q = pre + std::to_string(sub) + ".conv.";
+        DDMI_TRY(n.make_conv(q + "weight", q + "bias", &cu));  // Upsample: nearest x2 + conv3x3 (openaimodel.py:110-120)
+        h = n.op_conv(h, cu, 1, 1, -1, -1);
+        ds /= 2;
+      }
+      ++blk;
+    }
+  }
+  int gno, co;
+  DDMI_TRY(n.make_gn("out.0.", &gno));
+  DDMI_TRY(n.make_conv("out.2.weight", "out.2.bias", &co));
+  int a = n.op_gn(h, gno, 1, 1e-5f);
+  int y = n.op_conv(a, co, 1, 0, -1, -1);
+  n.ops.back().out_nchw = 1;
+  n.ops.back().ext = 1;
+  (void)y;
+
+  // ---- concatenated emb projections ------------------------------------------------------------------
+  u.emb_total = (int)u.emb_b_host.size();
+  DDMI_TRY(n.dev_upload(u.emb_w_host.data(), (int64_t)u.emb_w_host.size(), &u.emb_w));
+  DDMI_TRY(n.dev_upload(u.emb_b_host.data(), (int64_t)u.emb_b_host.size(), &u.emb_b));
+  u.emb_w_host.clear();
+  u.emb_w_host.shrink_to_fit();
+  size_t fb = (size_t)c.max_batch * (mc + 2 * u.emb_dim + u.emb_total) * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&u.tbuf, fb));
+  n.dev_allocs.push_back(u.tbuf);
+  return n.plan();
+}
+
+int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s) {
+  Net& n = u.net;
+  if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "unet not finalized");
+  DDMI_REQUIRE(x && t && eps_out, "unet_forward: null pointer");
+  DDMI_REQUIRE(B >= 1 && B <= n.max_batch, "unet_forward: batch exceeds max_batch");
+  const int mc = u.cfg.model_channels, E = u.emb_dim;
+  float* temb = u.tbuf;                       // [B][mc]
+  float* e1 = temb + (size_t)B * mc;          // [B][E]
+  float* e2 = e1 + (size_t)B * E;             // [B][E]
+  float* eall = e2 + (size_t)B * E;           // [B][emb_total]
+  DDMI_TRY(launch_timestep_embedding(t, u.freqs, temb, B, mc, s));
+  DDMI_TRY(launch_linear_small(temb, mc, u.te_w0, u.te_b0, e1, E, B, mc, E, 0, s));
+  DDMI_TRY(launch_linear_small(e1, E, u.te_w1, u.te_b1, e2, E, B, E, E, 1, s));
+  // every ResBlock's emb_layers = Linear(SiLU(emb)) (openaimodel.py:219-225) in one launch
+  DDMI_TRY(launch_linear_small(e2, E, u.emb_w, u.emb_b, eall, u.emb_total, B, E, u.emb_total, 1, s));
+  void* ext[2] = {(void*)x, (void*)eps_out};
+  return n.run(B, ext, eall, u.emb_total, s);
+}
+
+// =====================================================================================================
+// D2C-VAE image decoder
+// =====================================================================================================
+// ResnetBlock (autoencoder_unet.py:129-149) with temb=None
+static int build_vae_resblock(Net& n, const std::string& pre, int x, int cout, int* out) {
+  int cin = n.tensors[x].C;
+  int gn1, gn2, c1, c2;
+  DDMI_TRY(n.make_gn(pre + "norm1.", &gn1));
+  DDMI_TRY(n.make_conv(pre + "conv1.weight", pre + "conv1.bias", &c1));
+  DDMI_TRY(n.make_gn(pre + "norm2.", &gn2));
+  DDMI_TRY(n.make_conv(pre + "conv2.weight", pre + "conv2.bias", &c2));
+  DDMI_REQUIRE(n.convs[c1].Cin == cin && n.convs[c1].Cout == cout, "decoder resblock shape mismatch at " + pre);
+  int skip = x;
+  if (cin != cout) {
+    int cs;
+    DDMI_TRY(n.make_conv(pre + "nin_shortcut.weight", pre + "nin_shortcut.bias", &cs));
+    skip = n.op_conv(x, cs, 1, 0, -1, -1);
+  }
+  int a = n.op_gn(x, gn1, 1, 1e-6f);
+  int h = n.op_conv(a, c1, 1, 0, -1, -1);
+  int b = n.op_gn(h, gn2, 1, 1e-6f);
+  *out = n.op_conv(b, c2, 1, 0, skip, -1);
+  return DDMI_OK;
+}
+
+// AttnBlock with num_heads=1 (autoencoder_unet.py:187-215; make_attn 'vanilla' :561-567)
+static int build_vae_attn(Net& n, const std::string& pre, int x, int* out) {
+  const TensorDesc t = n.tensors[x];
+  int gn, cq, ck, cv, cp;
+  DDMI_TRY(n.make_gn(pre + "norm.", &gn));
+  DDMI_TRY(n.make_conv(pre + "q.weight", pre + "q.bias", &cq));
+  DDMI_TRY(n.make_conv(pre + "k.weight", pre + "k.bias", &ck));
+  DDMI_TRY(n.make_conv(pre + "v.weight", pre + "v.bias", &cv));
+  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &cp));
+  int a = n.op_gn(x, gn, 0, 1e-6f);
+  int q = n.op_conv(a, cq, 1, 0, -1, -1);
+  int k = n.op_conv(a, ck, 1, 0, -1, -1);
+  int v = n.op_conv(a, cv, 1, 0, -1, -1);
+  int T = t.H * t.W;
+  Op o;
+  o.kind = OP_ATTN_FULL;
+  o.in = q; o.in2 = k; o.res = v;
+  o.out = n.new_tensor(t.C, t.H, t.W);
+  o.tmp0 = n.new_tensor(T, T, 1);        // scores [T][T]
+  o.tmp1 = n.new_tensor(t.C, t.H, t.W);  // V^T [C][T]
+  o.scale = 1.0f / std::sqrt((float)t.C);  // int(c)**(-0.5), autoencoder_unet.py:203
+  n.ops.push_back(o);
+  *out = n.op_conv(o.out, cp, 1, 0, x, -1);
+  return DDMI_OK;
+}
+
+int decoder2d_finalize(Decoder2d& d) {
+  Net& n = d.net;
+  const ddmi_decoder2d_cfg& c = d.cfg;
+  DDMI_REQUIRE(c.n_mult >= 1 && c.n_mult <= 8, "bad ch_mult");
+  const int nres = c.n_mult;
+  int curr = c.resolution >> (nres - 1);
+  DDMI_REQUIRE(c.latent_size == curr, "latent_size must equal resolution / 2^(len(ch_mult)-1)");
+  Op in;
+  in.kind = OP_NCHW_IN;
+  in.ext = 0;
+  in.out = n.new_tensor(c.embed_dim, curr, curr);
+  n.ops.push_back(in);
+  int cpq, cin_;
+  DDMI_TRY(n.make_conv("post_quant_conv.weight", "post_quant_conv.bias", &cpq));
+  DDMI_TRY(n.make_conv("decoder.conv_in.weight", "decoder.conv_in.bias", &cin_));
+  int h = n.op_conv(in.out, cpq, 1, 0, -1, -1);
+  h = n.op_conv(h, cin_, 1, 0, -1, -1);
+  int block_in = c.ch * c.ch_mult[nres - 1];
+  DDMI_TRY(build_vae_resblock(n, "decoder.mid.block_1.", h, block_in, &h));
+  DDMI_TRY(build_vae_attn(n, "decoder.mid.attn_1.", h, &h));
+  DDMI_TRY(build_vae_resblock(n, "decoder.mid.block_2.", h, block_in, &h));
+  d.n_planes = 0;
+  auto add_export = [&](int tensor) {
+    Op e;
+    e.kind = OP_EXPORT;
+    e.in = tensor;
+    e.ext = 1 + d.n_planes;
+    n.ops.push_back(e);
+    d.export_ops[d.n_planes] = (int)n.ops.size() - 1;
+    d.plane_hw[d.n_planes] = n.tensors[tensor].H;
+    d.n_planes++;
+  };
+  for (int lvl = nres - 1; lvl >= 0; --lvl) {
+    int block_out = c.ch * c.ch_mult[lvl];
+    for (int ib = 0; ib <= c.num_res_blocks; ++ib) {
+      std::string pre = "decoder.up." + std::to_string(lvl) + ".block." + std::to_string(ib) + ".";
+      DDMI_TRY(build_vae_resblock(n, pre, h, block_out, &h));
+      if (in_list(c.attn_resolutions, c.n_attn, curr)) {
+        std::string pa = "decoder.up." + std::to_string(lvl) + ".attn." + std::to_string(ib) + ".";
+        DDMI_TRY(build_vae_attn(n, pa, h, &h));
+      }
+    }
+    if (in_list(c.hdbf_resolutions, c.n_hdbf, curr)) {
+      DDMI_REQUIRE(d.n_planes < 7, "too many HDBF planes");
+      std::string ph = "decoder.up." + std::to_string(lvl) + ".hdbf.0.";
+      int chd;
+      DDMI_TRY(n.make_conv(ph + "weight", ph + "bias", &chd));
+      int p = n.op_conv(h, chd, 1, 0, -1, -1);
+      add_export(p);
+    }
+    if (lvl != 0) {
+      std::string pu = "decoder.up." + std::to_string(lvl) + ".upsample.conv.";
+      int cu;
+      DDMI_TRY(n.make_conv(pu + "weight", pu + "bias", &cu));
+      h = n.op_conv(h, cu, 1, 1, -1, -1);
+      curr *= 2;
+    }
+  }
+  int gno, co;
+  DDMI_TRY(n.make_gn("decoder.norm_out.", &gno));
+  DDMI_TRY(n.make_conv("decoder.conv_out.weight", "decoder.conv_out.bias", &co));
+  int a = n.op_gn(h, gno, 1, 1e-6f);
+  int y = n.op_conv(a, co, 1, 0, -1, -1);
+  add_export(y);
+  return n.plan();
+}
+
+int decoder2d_forward(Decoder2d& d, const float* z, void* const* planes, int layout, int B, hipStream_t s) {
+  Net& n = d.net;
+  if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "decoder not finalized");
+  DDMI_REQUIRE(z && planes, "decoder2d_forward: null pointer");
+  DDMI_REQUIRE(layout == 0 || layout == 1, "decoder2d_forward: layout must be 0 (NCHW fp32) or 1 (NHWC native)");
+  void* ext[8] = {(void*)z};
+  for (int i = 0; i < d.n_planes; ++i) {
+    ext[1 + i] = planes[i];
+    n.ops[d.export_ops[i]].out_nchw = layout == 0;
+  }
+  return n.run(B, ext, nullptr, 0, s);
+}

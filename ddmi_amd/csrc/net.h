@@ -1,0 +1,97 @@
+// Static-shape network executor shared by the UNet and the D2C-VAE decoder.
+//
+// A network is built once (at *_finalize) into a flat list of ops over symbolic tensors; tensors get offsets in one
+// activation arena by a liveness-based first-fit allocator (so the working set stays small enough to live in the
+// 256 MiB Infinity Cache at moderate batch), weights are packed once into device memory, and `run()` is a plain
+// sequence of asynchronous kernel launches on the caller's stream: no allocation, no host sync, hipGraph-capturable.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "kernels.h"
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct ConvW {
+  void* w = nullptr;      // packed [Cout][taps*Cin], network dtype
+  float* bias = nullptr;  // [Cout] fp32 (may be null)
+  int Cout = 0, Cin = 0, K = 1;
+};
+
+struct GNW {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int C = 0;
+};
+
+enum OpKind { OP_NCHW_IN = 0, OP_GN, OP_CONV, OP_ATTN_LEGACY, OP_ATTN_FULL, OP_CONCAT, OP_EXPORT };
+
+struct Op {
+  int kind = 0;
+  int in = -1, in2 = -1, out = -1, res = -1;
+  int conv = -1, gn = -1;
+  int silu = 0;
+  float eps = 1e-5f;
+  int stride = 1, pad = 0, ups = 0;
+  int emb_off = -1;
+  int heads = 0;
+  int out_nchw = 0;   // OP_CONV: write fp32 NCHW to external output slot `ext`
+  int ext = -1;       // external pointer slot (inputs / outputs of the network)
+  int gn_slot = -1;   // index into the GN statistics arena
+  int tmp0 = -1, tmp1 = -1, tmp2 = -1;  // scratch tensors (OP_ATTN_FULL)
+  float scale = 1.f;
+};
+
+struct TensorDesc {
+  int C = 0, H = 0, W = 0;
+  int64_t elems = 0;    // per sample
+  int first = -1, last = -1;
+  size_t off = 0;       // byte offset in the arena (for max batch)
+  int dt_override = -1; // -1: network dtype
+};
+
+struct Net {
+  int dt = DT_F32;
+  int max_batch = 1;
+  bool finalized = false;
+  std::map<std::string, HostTensor> host;   // raw state-dict tensors (fp32) until finalize
+  std::vector<ConvW> convs;
+  std::vector<GNW> gns;
+  std::vector<Op> ops;
+  std::vector<TensorDesc> tensors;
+  std::vector<void*> dev_allocs;            // everything hipMalloc'ed by this net
+  unsigned char* arena = nullptr;
+  size_t arena_bytes = 0;
+  double* gn_stats = nullptr;               // [n_gn_slots][max_batch][32][2]
+  int n_gn_slots = 0;
+  float* splitk_ws = nullptr;
+  size_t splitk_bytes = 0;
+  size_t weight_bytes = 0;
+
+  ~Net();
+  int add_host(const char* key, const float* data, const int64_t* shape, int ndim);
+  const HostTensor* find(const std::string& key) const;
+
+  // ---- build helpers -------------------------------------------------------------------------------
+  int new_tensor(int C, int H, int W, int dt_override = -1);
+  int dev_upload(const float* src, int64_t n, float** out);
+  int make_conv(const std::string& wkey, const std::string& bkey, int* idx);   // [Cout,Cin,K,K] or [Cout,Cin,1] / [Cout,Cin]
+  int make_gn(const std::string& prefix, int* idx);
+  int op_gn(int in, int gn, int silu, float eps);
+  int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
+  int plan();   // liveness + arena + workspaces
+  void* tptr(int id) const { return arena + tensors[id].off; }
+  size_t tbytes(int id, int B) const;
+
+  // ---- execution -----------------------------------------------------------------------------------
+  // ext: external pointers indexed by Op::ext; emb: [B][emb_stride] fp32 or null
+  int run(int B, void* const* ext, const float* emb, int emb_stride, hipStream_t s);
+};

@@ -1,0 +1,332 @@
+// Network executor: weight packing, liveness-planned activation arena, op dispatch (see net.h).
+#include "net.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_last_error;
+
+void ddmi_set_error(const std::string& msg) { g_last_error = msg; }
+int ddmi_fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+const char* ddmi_error_cstr() { return g_last_error.c_str(); }
+
+Net::~Net() {
+  for (void* p : dev_allocs)
+    if (p) (void)hipFree(p);
+}
+
+int Net::add_host(const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(key && data && ndim >= 0 && ndim <= 8, "load_weight: bad arguments");
+  if (finalized) return ddmi_fail(DDMI_ERR_STATE, "load_weight after finalize");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  int64_t n = t.numel();
+  t.data.assign(data, data + n);
+  host[key] = std::move(t);
+  return DDMI_OK;
+}
+
+const HostTensor* Net::find(const std::string& key) const {
+  auto it = host.find(key);
+  return it == host.end() ? nullptr : &it->second;
+}
+
+int Net::new_tensor(int C, int H, int W, int dt_override) {
+  TensorDesc t;
+  t.C = C; t.H = H; t.W = W;
+  t.elems = (int64_t)C * H * W;
+  t.dt_override = dt_override;
+  tensors.push_back(t);
+  return (int)tensors.size() - 1;
+}
+
+size_t Net::tbytes(int id, int B) const {
+  const TensorDesc& t = tensors[id];
+  int d = t.dt_override >= 0 ? t.dt_override : dt;
+  return (size_t)B * t.elems * dt_size(d);
+}
+
+int Net::dev_upload(const float* src, int64_t n, float** out) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, (size_t)n * sizeof(float)));
+  dev_allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  weight_bytes += (size_t)n * sizeof(float);
+  *out = (float*)p;
+  return DDMI_OK;
+}
+
+int Net::make_conv(const std::string& wkey, const std::string& bkey, int* idx) {
+  const HostTensor* w = find(wkey);
+  if (!w) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + wkey + "'");
+  DDMI_REQUIRE(w->shape.size() >= 2 && w->shape.size() <= 4, "conv weight must be 2-, 3- or 4-D: " + wkey);
+  ConvW c;
+  c.Cout = (int)w->shape[0];
+  c.Cin = (int)w->shape[1];
+  c.K = w->shape.size() == 4 ? (int)w->shape[2] : 1;
+  if (w->shape.size() == 4) DDMI_REQUIRE(w->shape[2] == w->shape[3], "conv kernel must be square: " + wkey);
+  if (w->shape.size() == 3) DDMI_REQUIRE(w->shape[2] == 1, "conv1d kernel must be 1: " + wkey);
+  int64_t n = w->numel();
+  float* raw = nullptr;
+  HIP_TRY(hipMalloc((void**)&raw, (size_t)n * sizeof(float)));
+  hipError_t e = hipMemcpy(raw, w->data.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight upload failed: " + wkey); }
+  void* packed = nullptr;
+  e = hipMalloc(&packed, (size_t)n * dt_size(dt));
+  if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight alloc failed: " + wkey); }
+  dev_allocs.push_back(packed);
+  int rc = launch_pack_conv_weight(raw, packed, dt, c.Cout, c.Cin, c.K, c.K, 0);
+  hipError_t e2 = hipDeviceSynchronize();
+  (void)hipFree(raw);
+  if (rc != DDMI_OK) return rc;
+  if (e2 != hipSuccess) return ddmi_fail(DDMI_ERR_HIP, "weight pack failed: " + wkey);
+  weight_bytes += (size_t)n * dt_size(dt);
+  c.w = packed;
+  if (!bkey.empty()) {
+    const HostTensor* b = find(bkey);
+    if (!b) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + bkey + "'");
+    DDMI_REQUIRE(b->numel() == c.Cout, "bias size mismatch: " + bkey);
+    DDMI_TRY(dev_upload(b->data.data(), c.Cout, &c.bias));
+  }
+  convs.push_back(c);
+  *idx = (int)convs.size() - 1;
+  return DDMI_OK;
+}
+
+int Net::make_gn(const std::string& prefix, int* idx) {
+  const HostTensor* g = find(prefix + "weight");
+  const HostTensor* b = find(prefix + "bias");
+  if (!g) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + prefix + "weight'");
+  if (!b) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + prefix + "bias'");
+  DDMI_REQUIRE(g->numel() == b->numel(), "groupnorm affine size mismatch: " + prefix);
+  GNW w;
+  w.C = (int)g->numel();
+  DDMI_TRY(dev_upload(g->data.data(), w.C, &w.gamma));
+  DDMI_TRY(dev_upload(b->data.data(), w.C, &w.beta));
+  gns.push_back(w);
+  *idx = (int)gns.size() - 1;
+  return DDMI_OK;
+}
+
+int Net::op_gn(int in, int gn, int silu, float eps) {
+  const TensorDesc& t = tensors[in];
+  Op o;
+  o.kind = OP_GN;
+  o.in = in;
+  o.out = new_tensor(t.C, t.H, t.W);
+  o.gn = gn;
+  o.silu = silu;
+  o.eps = eps;
+  o.gn_slot = n_gn_slots++;
+  ops.push_back(o);
+  return o.out;
+}
+
+int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale) {
+  const TensorDesc& t = tensors[in];
+  const ConvW& c = convs[conv];
+  int pad = c.K / 2;
+  int hin = ups ? 2 * t.H : t.H, win = ups ? 2 * t.W : t.W;
+  int ho = (hin + 2 * pad - c.K) / stride + 1, wo = (win + 2 * pad - c.K) / stride + 1;
+  Op o;
+  o.kind = OP_CONV;
+  o.in = in;
+  o.out = new_tensor(c.Cout, ho, wo);
+  o.conv = conv;
+  o.stride = stride;
+  o.pad = pad;
+  o.ups = ups;
+  o.res = res;
+  o.emb_off = emb_off;
+  o.scale = scale;
+  ops.push_back(o);
+  return o.out;
+}
+
+// ------------------------------------------------------------------------------------------------------
+static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
+  const TensorDesc& ti = n.tensors[o.in];
+  const ConvW& c = n.convs[o.conv];
+  *a = ConvArgs{};
+  a->x = n.tptr(o.in);
+  a->w = c.w;
+  a->bias = c.bias;
+  a->B = B; a->Hin = ti.H; a->Win = ti.W; a->Cin = c.Cin;
+  a->Cout = c.Cout;
+  a->KH = a->KW = c.K; a->stride = o.stride; a->pad = o.pad; a->ups = o.ups;
+  int hin = o.ups ? 2 * ti.H : ti.H, win = o.ups ? 2 * ti.W : ti.W;
+  a->Hout = (hin + 2 * o.pad - c.K) / o.stride + 1;
+  a->Wout = (win + 2 * o.pad - c.K) / o.stride + 1;
+  a->out_scale = o.scale;
+  a->splitk = 1;
+}
+
+int Net::plan() {
+  const int nops = (int)ops.size();
+  auto touch = [&](int id, int i, bool write) {
+    if (id < 0) return;
+    TensorDesc& t = tensors[id];
+    if (t.first < 0) t.first = i;
+    (void)write;
+    t.last = std::max(t.last, i);
+  };
+  for (int i = 0; i < nops; ++i) {
+    const Op& o = ops[i];
+    touch(o.in, i, false); touch(o.in2, i, false); touch(o.res, i, false);
+    touch(o.out, i, true); touch(o.tmp0, i, true); touch(o.tmp1, i, true); touch(o.tmp2, i, true);
+  }
+  // first-fit allocator over op order
+  struct Blk { size_t off, size; };
+  std::vector<Blk> free_list;
+  size_t top = 0;
+  auto alloc = [&](size_t bytes) -> size_t {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+      if (free_list[i].size >= bytes) {
+        size_t off = free_list[i].off;
+        free_list[i].off += bytes;
+        free_list[i].size -= bytes;
+        if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+        return off;
+      }
+    }
+    // extend; merge with a trailing free block if it touches the top
+    if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+      size_t off = free_list.back().off;
+      top = off + bytes;
+      free_list.pop_back();
+      return off;
+    }
+    size_t off = top;
+    top += bytes;
+    return off;
+  };
+  auto release = [&](size_t off, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    Blk b{off, bytes};
+    auto it = std::lower_bound(free_list.begin(), free_list.end(), b, [](const Blk& x, const Blk& y) { return x.off < y.off; });
+    it = free_list.insert(it, b);
+    // coalesce with neighbours
+    size_t i = it - free_list.begin();
+    if (i + 1 < free_list.size() && free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+      free_list[i].size += free_list[i + 1].size;
+      free_list.erase(free_list.begin() + i + 1);
+    }
+    if (i > 0 && free_list[i - 1].off + free_list[i - 1].size == free_list[i].off) {
+      free_list[i - 1].size += free_list[i].size;
+      free_list.erase(free_list.begin() + i);
+    }
+  };
+  for (int i = 0; i < nops; ++i) {
+    for (size_t t = 0; t < tensors.size(); ++t)
+      if (tensors[t].first == i) tensors[t].off = alloc(tbytes((int)t, max_batch));
+    for (size_t t = 0; t < tensors.size(); ++t)
+      if (tensors[t].last == i && tensors[t].first >= 0) release(tensors[t].off, tbytes((int)t, max_batch));
+  }
+  arena_bytes = std::max<size_t>(top, 256);
+  HIP_TRY(hipMalloc((void**)&arena, arena_bytes));
+  dev_allocs.push_back(arena);
+
+  if (n_gn_slots > 0) {
+    size_t bytes = (size_t)n_gn_slots * max_batch * 64 * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&gn_stats, bytes));
+    dev_allocs.push_back(gn_stats);
+  }
+  // split-K slabs: worst case over batch sizes
+  splitk_bytes = 0;
+  for (const Op& o : ops) {
+    if (o.kind != OP_CONV) continue;
+    for (int B = 1; B <= max_batch; ++B) {
+      ConvArgs a;
+      fill_conv_args(*this, o, B, &a);
+      int sk = conv_pick_splitk(a, dt);
+      if (sk > 1) splitk_bytes = std::max(splitk_bytes, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
+    }
+  }
+  if (splitk_bytes) {
+    HIP_TRY(hipMalloc((void**)&splitk_ws, splitk_bytes));
+    dev_allocs.push_back(splitk_ws);
+  }
+  host.clear();  // raw fp32 copies are no longer needed
+  finalized = true;
+  return DDMI_OK;
+}
+
+int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStream_t s) {
+  if (!finalized) return ddmi_fail(DDMI_ERR_STATE, "network not finalized");
+  DDMI_REQUIRE(B >= 1 && B <= max_batch, "batch exceeds max_batch given at create time");
+  if (n_gn_slots > 0) HIP_TRY(hipMemsetAsync(gn_stats, 0, (size_t)n_gn_slots * max_batch * 64 * sizeof(double), s));
+  for (const Op& o : ops) {
+    switch (o.kind) {
+      case OP_NCHW_IN: {
+        const TensorDesc& t = tensors[o.out];
+        DDMI_TRY(launch_nchw_to_nhwc((const float*)ext[o.ext], tptr(o.out), dt, B, t.C, t.H * t.W, s));
+        break;
+      }
+      case OP_GN: {
+        const TensorDesc& t = tensors[o.in];
+        const GNW& g = gns[o.gn];
+        DDMI_REQUIRE(g.C == t.C, "groupnorm channel mismatch");
+        double* st = gn_stats + (size_t)o.gn_slot * max_batch * 64;
+        DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, t.C, s));
+        DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, t.C, s));
+        break;
+      }
+      case OP_CONV: {
+        ConvArgs a;
+        fill_conv_args(*this, o, B, &a);
+        DDMI_REQUIRE(tensors[o.in].C == a.Cin, "conv input channel mismatch");
+        if (o.out_nchw) a.y_nchw = (float*)ext[o.ext];
+        else a.y = tptr(o.out);
+        if (o.res >= 0) a.res = tptr(o.res);
+        if (o.emb_off >= 0) {
+          DDMI_REQUIRE(emb != nullptr, "conv needs the time embedding");
+          a.emb = emb + o.emb_off;
+          a.emb_stride = emb_stride;
+        }
+        a.splitk = conv_pick_splitk(a, dt);
+        a.splitk_ws = splitk_ws;
+        if (a.splitk > 1)
+          DDMI_REQUIRE((size_t)a.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
+        DDMI_TRY(launch_conv(a, dt, s));
+        break;
+      }
+      case OP_ATTN_LEGACY: {
+        const TensorDesc& t = tensors[o.out];
+        DDMI_TRY(launch_attention_legacy(tptr(o.in), tptr(o.out), dt, B, t.H * t.W, o.heads, s));
+        break;
+      }
+      case OP_ATTN_FULL: {
+        // single-head attention over T = H*W tokens with C channels: q = in, k = in2, v = res
+        const TensorDesc& t = tensors[o.out];
+        int T = t.H * t.W, C = t.C;
+        void *q = tptr(o.in), *k = tptr(o.in2), *v = tptr(o.res), *S = tptr(o.tmp0), *vT = tptr(o.tmp1);
+        DDMI_TRY(launch_gemm_nt(q, k, S, dt, B, T, T, C, (int64_t)T * C, (int64_t)T * C, (int64_t)T * T, o.scale, s));
+        DDMI_TRY(launch_softmax_rows(S, dt, (int64_t)B * T, T, s));
+        DDMI_TRY(launch_transpose_2d(v, vT, dt, B, T, C, s));
+        DDMI_TRY(launch_gemm_nt(S, vT, tptr(o.out), dt, B, T, C, T, (int64_t)T * T, (int64_t)C * T, (int64_t)T * C, 1.0f, s));
+        break;
+      }
+      case OP_CONCAT: {
+        const TensorDesc &ta = tensors[o.in], &tb = tensors[o.in2];
+        DDMI_TRY(launch_concat(tptr(o.in), ta.C, tptr(o.in2), tb.C, tptr(o.out), dt, (int64_t)B * ta.H * ta.W, s));
+        break;
+      }
+      case OP_EXPORT: {
+        const TensorDesc& t = tensors[o.in];
+        if (ext[o.ext] == nullptr) break;
+        if (o.out_nchw)
+          DDMI_TRY(launch_nhwc_to_nchw(tptr(o.in), dt, (float*)ext[o.ext], B, t.C, t.H * t.W, s));
+        else
+          HIP_TRY(hipMemcpyAsync(ext[o.ext], tptr(o.in), tbytes(o.in, B), hipMemcpyDeviceToDevice, s));
+        break;
+      }
+      default:
+        return ddmi_fail(DDMI_ERR_STATE, "unknown op");
+    }
+  }
+  return DDMI_OK;
+}

@@ -1,0 +1,153 @@
+/* ddmi_hip.h - C ABI of libddmi_hip.so: the MI355X (gfx950) implementation of the DDMI generation path.
+ *
+ * The reference (mlvlab/DDMI) has no FFI around its sampling path: the seams are Python call signatures
+ * (SURVEY.md 8b).  Each entry point below names the reference function it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 (DDMI_OK) on success, a non-zero DDMI_ERR_* code otherwise; the message for the
+ *     calling thread is available from ddmi_last_error().  No exception crosses this boundary.
+ *   - all tensor pointers are DEVICE pointers unless the parameter says "host"; the caller owns every input and
+ *     output buffer.  The library owns only packed weights and a per-handle activation workspace sized at
+ *     *_finalize for `max_batch`.
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously on it: no allocation, no host synchronisation inside forward/step calls, so the
+ *     calls are hipGraph-capturable.
+ *   - handles are not thread-safe; distinct handles may be used concurrently on distinct streams.
+ *   - model-boundary tensors keep the reference layout: NCHW fp32.  Internally activations are NHWC in the
+ *     handle's numerics mode (fp32 operands on the exact fp32 MFMA, or bf16 operands with fp32 accumulation).
+ */
+#ifndef DDMI_HIP_H
+#define DDMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DDMI_OK = 0, DDMI_ERR_INVALID = 1, DDMI_ERR_HIP = 2, DDMI_ERR_STATE = 3, DDMI_ERR_MISSING_WEIGHT = 4 };
+
+/* numerics modes: PARITY = fp32 storage + v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains), used to match the
+ * reference's CPU fp32 path to 1e-3; PERF = bf16 storage/operands + fp32 accumulate (the reference's GPU path
+ * is fp16 autocast, tools/ldm/image.py:32-36,239). */
+enum { DDMI_PARITY_FP32 = 0, DDMI_PERF_BF16 = 1 };
+
+/* plane / tensor layouts at the decoder -> MLP seam */
+enum { DDMI_LAYOUT_NCHW_F32 = 0, DDMI_LAYOUT_NHWC_NATIVE = 1 };
+
+int ddmi_init(int device);                 /* selects the device, checks it is gfx950 */
+const char* ddmi_last_error(void);         /* thread-local message of the last failing call */
+const char* ddmi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Denoiser: replaces UNetModel.forward(x, timesteps)   models/ldm/modules/diffusionmodules/openaimodel.py:761-793
+ * (constructor topology :493-743; the DDPM wrapper calls it as self.model(x, t, cond), diffusion/ddpm.py:258,305)
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct ddmi_unet ddmi_unet;
+typedef struct {
+  int image_size;               /* latent H = W                       (unetconfig.image_size) */
+  int in_channels, model_channels, out_channels, num_res_blocks;
+  int n_mult;  int channel_mult[8];
+  int n_attn;  int attention_resolutions[8];   /* downsample rates with attention */
+  int num_head_channels;        /* must be 32 */
+  int max_batch;
+  int numerics;                 /* DDMI_PARITY_FP32 | DDMI_PERF_BF16 */
+} ddmi_unet_cfg;
+
+int ddmi_unet_create(const ddmi_unet_cfg* cfg, ddmi_unet** out);
+/* hands over one state-dict tensor (reference key names, e.g. "input_blocks.4.0.in_layers.2.weight");
+ * `data` is a HOST pointer to contiguous fp32 */
+int ddmi_unet_load_weight(ddmi_unet* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_unet_finalize(ddmi_unet* h);      /* packs weights for MFMA, plans the workspace; frees host copies */
+/* x [B,Cin,S,S] fp32, t [B] int64 (device), eps_out [B,Cout,S,S] fp32 */
+int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps_out, int B, void* stream);
+int ddmi_unet_destroy(ddmi_unet* h);
+/* bytes held by the handle: [0] packed weights, [1] activation arena, [2] split-K slabs */
+int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sampler step: replaces p_mean_variance + q_posterior + p_sample (diffusion/ddpm.py:257-281), and
+ * model_predictions + the DDIM update (ddpm.py:303-332, 353-368), given the denoiser output.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  float sqrt_one_minus_ac;   /* sqrt_one_minus_alphas_cumprod[t]      ddpm.py:476-477 */
+  float sqrt_recip_ac;       /* sqrt_recip_alphas_cumprod[t]          ddpm.py:238 */
+  float sqrt_recipm1_ac;     /* sqrt_recipm1_alphas_cumprod[t]        ddpm.py:239 */
+  float coef1, coef2;        /* posterior_mean_coef1/2[t]             ddpm.py:250-251   (ANCESTRAL) */
+  float noise_scale;         /* [t!=0] * exp(0.5*posterior_log_variance_clipped[t])  ddpm.py:280-281 */
+  float sqrt_ac_next;        /* sqrt(alphas_cumprod[t_next])          ddpm.py:366       (DDIM) */
+  float c_dir;               /* sqrt(1 - alpha_next - sigma^2)        ddpm.py:361 */
+  float sigma;               /* eta * sqrt(...)                       ddpm.py:360 */
+} ddmi_step_coefs;
+enum { DDMI_STEP_ANCESTRAL = 0, DDMI_STEP_DDIM = 1, DDMI_STEP_DDIM_LAST = 2 };
+/* x, model_out, noise (nullable -> 0), x_out, x0_out (nullable): [B,C,HW] fp32 NCHW; mixing_logit [C] or null */
+int ddmi_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
+                   const ddmi_step_coefs* coefs, int mode, int clip_denoised, float* x_out, float* x0_out, int B,
+                   int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * D2C-VAE image decoder: replaces Autoencoder.decode (models/d2c_vae/autoencoder_unet.py:855-858) =
+ * post_quant_conv + Decoder.forward (:790-829).  Keys: "post_quant_conv.*", "decoder.*".
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct ddmi_decoder2d ddmi_decoder2d;
+typedef struct {
+  int embed_dim;               /* latent channels (model.embed_dim) */
+  int z_channels, resolution, out_ch, ch, num_res_blocks;
+  int n_mult;  int ch_mult[8];
+  int n_attn;  int attn_resolutions[8];
+  int n_hdbf;  int hdbf_resolutions[8];
+  int latent_size;             /* = resolution / 2^(n_mult-1) */
+  int max_batch;
+  int numerics;
+} ddmi_decoder2d_cfg;
+int ddmi_decoder2d_create(const ddmi_decoder2d_cfg* cfg, ddmi_decoder2d** out);
+int ddmi_decoder2d_load_weight(ddmi_decoder2d* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_decoder2d_finalize(ddmi_decoder2d* h);
+int ddmi_decoder2d_num_planes(ddmi_decoder2d* h, int* n, int plane_hw[8]);
+/* z [B,embed_dim,S,S] fp32 NCHW; planes[i]: coarse -> fine, each [B,out_ch,P_i,P_i] in `layout`
+ * (DDMI_LAYOUT_NCHW_F32, or DDMI_LAYOUT_NHWC_NATIVE = channels-last in the handle's storage dtype, the layout the
+ * fused plane-sampling kernel wants) */
+int ddmi_decoder2d_forward(ddmi_decoder2d* h, const float* z, void* const* planes, int layout, int B, void* stream);
+int ddmi_decoder2d_destroy(ddmi_decoder2d* h);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused HDPE plane sampling + coordinate MLP (image): replaces MLP.forward (models/d2c_vae/mlp.py:34-66):
+ * 3 x F.grid_sample(bilinear, border, align_corners=False) (utils/general_utils.py:122-123) + 4 StyledResBlocks
+ * + ToRGB (models/d2c_vae/blocks.py:604-638, 390-412) + FusedLeakyReLU (op/fused_bias_act_kernel.cu:19-49).
+ * Keys: the MLP state dict ("time_mlp.1.weight", "net_res1.conv1.conv.weight", ...).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct ddmi_mlp2d ddmi_mlp2d;
+typedef struct {
+  int in_ch, out_ch, ch, latent_dim;   /* mlpconfig; supported: in_ch 2, out_ch 3, ch 256, latent_dim 64 */
+  int numerics;
+} ddmi_mlp2d_cfg;
+int ddmi_mlp2d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp2d** out);
+int ddmi_mlp2d_load_weight(ddmi_mlp2d* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_mlp2d_finalize(ddmi_mlp2d* h);
+/* planes[3] coarse->fine in `layout` (see above), plane_hw[3]; coords [N,2] fp32 (x,y in [-1,1]) - the grid
+ * convert_to_coord_format_2d builds, flattened row-major; si = scale injection (get_scale_injection);
+ * noise: optional [12,B,N] fp32 NoiseInjection draws (blocks.py:286-297), null = none; rgb_out [B,3,N] fp32 */
+int ddmi_hdpe_mlp2d(ddmi_mlp2d* h, const void* const* planes, const int* plane_hw, int layout, const float* coords,
+                    float si, const float* noise, float* rgb_out, int B, int N, void* stream);
+int ddmi_mlp2d_destroy(ddmi_mlp2d* h);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Diagnostic single-op entry points (used by the parity tests; reference-layout tensors in, reference-layout
+ * tensors out; they allocate temporaries and synchronise - not for the hot path).
+ * --------------------------------------------------------------------------------------------------------- */
+/* F.conv2d(x, w, b, stride, padding=k/2) optionally preceded by nearest x2 upsampling; k in {1,3} */
+int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                   int Cout, int k, int stride, int upsample, int numerics, int splitk);
+/* GroupNorm(32 groups, eps) [+ SiLU] over [B,C,HW] */
+int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
+                      int silu, int numerics);
+/* QKVAttentionLegacy (openaimodel.py:397-422): qkv [B, heads*3*32, T] -> out [B, heads*32, T] */
+int ddmi_op_attention_legacy(const float* qkv, float* out, int B, int heads, int T, int numerics);
+/* timestep_embedding (util.py:150-170): t [B] int64 -> [B, dim] */
+int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDMI_HIP_H */

@@ -1,0 +1,166 @@
+"""Network-level parity on the GPU: UNet (U2), decoder (D1), fused plane-sampling + MLP (M1) and generate() chains
+(G1) against golden vectors captured from the reference, in both numerics modes; plus full-size AFHQ checks against
+the CPU oracle on the same named-seed weights."""
+import numpy as np
+import pytest
+import torch
+
+from ddmi_amd import initweights as iw
+from ddmi_amd.autoencoder import Autoencoder
+from ddmi_amd.coords import generation_coords, get_scale_injection
+from ddmi_amd.ddpm import DDPM
+from ddmi_amd.mlp import MLP
+from ddmi_amd.unet import UNetModel
+from helpers import AFHQ_DD, AFHQ_EMBED, AFHQ_UNET, MLP_CFG, TOL_BF16, TOL_FP32, named_state, rel_err, to_torch
+from oracle import ddmi_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_unet(cfg, tag, numerics, max_batch=2):
+    m = UNetModel(**cfg, numerics=numerics, max_batch=max_batch)
+    m.load_state_dict(named_state(tag, m.manifest()))
+    return m
+
+
+def make_vae(dd, embed, tag, numerics, max_batch=2):
+    m = Autoencoder(dd, embed, numerics=numerics, max_batch=max_batch)
+    m.load_state_dict(named_state(tag, m.manifest()))
+    return m
+
+
+def make_mlp(tag, numerics, overrides=None):
+    m = MLP(**MLP_CFG, numerics=numerics)
+    st = named_state(tag, m.manifest())
+    if overrides:
+        st.update(overrides)
+    m.load_state_dict(st)
+    return m
+
+
+@pytest.mark.parametrize("name,cfgname", [("a", "TOY_UNET"), ("b", "TOY_UNET_B")])
+@pytest.mark.parametrize("numerics,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_unet_golden(golden, name, cfgname, numerics, tol):
+    u2 = golden.npz("U2_unet.npz")
+    cfg = golden.json("configs.json")[cfgname]
+    unet = make_unet(cfg, f"U2{name}.unet", numerics)
+    x = torch.from_numpy(u2[f"{name}.x"]).to(DEV)
+    t = torch.from_numpy(u2[f"{name}.t"]).to(DEV)
+    eps = unet(x, t)
+    assert rel_err(eps, u2[f"{name}.eps"]) < tol
+    # batch-size independence + determinism: sample 1 alone gives the same row
+    eps1 = unet(x[1:2].contiguous(), t[1:2].contiguous())
+    assert rel_err(eps1, eps[1:2]) < (1e-6 if numerics == "fp32" else 1e-2)
+    assert torch.equal(unet(x, t), eps)
+
+
+@pytest.mark.parametrize("numerics,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_decoder_golden(golden, numerics, tol):
+    d1 = golden.npz("D1_decoder.npz")
+    cfgs = golden.json("configs.json")
+    vae = make_vae(cfgs["TOY_DD"], cfgs["TOY_EMBED"], "D1.vae", numerics)
+    z = torch.from_numpy(d1["z"]).to(DEV)
+    planes = vae.decode(z)
+    ref_layout = vae.decode(z, reference_layout=True)
+    assert [tuple(p.shape) for p in planes] == [(2, 64, 8, 8), (2, 64, 16, 16), (2, 64, 32, 32)]
+    for i, (p, r) in enumerate(zip(planes, ref_layout)):
+        assert rel_err(p.float(), d1[f"plane{i}"]) < tol, i
+        assert rel_err(r, d1[f"plane{i}"]) < tol, i
+        assert r.is_contiguous() and r.dtype == torch.float32
+
+
+@pytest.mark.parametrize("numerics,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_mlp_golden(golden, numerics, tol):
+    d1 = golden.npz("D1_decoder.npz")
+    m1 = golden.npz("M1_mlp.npz")
+    mlp = make_mlp("M1.mlp", numerics)
+    planes = [torch.from_numpy(d1[f"plane{i}"]).to(DEV) for i in range(3)]  # reference-layout planes (NCHW fp32)
+    native = torch.float32 if numerics == "fp32" else torch.bfloat16
+    planes_cl = [p.to(native).contiguous(memory_format=torch.channels_last) for p in planes]
+    for R in (32, 48, 8):  # 48: si = 5.33 and fractional bilinear weights; 8: tile tail (128 points < tile)
+        coords = torch.from_numpy(m1[f"coords{R}"])
+        rgb = mlp(coords, hdbf=planes, si=float(m1[f"si{R}"]))
+        assert rgb.shape == (2, 3, R, R)
+        assert rel_err(rgb, m1[f"rgb{R}"]) < tol, R
+        rgb2 = mlp(coords, hdbf=planes_cl, si=float(m1[f"si{R}"]))
+        assert rel_err(rgb2, m1[f"rgb{R}"]) < tol, R
+    assert rel_err(generation_coords(48), m1["coords48"]) < 2e-7
+    assert get_scale_injection(48) == float(m1["si48"])
+
+
+def test_mlp_noise_injection_golden(golden):
+    d1 = golden.npz("D1_decoder.npz")
+    m1 = golden.npz("M1_mlp.npz")
+    man = golden.json("manifests.json")["M1n.mlp"]
+    over = {k: iw.normal("M1n.mlp", k, tuple(s), 0.0, 0.1) for k, s in man.items() if k.endswith("noise.weight")}
+    mlp = make_mlp("M1n.mlp", "fp32", over)
+    planes = [torch.from_numpy(d1[f"plane{i}"]).to(DEV) for i in range(3)]
+    draws = np.stack([iw.normal("M1n", f"draw{i}", (2, 1, 32, 32)).reshape(2, 1024) for i in range(12)])
+    rgb = mlp(torch.from_numpy(m1["coords32"]), hdbf=planes, si=float(m1["si32"]), noise=draws)
+    assert rel_err(rgb, m1["rgb32_noise"]) < TOL_FP32
+
+
+@pytest.mark.parametrize("name,T,S,eta", [("ddim_eta0", 1000, 10, 0.0), ("ddim_eta1", 1000, 10, 1.0),
+                                          ("anc", 10, 10, 1.0), ("anc250", 250, 250, 1.0)])
+def test_generate_chain_golden(golden, name, T, S, eta):
+    """tools/ldm/image.py:225-249 end to end in parity mode: sample -> decode -> mlp -> clamp, noise fed explicitly
+    in the reference's draw order."""
+    g1 = golden.npz("G1_generate.npz")
+    cfgs = golden.json("configs.json")
+    unet = make_unet(cfgs["TOY_UNET"], "U2a.unet", "fp32")
+    ddpm = DDPM(model=unet, timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta, channels=64, image_size=8)
+    ddpm.load_state_dict({"mixing_logit": iw.fill_state("G1.ddpm", [("mixing_logit", (1, 64, 1, 1))])["mixing_logit"]},
+                         strict=False)
+    shape = list(g1["x_T"].shape)
+    ndraw = S - 1 if S < T else T
+    noises = [iw.normal("G1", f"{name}.n{i}", shape) for i in range(ndraw)]
+    z = ddpm.sample(shape, noise=g1["x_T"], step_noise=noises, device=DEV)
+    assert rel_err(z, g1[f"{name}.z"]) < TOL_FP32
+    if name == "anc250":
+        return
+    vae = make_vae(cfgs["TOY_DD"], cfgs["TOY_EMBED"], "D1.vae", "fp32")
+    mlp = make_mlp("M1.mlp", "fp32")
+    img = mlp(generation_coords(32), hdbf=vae.decode(z), si=get_scale_injection(32)).clamp(-1.0, 1.0)
+    assert rel_err(img, g1[f"{name}.img"]) < TOL_FP32
+
+
+# ---------------- full-size AFHQ shapes against the CPU oracle (same named-seed weights) ---------------------------
+def test_afhq_unet_full_size_vs_oracle():
+    unet32 = make_unet(AFHQ_UNET, "afhq.unet", "fp32", max_batch=1)
+    st = named_state("afhq.unet", unet32.manifest())
+    x = iw.normal("afhq", "x", (1, 64, 64, 64))
+    t = torch.tensor([437], dtype=torch.int64)
+    ref = O.unet_forward(O.to_state(st), AFHQ_UNET, torch.from_numpy(x), t)
+    eps32 = unet32(torch.from_numpy(x).to(DEV), t.to(DEV))
+    assert rel_err(eps32, ref) < TOL_FP32
+    del unet32
+    torch.cuda.empty_cache()
+    unet16 = make_unet(AFHQ_UNET, "afhq.unet", "bf16", max_batch=1)
+    eps16 = unet16(torch.from_numpy(x).to(DEV), t.to(DEV))
+    assert rel_err(eps16, ref) < TOL_BF16
+
+
+def test_afhq_decoder_and_mlp_full_size_vs_oracle():
+    z = iw.normal("afhq", "z", (1, 64, 64, 64))
+    vae = make_vae(AFHQ_DD, AFHQ_EMBED, "afhq.vae", "fp32", max_batch=1)
+    st = named_state("afhq.vae", vae.manifest())
+    ref_planes = O.vae_decode(O.to_state(st), AFHQ_DD, torch.from_numpy(z))
+    planes = vae.decode(torch.from_numpy(z).to(DEV))
+    assert [tuple(p.shape) for p in planes] == [(1, 64, 64, 64), (1, 64, 128, 128), (1, 64, 256, 256)]
+    for p, r in zip(planes, ref_planes):
+        assert rel_err(p, r) < TOL_FP32
+    mlp = make_mlp("afhq.mlp", "fp32")
+    mst = named_state("afhq.mlp", mlp.manifest())
+    ref_rgb = O.image_mlp(O.to_state(mst), O.generate_coords(256), ref_planes, 1.0)
+    rgb = mlp(generation_coords(256), hdbf=planes, si=get_scale_injection(256))
+    assert rel_err(rgb, ref_rgb) < TOL_FP32
+    del vae
+    torch.cuda.empty_cache()
+    vae16 = make_vae(AFHQ_DD, AFHQ_EMBED, "afhq.vae", "bf16", max_batch=1)
+    planes16 = vae16.decode(torch.from_numpy(z).to(DEV))
+    for p, r in zip(planes16, ref_planes):
+        assert rel_err(p.float(), r) < TOL_BF16
+    mlp16 = make_mlp("afhq.mlp", "bf16")
+    rgb16 = mlp16(generation_coords(256), hdbf=planes16, si=1.0)
+    assert rel_err(rgb16, ref_rgb) < TOL_BF16

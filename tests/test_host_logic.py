@@ -1,0 +1,107 @@
+"""CPU-only checks of the host side: C-ABI symbols, state-dict manifests, schedules, integer time pairs."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from ddmi_amd import _lib
+from ddmi_amd.autoencoder import decoder_manifest
+from ddmi_amd.ddpm import DDPM, ddim_time_pairs
+from ddmi_amd.mlp import mlp_manifest
+from ddmi_amd.unet import unet_manifest
+from helpers import AFHQ_DD, AFHQ_EMBED, AFHQ_UNET
+from oracle import ddmi_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports everything include/ddmi_hip.h declares."""
+    if not os.path.exists(_lib.LIB_PATH):
+        from ddmi_amd.build import build_library
+        build_library()
+    header = open(os.path.join(ROOT, "include", "ddmi_hip.h")).read()
+    declared = set(re.findall(r"\b(ddmi_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ddmi_unet_cfg", "ddmi_decoder2d_cfg", "ddmi_mlp2d_cfg", "ddmi_step_coefs"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in _lib.lib().ddmi_version()
+
+
+def test_struct_layouts_match_header():
+    # sizes of the by-value / by-pointer structs (all int/float fields, no padding)
+    assert ctypes.sizeof(_lib.UnetCfg) == 4 * (6 + 8 + 1 + 8 + 3)
+    assert ctypes.sizeof(_lib.Decoder2dCfg) == 4 * (7 + 8 + 1 + 8 + 1 + 8 + 3)
+    assert ctypes.sizeof(_lib.Mlp2dCfg) == 4 * 5
+    assert ctypes.sizeof(_lib.StepCoefs) == 4 * 9
+
+
+def test_errors_are_reported_without_a_gpu():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    cfg = _lib.UnetCfg()
+    cfg.max_batch = 0
+    assert L.ddmi_unet_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"max_batch" in L.ddmi_last_error()
+    with pytest.raises(_lib.DdmiError):
+        _lib.check(L.ddmi_unet_create(ctypes.byref(cfg), ctypes.byref(h)))
+
+
+def test_manifests_match_reference_state_dicts(golden):
+    man = golden.json("manifests.json")
+    cfgs = golden.json("configs.json")
+
+    def same(ours, ref):
+        return {k: tuple(v) for k, v in ours} == {k: tuple(v) for k, v in ref.items()}
+    assert same(unet_manifest(**cfgs["TOY_UNET"]), man["U2a.unet"])
+    assert same(unet_manifest(**cfgs["TOY_UNET_B"]), man["U2b.unet"])
+    assert same(unet_manifest(**AFHQ_UNET), man["afhq.unet"])           # 368 tensors, 519 M parameters
+    assert same(decoder_manifest(cfgs["TOY_DD"], cfgs["TOY_EMBED"]), man["D1.vae"])
+    assert same(decoder_manifest(AFHQ_DD, AFHQ_EMBED), man["afhq.vae_decoder"])
+    assert same(mlp_manifest(**cfgs["MLP_CFG"]), man["M1.mlp"])
+    nparams = sum(int(np.prod(s)) for _, s in unet_manifest(**AFHQ_UNET))
+    assert abs(nparams - 519.2e6) < 0.2e6
+
+
+def test_product_schedule_bitexact_vs_reference(golden):
+    s1 = golden.npz("S1_schedule.npz")
+    for T in (1000, 250, 10):
+        d = DDPM(model=None, timesteps=T, sampling_timesteps=T, channels=4)
+        for name in ("betas", "alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                     "sqrt_one_minus_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+                     "posterior_log_variance_clipped", "posterior_variance", "alphas_cumprod_prev",
+                     "sqrt_alphas_cumprod", "log_one_minus_alphas_cumprod"):
+            assert np.array_equal(getattr(d, name).view(np.uint32), s1[f"T{T}.{name}"].view(np.uint32)), (T, name)
+
+
+def test_product_time_pairs_bitexact(golden):
+    for key, ref in golden.json("S1_time_pairs.json").items():
+        T, S = map(int, key.split("_"))
+        assert [list(p) for p in ddim_time_pairs(T, S)] == ref
+    for S in range(1, 1000):  # and against torch.linspace itself for every S
+        times = list(reversed(torch.linspace(-1, 999, steps=S + 1).int().tolist()))
+        assert ddim_time_pairs(1000, S) == list(zip(times[:-1], times[1:])), S
+    pairs = ddim_time_pairs(1000, 250)
+    assert pairs[0] == (999, 995) and pairs[-1] == (3, -1) and len(pairs) == 250
+
+
+def test_ddim_coefs_match_oracle():
+    d = DDPM(model=None, timesteps=1000, sampling_timesteps=50, ddim_sampling_eta=0.7, channels=4)
+    sched = O.make_schedule(1000)
+    for t, tn in ddim_time_pairs(1000, 50)[:-1]:
+        k = d.ddim_coefs(t, tn)
+        san, c, sigma = O.ddim_coefs(sched, t, tn, 0.7)
+        assert abs(k.sqrt_ac_next - san) <= 1e-7 * abs(san)
+        assert abs(k.c_dir - c) <= 2e-7 * abs(c) and abs(k.sigma - sigma) <= 2e-7 * abs(sigma)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DdmiError, match="no fallback"):
+        _lib.lib()
