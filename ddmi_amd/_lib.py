@@ -54,6 +54,8 @@ SYMBOLS = {
     "ddmi_init": (_I, [_I]),
     "ddmi_last_error": (C.c_char_p, []),
     "ddmi_version": (C.c_char_p, []),
+    "ddmi_profile_enable": (_I, [_I]),
+    "ddmi_profile_collect": (_I, [C.c_char_p, C.c_uint64]),
     "ddmi_unet_create": (_I, [C.POINTER(UnetCfg), C.POINTER(_VP)]),
     "ddmi_unet_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
     "ddmi_unet_finalize": (_I, [_VP]),
@@ -111,6 +113,17 @@ def init_device(index: int) -> None:
     if index not in _inited_devices:
         check(lib().ddmi_init(index))
         _inited_devices.add(index)
+
+
+def profile_enable(every_n_forwards: int) -> None:
+    check(lib().ddmi_profile_enable(int(every_n_forwards)))
+
+
+def profile_collect() -> dict:
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().ddmi_profile_collect(buf, len(buf)))
+    return json.loads(buf.value.decode())
 
 
 def stream_ptr() -> int:

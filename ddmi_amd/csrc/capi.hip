@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 #include "models.h"
+#include "prof.h"
 
 const char* ddmi_error_cstr();
 
@@ -29,6 +30,19 @@ int ddmi_init(int device) {
   HIP_TRY(hipGetDeviceProperties(&p, device));
   if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
     return ddmi_fail(DDMI_ERR_INVALID, std::string("ddmi_init: this library is built for gfx950 only, device is ") + p.gcnArchName);
+  return DDMI_OK;
+}
+
+// ---- live kernel timing (HIP events on the launch stream) -------------------------------------------------
+int ddmi_profile_enable(int every_n_forwards) {
+  prof_enable(every_n_forwards);
+  return DDMI_OK;
+}
+int ddmi_profile_collect(char* json_out, uint64_t capacity) {
+  DDMI_REQUIRE(json_out && capacity > 2, "profile_collect: bad buffer");
+  std::string j = prof_collect_json();
+  if (j.size() + 1 > capacity) return ddmi_fail(DDMI_ERR_INVALID, "profile_collect: buffer too small");
+  std::memcpy(json_out, j.c_str(), j.size() + 1);
   return DDMI_OK;
 }
 
@@ -216,9 +230,8 @@ int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, flo
   void *xn, *yn, *st;
   DDMI_TRY(sc.get((size_t)B * C * HW * dt_size(dt), &xn));
   DDMI_TRY(sc.get((size_t)B * C * HW * dt_size(dt), &yn));
-  DDMI_TRY(sc.get((size_t)B * 64 * sizeof(double), &st));
+  DDMI_TRY(sc.get(GN_STATS_DOUBLES(B) * sizeof(double), &st));
   DDMI_TRY(launch_nchw_to_nhwc(x, xn, dt, B, C, HW, 0));
-  HIP_TRY(hipMemsetAsync(st, 0, (size_t)B * 64 * sizeof(double), 0));
   DDMI_TRY(launch_gn_stats(xn, dt, (double*)st, B, HW, C, 0));
   DDMI_TRY(launch_gn_apply(xn, yn, dt, (const double*)st, gamma, beta, eps, silu, B, HW, C, 0));
   DDMI_TRY(launch_nhwc_to_nchw(yn, dt, y, B, C, HW, 0));

@@ -14,6 +14,7 @@
 //                     -> lane holds out channels 16*df + 4*(lane>>4) + j of its query: 8/16-byte vector stores.
 // bf16 path: v_mfma_f32_16x16x32_bf16, fp32 softmax/accumulate.  fp32 (parity) path: v_mfma_f32_16x16x4_f32.
 #include "kernels.h"
+#include "prof.h"
 #include <math.h>
 
 #define ATT_D 32
@@ -207,6 +208,7 @@ int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, in
   DDMI_REQUIRE(B > 0 && T > 0 && heads > 0, "attention: bad shape");
   dim3 grid(cdiv(T, ATT_QB), B * heads);
   float scale = 1.0f / sqrtf((float)ATT_D);
+  PROF_SCOPE("attention_legacy", 4.0 * B * heads * (double)T * T * ATT_D, 4.0 * B * heads * T * ATT_D * dt_size(dt), s);
   if (dt == DT_BF16)
     hipLaunchKernelGGL(attention_legacy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, T, heads, scale);
   else

@@ -16,6 +16,7 @@
 // * epilogue fuses + bias[n] + emb[b][n] + residual, * out_scale, optional fp32-NCHW store, optional split-K
 //   (fp32 partial slabs [z][M][Cout] written with plain 16-byte stores, summed by splitk_finish_kernel).
 #include "kernels.h"
+#include "prof.h"
 
 struct ConvK {
   const void* x;
@@ -380,7 +381,15 @@ static int launch_cfg(ConvK k, int splitk, int batch, hipStream_t s) {
                                 2 * stage));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), 2 * stage, s, k);
+  {
+    // algorithmic work of this launch: 2*M*N*K flops; operands + output once
+    const double Kdim = (double)k.KH * k.KW * k.Cin, Mtot = (double)k.M * batch;
+    const double flops = 2.0 * Mtot * k.Cout * Kdim;
+    const double bytes = sizeof(T) * ((double)batch * k.B * k.Hin * k.Win * k.Cin + (double)k.Cout * Kdim * (k.w_bstride ? batch : 1) + Mtot * k.Cout);
+    static const std::string name = std::string("conv_igemm<") + (sizeof(T) == 2 ? "bf16" : "f32") + "," + std::to_string(BM) + "x" + std::to_string(BN) + ">";
+    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), 2 * stage, s, k);
+  }
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

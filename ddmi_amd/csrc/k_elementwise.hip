@@ -1,6 +1,7 @@
 // HBM-bound elementwise / layout kernels: fused DDPM-DDIM step, NCHW<->NHWC, concat, weight packing,
 // timestep embedding and the small fp32 dense layers of the time-embedding path.
 #include "kernels.h"
+#include "prof.h"
 
 // =====================================================================================================
 // Fused eps-mix -> x0 -> x_{t-1} step.  Replaces diffusion/ddpm.py:257-281 (p_mean_variance + p_sample) and
@@ -78,6 +79,7 @@ int launch_ddpm_step(const float* x, const float* model_out, const float* noise,
                                  (uintptr_t)x0_out) % 16 == 0);
   int64_t nvec = vec4 ? n / 4 : n;
   int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 8);
+  PROF_SCOPE("ddpm_step", 0, (noise && mode != STEP_DDIM_LAST ? 16.0 : 12.0) * (double)n, stream);
   if (vec4)
     hipLaunchKernelGGL(ddpm_step_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, mixing_logit, k,
                        mode, clip, x_out, x0_out, C, HW, nvec);
@@ -170,6 +172,7 @@ int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int d
   DDMI_REQUIRE(Ca % per == 0 && Cb % per == 0, "concat: channels must be multiples of the 16-byte vector");
   int va = Ca / per, vb = Cb / per;
   int64_t nvec = npix * (va + vb);
+  PROF_SCOPE("concat", 0, 32.0 * (double)nvec, s);
   int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 16);
   hipLaunchKernelGGL(concat_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)a, va, (const uint4*)b, vb,
                      (uint4*)out, nvec);

@@ -1,9 +1,10 @@
 // GroupNorm(32 groups) over NHWC activations, fp32 statistics (util.py:198-215 eps 1e-5; autoencoder_unet.py:46-47
 // eps 1e-6), optionally fused with SiLU.  HBM-bound: stats pass reads x once, apply pass reads x and writes y.
-//   gn_stats : per-(sample, group) sum / sum-of-squares; per-thread fp32 partials over a few dozen pixels, LDS fp32
-//              combine per block, fp64 global atomics across blocks (so E[x^2]-E[x]^2 keeps ~1e-7 relative accuracy)
+//   gn_stats : per-(sample, group) sum / sum-of-squares; per-thread fp32 partials over a few dozen pixels, fixed-order
+//              fp64 combine per block and across blocks (deterministic; E[x^2]-E[x]^2 keeps ~1e-7 relative accuracy)
 //   gn_apply : y = silu?(x * (rstd*gamma) + (beta - mean*rstd*gamma)), per-channel scale/shift staged in LDS
 #include "kernels.h"
+#include "prof.h"
 
 #define GN_GROUPS 32
 
@@ -33,22 +34,23 @@ template <> struct Vec16<bf16_t> {
   }
 };
 
-// grid (nsplit, B); block = NV * R threads (NV = C / vec channels-vectors per pixel, R pixel lanes)
+// grid (nsplit, B); block = NV * R threads (NV = C / vec channel-vectors per pixel, R pixel lanes).
+// Deterministic: per-thread fp32 partials -> LDS [R][C] -> 64 threads sum (r, channel-in-group) in a fixed order in
+// fp64 -> part[b][split][group*2 + {sum, sumsq}].  No atomics, no zero-fill; bit-identical from run to run.
+#define GN_MAXSPLIT 64
 template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int HW, int C, int NV, int R) {
+__global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ part, int HW, int C, int NV, int R) {
   constexpr int VN = Vec16<T>::N;
-  __shared__ float gs[GN_GROUPS * 2];
+  extern __shared__ float red[];  // s1[R][C] | s2[R][C]
   int b = blockIdx.y;
   int tid = threadIdx.x;
-  if (tid < GN_GROUPS * 2) gs[tid] = 0.f;
-  __syncthreads();
   int v = tid % NV, r = tid / NV;
   int per = cdiv(HW, gridDim.x);
   int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
-  float s1[VN], s2[VN];
-#pragma unroll
-  for (int i = 0; i < VN; ++i) s1[i] = s2[i] = 0.f;
   if (r < R) {
+    float s1[VN], s2[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) s1[i] = s2[i] = 0.f;
     const T* base = x + (int64_t)b * HW * C + (int64_t)v * VN;
     for (int p = p0 + r; p < p1; p += R) {
       float t[VN];
@@ -59,35 +61,48 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ st
         s2[i] += t[i] * t[i];
       }
     }
-    int cpg = C / GN_GROUPS;
 #pragma unroll
     for (int i = 0; i < VN; ++i) {
-      int g = (v * VN + i) / cpg;
-      atomicAdd(&gs[g * 2], s1[i]);
-      atomicAdd(&gs[g * 2 + 1], s2[i]);
+      red[r * C + v * VN + i] = s1[i];
+      red[(R + r) * C + v * VN + i] = s2[i];
     }
   }
   __syncthreads();
-  if (tid < GN_GROUPS * 2) atomicAdd(&stats[(int64_t)b * GN_GROUPS * 2 + tid], (double)gs[tid]);
+  if (tid < GN_GROUPS * 2) {
+    int g = tid >> 1, which = tid & 1;
+    int cpg = C / GN_GROUPS;
+    double acc = 0.0;
+    for (int rr = 0; rr < R; ++rr)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += (double)red[(which * R + rr) * C + c];
+    part[((int64_t)b * GN_MAXSPLIT + blockIdx.x) * (GN_GROUPS * 2) + tid] = acc;
+  }
 }
 
-// grid (nsplit, B); block 256.  dynamic LDS: 2*C floats (scale, shift)
+// grid (nsplit, B); block 256.  dynamic LDS: 2*C floats (scale, shift); nsplit_stats = grid.x of the stats launch
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                       const double* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, int silu, int HW,
-                                                       int C) {
+                                                       const double* __restrict__ part, int nsplit_stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int silu, int HW, int C) {
   constexpr int VN = Vec16<T>::N;
   extern __shared__ float ss[];  // scale[C], shift[C]
+  __shared__ double tot[GN_GROUPS * 2];
   float* scale = ss;
   float* shift = ss + C;
   int b = blockIdx.y;
   int cpg = C / GN_GROUPS;
   double cnt = (double)HW * cpg;
+  if (threadIdx.x < GN_GROUPS * 2) {
+    double acc = 0.0;
+    for (int sidx = 0; sidx < nsplit_stats; ++sidx)
+      acc += part[((int64_t)b * GN_MAXSPLIT + sidx) * (GN_GROUPS * 2) + threadIdx.x];
+    tot[threadIdx.x] = acc;
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     int g = c / cpg;
-    double m = stats[(int64_t)b * GN_GROUPS * 2 + g * 2] / cnt;
-    double var = stats[(int64_t)b * GN_GROUPS * 2 + g * 2 + 1] / cnt - m * m;
+    double m = tot[g * 2] / cnt;
+    double var = tot[g * 2 + 1] / cnt - m * m;
     if (var < 0) var = 0;
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float sc = rstd * gamma[c];
@@ -117,7 +132,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
 static int gn_splits(int B, int HW) {
   // enough blocks to fill 256 CUs a few times over, at least 16 pixels per block
   int want = std::max(1, (256 * 4) / std::max(B, 1));
-  return std::max(1, std::min(want, HW / 16));
+  return std::max(1, std::min(std::min(want, HW / 16), GN_MAXSPLIT));
 }
 
 int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s) {
@@ -129,10 +144,12 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
   int R = std::max(1, 256 / NV);
   int threads = std::max(64, cdiv(NV * R, 64) * 64);
   dim3 g(gn_splits(B, HW), B);
+  size_t lds = (size_t)2 * R * C * sizeof(float);
+  PROF_SCOPE("gn_stats", 0, (double)B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_stats_kernel<float>, g, dim3(threads), 0, s, (const float*)x, stats, HW, C, NV, R);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, g, dim3(threads), lds, s, (const float*)x, stats, HW, C, NV, R);
   else
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, stats, HW, C, NV, R);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, stats, HW, C, NV, R);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -140,13 +157,15 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s) {
   dim3 g(gn_splits(B, HW), B);
+  int ns = gn_splits(B, HW);
   size_t lds = (size_t)2 * C * sizeof(float);
+  PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(256), lds, s, (const float*)x, (float*)y, stats, gamma, beta, eps,
-                       silu, HW, C);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, stats, gamma, beta,
+    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(256), lds, s, (const float*)x, (float*)y, stats, ns, gamma, beta,
                        eps, silu, HW, C);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, stats, ns, gamma,
+                       beta, eps, silu, HW, C);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

@@ -15,6 +15,7 @@
 // are shared through LDS.  The skip path of a block (a second GEMM on the block input) accumulates in registers
 // next to conv1 and is merged in the conv3 epilogue; for block 4 (identity skip) the same registers carry x3.
 #include "kernels.h"
+#include "prof.h"
 
 #define MLP_CH 256
 #define MLP_F 64
@@ -369,6 +370,10 @@ int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s) {
   }
   k.coords = a.coords; k.w = a.w; k.fb = a.fb; k.noise = a.noise; k.noise_w = a.noise_w; k.rgb = a.rgb;
   k.B = a.B; k.N = a.N; k.total = (int64_t)a.B * a.N;
+  // algorithmic work: 954,112 MAC per point (mlp.py:28-32); bytes: planes read once + rgb written
+  double plane_bytes = 0;
+  for (int i = 0; i < 3; ++i) plane_bytes += (double)a.B * a.plane_hw[i] * a.plane_hw[i] * 64 * dt_size(dt);
+  PROF_SCOPE("mlp2d_fused", 2.0 * 954112.0 * (double)k.total, plane_bytes + 12.0 * (double)k.total, s);
   if (dt == DT_BF16) {
     using L = MlpL<bf16_t>;
     size_t lds = (size_t)(2 * L::P * L::XP + L::P * L::FP) * sizeof(bf16_t);

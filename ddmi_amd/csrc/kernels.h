@@ -34,7 +34,8 @@ int launch_linear_small(const float* x, int x_stride, const float* W, const floa
                         int B, int K, int N, int silu_in, hipStream_t s);
 
 // ---- GroupNorm(32) ----------------------------------------------------------------------------------
-// stats: [B][32][2] doubles (sum, sum of squares), must be zero before launch_gn_stats
+// stats: scratch of GN_STATS_DOUBLES(B) doubles ([B][64 splits][32 groups][sum, sumsq]); no zero-fill needed
+#define GN_STATS_DOUBLES(B) ((size_t)(B) * 64 * 64)
 int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s);

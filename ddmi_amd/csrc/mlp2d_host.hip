@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include "models.h"
+#include "prof.h"
 
 Mlp2d::~Mlp2d() {
   for (void* p : dev_allocs)
@@ -207,6 +208,7 @@ int mlp2d_forward(Mlp2d& m, const void* const* planes, const int* plane_hw, int 
   } else {
     DDMI_REQUIRE(layout == DDMI_LAYOUT_NHWC_NATIVE, "mlp2d_forward: bad layout");
   }
+  prof_begin_forward();
   Mlp2dArgs a{};
   for (int i = 0; i < 3; ++i) {
     a.planes[i] = (const float*)pl[i];

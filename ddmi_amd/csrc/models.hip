@@ -3,6 +3,7 @@
 //   * D2C-VAE image decoder - models/d2c_vae/autoencoder_unet.py:702-829 (Decoder) + :855-858 (Autoencoder.decode)
 // Weight names are the reference's state-dict keys, so `ldm-last.pt` tensors can be handed over unchanged.
 #include "models.h"
+#include "prof.h"
 #include <cmath>
 
 // =====================================================================================================
@@ -188,6 +189,7 @@ int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int 
   if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "unet not finalized");
   DDMI_REQUIRE(x && t && eps_out, "unet_forward: null pointer");
   DDMI_REQUIRE(B >= 1 && B <= n.max_batch, "unet_forward: batch exceeds max_batch");
+  prof_begin_forward();
   const int mc = u.cfg.model_channels, E = u.emb_dim;
   float* temb = u.tbuf;                       // [B][mc]
   float* e1 = temb + (size_t)B * mc;          // [B][E]
@@ -325,6 +327,7 @@ int decoder2d_forward(Decoder2d& d, const float* z, void* const* planes, int lay
   if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "decoder not finalized");
   DDMI_REQUIRE(z && planes, "decoder2d_forward: null pointer");
   DDMI_REQUIRE(layout == 0 || layout == 1, "decoder2d_forward: layout must be 0 (NCHW fp32) or 1 (NHWC native)");
+  prof_begin_forward();
   void* ext[8] = {(void*)z};
   for (int i = 0; i < d.n_planes; ++i) {
     ext[1 + i] = planes[i];

@@ -70,7 +70,7 @@ struct Net {
   std::vector<void*> dev_allocs;            // everything hipMalloc'ed by this net
   unsigned char* arena = nullptr;
   size_t arena_bytes = 0;
-  double* gn_stats = nullptr;               // [n_gn_slots][max_batch][32][2]
+  double* gn_stats = nullptr;               // GN_STATS_DOUBLES(max_batch) scratch shared by all GN ops
   int n_gn_slots = 0;
   float* splitk_ws = nullptr;
   size_t splitk_bytes = 0;

@@ -231,7 +231,7 @@ int Net::plan() {
   dev_allocs.push_back(arena);
 
   if (n_gn_slots > 0) {
-    size_t bytes = (size_t)n_gn_slots * max_batch * 64 * sizeof(double);
+    size_t bytes = GN_STATS_DOUBLES(max_batch) * sizeof(double);  // one scratch shared by every GN op (stream order)
     HIP_TRY(hipMalloc((void**)&gn_stats, bytes));
     dev_allocs.push_back(gn_stats);
   }
@@ -258,7 +258,6 @@ int Net::plan() {
 int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStream_t s) {
   if (!finalized) return ddmi_fail(DDMI_ERR_STATE, "network not finalized");
   DDMI_REQUIRE(B >= 1 && B <= max_batch, "batch exceeds max_batch given at create time");
-  if (n_gn_slots > 0) HIP_TRY(hipMemsetAsync(gn_stats, 0, (size_t)n_gn_slots * max_batch * 64 * sizeof(double), s));
   for (const Op& o : ops) {
     switch (o.kind) {
       case OP_NCHW_IN: {
@@ -270,7 +269,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         const TensorDesc& t = tensors[o.in];
         const GNW& g = gns[o.gn];
         DDMI_REQUIRE(g.C == t.C, "groupnorm channel mismatch");
-        double* st = gn_stats + (size_t)o.gn_slot * max_batch * 64;
+        double* st = gn_stats;
         DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, t.C, s));
         DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, t.C, s));
         break;

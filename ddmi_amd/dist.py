@@ -1,0 +1,90 @@
+"""Sample-parallel generation over the GPUs of one node.
+
+Generation is embarrassingly parallel per sample (independent Markov chains; GroupNorm and attention are per-sample),
+so there is NO collective on the data path: every rank holds a full weight replica, owns the global sample indices
+`i = rank, rank + world, ...`, seeds each chain from (base_seed, i) - so the set of samples does not depend on the
+number of GPUs - and finished images are all-gathered once per batch (RCCL over xGMI with the `nccl` backend; `gloo`
+in the CPU tests).  The reference never shards sampling: it builds the EMA model on the main process only
+(tools/ldm/image.py:63-65), which is exactly what is NOT reproduced here.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialises torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_indices(total: int, rank: int, world: int) -> List[int]:
+    """Global sample indices owned by `rank` (round-robin, so any prefix of the index space is balanced)."""
+    return list(range(rank, total, world))
+
+
+def sample_seed(base_seed: int, index: int) -> int:
+    """Per-chain seed: base_seed * 2^32 + global sample index."""
+    return (int(base_seed) << 32) + int(index)
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def all_gather_samples(local: torch.Tensor, world: int) -> torch.Tensor:
+    """[B_local, ...] on every rank -> [world * B_local, ...] in rank-major order (one all-gather per batch)."""
+    if world == 1 or not dist.is_initialized():
+        return local
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def reorder_rank_major(gathered: torch.Tensor, world: int, b_local: int) -> torch.Tensor:
+    """Undo the round-robin sharding: row r*b_local + j of the gather is global index j*world + r."""
+    if world == 1:
+        return gathered
+    g = gathered.reshape(world, b_local, *gathered.shape[1:])
+    return g.transpose(0, 1).reshape(world * b_local, *gathered.shape[1:])
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def generate_sharded(generate_fn: Callable[[Sequence[int]], torch.Tensor], total: int, b_local: int, rank: int,
+                     world: int) -> torch.Tensor:
+    """Runs `generate_fn(indices) -> [len(indices), ...]` over this rank's shard in batches of b_local and returns the
+    full, index-ordered sample set on every rank.  `total` must be a multiple of world * b_local."""
+    assert total % (world * b_local) == 0, "total must be a multiple of world_size * per-GPU batch"
+    mine = shard_indices(total, rank, world)
+    chunks = []
+    for k in range(0, len(mine), b_local):
+        local = generate_fn(mine[k:k + b_local])
+        chunks.append(reorder_rank_major(all_gather_samples(local, world), world, b_local))
+    return torch.cat(chunks, dim=0)

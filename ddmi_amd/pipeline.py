@@ -1,0 +1,100 @@
+"""Image generation pipeline - the shape of tools/ldm/image.py:225-249 (`LDMTrainer.generate`) and of the 10k-sample
+loop in evals/eval.py:215-226: sample(shape) -> decode -> mlp(coords, planes, si) -> clamp.
+
+Construction mirrors exp/stage.py:194-203: the YAML blocks are splatted into the model constructors.
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import initweights
+from .autoencoder import Autoencoder
+from .coords import generation_coords, get_scale_injection
+from .ddpm import DDPM
+from .dist import sample_seed
+from .mlp import MLP
+from .unet import UNetModel
+
+
+class ImagePipeline:
+    def __init__(self, unetconfig: Mapping, ddconfig: Mapping, mlpconfig: Mapping, ddpmconfig: Mapping, embed_dim: int,
+                 test_resolution: int = 256, numerics: str = "bf16", max_batch: int = 8, device: str = "cuda:0"):
+        self.device = device
+        self.numerics = numerics
+        self.max_batch = int(max_batch)
+        self.unet = UNetModel(**dict(unetconfig), numerics=numerics, max_batch=max_batch)
+        self.vae = Autoencoder(ddconfig, embed_dim, numerics=numerics, max_batch=max_batch)
+        self.mlp = MLP(**dict(mlpconfig), numerics=numerics)
+        self.ddpm = DDPM(model=self.unet, **dict(ddpmconfig))
+        self.embed_dim = int(embed_dim)
+        self.latent_size = int(ddpmconfig.get("image_size", unetconfig["image_size"]))
+        self.test_resolution = int(test_resolution)
+        self._coords = None
+
+    # ---- weights -------------------------------------------------------------------------------------------
+    def load_named_seed(self, tag: str = "afhq"):
+        """Deterministic synthetic weights (no network for checkpoints): ddmi_amd.initweights."""
+        self.unet.load_state_dict(initweights.fill_state(tag + ".unet", self.unet.manifest()))
+        self.vae.load_state_dict(initweights.fill_state(tag + ".vae", self.vae.manifest()))
+        self.mlp.load_state_dict(initweights.fill_state(tag + ".mlp", self.mlp.manifest()))
+        self.ddpm.load_state_dict({"mixing_logit": initweights.fill_state(tag + ".ddpm", [("mixing_logit", (1, self.ddpm.channels, 1, 1))])["mixing_logit"]},
+                                  strict=False)
+        return self
+
+    def load_checkpoint(self, path: str, use_ema: bool = True):
+        """`ldm-last.pt` as written by tools/ldm/image.py:104-119: keys 'vaemodel', 'mlp', 'diffusion', 'ema'
+        ('ema' = ema_pytorch state: the sampling weights live under the `ema_model.` prefix, tools/ldm/image.py:64,240)."""
+        import torch
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.vae.load_state_dict(ck["vaemodel"], strict=True)
+        self.mlp.load_state_dict(ck["mlp"], strict=True)
+        diff = ck["diffusion"]
+        if use_ema and "ema" in ck:
+            ema = {k[len("ema_model."):]: v for k, v in ck["ema"].items() if k.startswith("ema_model.")}
+            if ema:
+                diff = ema
+        diff = {k: v for k, v in diff.items() if k != "lvlb_weights" and k != "logvar"}
+        self.ddpm.load_state_dict(diff, strict=True)
+        return self
+
+    def finalize(self):
+        idx = int(str(self.device).split(":")[1]) if ":" in str(self.device) else 0
+        self.unet.finalize(idx)
+        self.vae.finalize(idx)
+        self.mlp.finalize(idx)
+        return self
+
+    # ---- generation ------------------------------------------------------------------------------------------
+    def coords(self):
+        if self._coords is None:
+            self._coords = generation_coords(self.test_resolution)
+        return self._coords
+
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False):
+        """One batch of finished samples for the given GLOBAL sample indices.  Every chain draws x_T and its per-step
+        noise from its own device generator seeded by (base_seed, index), so results do not depend on how indices are
+        sharded over GPUs or batched."""
+        import torch
+        B = len(indices)
+        dev = torch.device(self.device)
+        shape = (B, self.embed_dim, self.latent_size, self.latent_size)
+        gens = []
+        for i in indices:
+            g = torch.Generator(device=dev)
+            g.manual_seed(sample_seed(base_seed, i))
+            gens.append(g)
+        buf = torch.empty(shape, device=dev, dtype=torch.float32)
+
+        def draw(_step):
+            for j, g in enumerate(gens):
+                torch.randn(shape[1:], generator=g, out=buf[j])
+            return buf
+
+        x_T = draw(-1).clone()
+        z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
+        planes = self.vae.decode(z)
+        img = self.mlp(self.coords(), hdbf=planes, si=get_scale_injection(self.test_resolution))
+        img = img.clamp_(-1.0, 1.0)
+        return (img, z) if return_latent else img

@@ -40,6 +40,12 @@ int ddmi_init(int device);                 /* selects the device, checks it is g
 const char* ddmi_last_error(void);         /* thread-local message of the last failing call */
 const char* ddmi_version(void);
 
+/* Live per-kernel timing with HIP events recorded on the launch stream around each kernel (bench.py's roofline
+ * figure).  enable(n): time every kernel of every n-th network forward (0 = off, the default); collect():
+ * synchronises and writes a JSON object {kernel: {launches, total_ms, flops, bytes}} (algorithmic flops/bytes). */
+int ddmi_profile_enable(int every_n_forwards);
+int ddmi_profile_collect(char* json_out, uint64_t capacity);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Denoiser: replaces UNetModel.forward(x, timesteps)   models/ldm/modules/diffusionmodules/openaimodel.py:761-793
  * (constructor topology :493-743; the DDPM wrapper calls it as self.model(x, t, cond), diffusion/ddpm.py:258,305)

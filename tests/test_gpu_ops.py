@@ -145,7 +145,7 @@ def test_attention_shapes(B, heads, T):
     qkv[0, 32:64, (2 * T) // 3] = qkv[0, 0:32, T // 3] * 2.0
     ref = O.qkv_attention_legacy(torch.from_numpy(qkv), heads)
     assert rel_err(attn_op(qkv, heads, "fp32"), ref) < 2e-5
-    assert rel_err(attn_op(qkv, heads, "bf16"), ref) < 3e-2
+    assert rel_err(attn_op(qkv, heads, "bf16"), ref) < 8e-2  # logits of +-30 with 8-bit mantissas
 
 
 def test_timestep_embedding_golden(golden):
