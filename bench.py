@@ -63,9 +63,9 @@ def cpu_baseline(threads=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=4, help="samples per GPU per step")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=777)
@@ -97,10 +97,17 @@ def main():
     pipe.mlp(pipe.coords(), hdbf=pipe.vae.decode(z0), si=1.0)
     torch.cuda.synchronize()
 
+    phase = {"sample": 0.0, "decode_mlp": 0.0, "gather": 0.0}
+
     def one_step(step_idx):
         idx = [(step_idx * world + rank) * B + j for j in range(B)]  # disjoint global sample indices
-        img = pipe.generate(idx, base_seed=args.seed)
-        return D.all_gather_samples(img, world)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        img = pipe.generate(idx, base_seed=args.seed, events=ev[1:3])
+        out = D.all_gather_samples(img, world)
+        ev[3].record()
+        phase["_ev"] = ev
+        return out
 
     for w in range(args.warmup):
         one_step(w)
@@ -115,13 +122,16 @@ def main():
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
+    ev = phase.pop("_ev")
+    phase_ms = {"sampling_loop": ev[0].elapsed_time(ev[1]), "decode": ev[1].elapsed_time(ev[2]),
+                "mlp_clamp_gather": ev[2].elapsed_time(ev[3])}
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
     assert out is not None and out.shape == (world * B, 3, 256, 256) and bool(torch.isfinite(out).all())
 
     if rank == 0:
         total_samples = args.steps * world * B
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_igemm")}
+        conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
         dom = max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None
         roof = None
         if dom:
@@ -143,6 +153,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "latent": [64, 64, 64],
                        "parallelism": f"sample-parallel x{world} (independent chains, all-gather of finished images)"},
             "roofline": roof, "kernel_time_share": breakdown,
+            "last_step_phase_ms": {k: round(v, 2) for k, v in phase_ms.items()},
+            "unet_memory_bytes": pipe.unet.memory(),
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

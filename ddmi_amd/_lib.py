@@ -75,6 +75,7 @@ SYMBOLS = {
     "ddmi_hdpe_mlp2d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _F, _VP, _VP, _I, _I, _VP]),
     "ddmi_mlp2d_destroy": (_I, [_VP]),
     "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),
     "ddmi_op_attention_legacy": (_I, [_VP, _VP, _I, _I, _I, _I]),
     "ddmi_op_timestep_embedding": (_I, [_VP, _VP, _I, _I]),

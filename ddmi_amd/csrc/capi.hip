@@ -222,6 +222,67 @@ int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, 
   return DDMI_OK;
 }
 
+__global__ void fill_hash_kernel(unsigned* p, int64_t n_words, unsigned seed, int bf16) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    if (bf16) {  // two bf16 in [-1, 1): sign + exponent 126/125.. keep it simple: map to +-(1.0 .. 2.0) - 1.5
+      unsigned lo = 0x3F00u | (h & 0x807Fu), hi = 0x3F00u | ((h >> 16) & 0x807Fu);
+      p[i] = lo | (hi << 16);
+    } else {
+      p[i] = 0x3F000000u | (h & 0x807FFFFFu);  // +-[0.5, 1)
+    }
+  }
+}
+
+/* Micro-benchmark of one convolution shape on device-resident random data: average ms over `iters` launches. */
+int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, int upsample, int numerics, int splitk,
+                    int force_bm, int force_bn, int iters, double* ms_out, int* splitk_used) {
+  int dt;
+  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  DDMI_REQUIRE(ms_out && iters > 0, "bench_conv: bad arguments");
+  Scratch sc;
+  void *xn, *wp, *yn, *ws = nullptr;
+  int hin = upsample ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
+  int Ho = (hin + 2 * pad - k) / stride + 1, Wo = (win + 2 * pad - k) / stride + 1;
+  size_t xb = (size_t)B * Cin * H * W * dt_size(dt), wb = (size_t)Cout * Cin * k * k * dt_size(dt);
+  DDMI_TRY(sc.get(xb, &xn));
+  DDMI_TRY(sc.get(wb, &wp));
+  DDMI_TRY(sc.get((size_t)B * Cout * Ho * Wo * dt_size(dt), &yn));
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(1024), dim3(256), 0, 0, (unsigned*)xn, (int64_t)(xb / 4), 1u, dt == DT_BF16);
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(1024), dim3(256), 0, 0, (unsigned*)wp, (int64_t)(wb / 4), 2u, dt == DT_BF16);
+  conv_force_tile(force_bm, force_bn);
+  ConvArgs a{};
+  a.x = xn; a.w = wp; a.y = yn;
+  a.B = B; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout;
+  a.KH = a.KW = k; a.stride = stride; a.pad = pad; a.ups = upsample; a.out_scale = 1.f;
+  a.splitk = splitk > 0 ? splitk : conv_pick_splitk(a, dt);
+  if (splitk_used) *splitk_used = a.splitk;
+  int rc = DDMI_OK;
+  if (a.splitk > 1) {
+    rc = sc.get((size_t)a.splitk * B * Ho * Wo * Cout * sizeof(float), &ws);
+    a.splitk_ws = (float*)ws;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3 && rc == DDMI_OK; ++i) rc = launch_conv(a, dt, 0);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < iters && rc == DDMI_OK; ++i) rc = launch_conv(a, dt, 0);
+  (void)hipEventRecord(e1, 0);
+  hipError_t e = hipDeviceSynchronize();
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  conv_force_tile(0, 0);
+  if (rc != DDMI_OK) return rc;
+  if (e != hipSuccess) return ddmi_fail(DDMI_ERR_HIP, std::string("bench_conv: ") + hipGetErrorString(e));
+  *ms_out = (double)ms / iters;
+  return DDMI_OK;
+}
+
 int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
                       int silu, int numerics) {
   int dt;

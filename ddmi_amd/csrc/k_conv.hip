@@ -4,19 +4,25 @@
 //
 // * activations NHWC, weights packed [Cout][tap][Cin]: both GEMM operands are K-contiguous, so one 16-byte load
 //   per lane feeds an MFMA fragment directly (no transposes anywhere).
-// * K is walked in chunks of 32 channels of one tap; KPS chunks per pipeline stage; the im2col gather (padding,
-//   stride 2, fused nearest x2 upsample) happens in the global->register load, never materialised.
-// * register-staged double buffering: loads of stage s+1 are issued before the MFMAs of stage s and written to the
-//   other LDS buffer afterwards -> one barrier per stage.
-// * bf16 path: v_mfma_f32_16x16x32_bf16; LDS rows are 64 B with a 16-byte-slot XOR swizzle that makes every
-//   ds_read_b128 lane group hit 16 distinct slots (see swz()).
-//   fp32 (parity) path: v_mfma_f32_16x16x4_f32 - exact fp32 FMA chains - with 144-byte padded rows.
+// * K is walked in chunks of 32 channels of one tap, KPS chunks per pipeline stage; the im2col gather (padding,
+//   stride 2, fused nearest x2 upsample) is folded into the per-lane SOURCE offset of the loads and never
+//   materialised.  Loads go through buffer descriptors: an out-of-image tap, a channel tail or a row past M is an
+//   out-of-range offset, which the hardware answers with zeros - no branches around loads, no select afterwards.
+// * bf16 path: `buffer_load_dwordx4 ... lds` (LDS-DMA): tiles land in LDS without touching VGPRs.  One DMA
+//   wave-instruction writes 1 KiB lane-linearly = 16 rows x 64 B; the 16-byte-slot XOR swizzle that makes the
+//   ds_read_b128 fragment reads conflict-free is applied to the per-lane source address instead (swz()).
+//   Two LDS stages: DMA of stage s+1 is in flight while the MFMAs of stage s run; one barrier per stage.
+//   fp32 (parity) path: register staging (buffer_load -> ds_write), v_mfma_f32_16x16x4_f32 = exact fp32 FMA chains.
+// * the (tap, channel) walk is kept in wave-uniform scalar state, so per load only one add + range compares remain.
 // * operands are swapped (A-operand = weights, B-operand = pixels) so each lane ends up with 4 consecutive output
 //   channels of one pixel: bias / time-embedding / residual / store are 8- or 16-byte vector accesses.
 // * epilogue fuses + bias[n] + emb[b][n] + residual, * out_scale, optional fp32-NCHW store, optional split-K
 //   (fp32 partial slabs [z][M][Cout] written with plain 16-byte stores, summed by splitk_finish_kernel).
 #include "kernels.h"
 #include "prof.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
 
 struct ConvK {
   const void* x;
@@ -36,7 +42,9 @@ struct ConvK {
   int NS;       // total stages
   int SPS;      // stages per split
   int tiles_n;
+  int chan_major;                           // K walk order (ring kernel): taps innermost when set
   float out_scale;
+  unsigned x_bytes, w_bytes;                // buffer extents (per batch entry) for the range check
   int64_t x_bstride, w_bstride, y_bstride;  // element strides for blockIdx.y (batched GEMM mode)
 };
 
@@ -44,121 +52,212 @@ template <typename T> struct Tile;
 template <> struct Tile<bf16_t> {
   static constexpr int EPS = 8;     // elements per 16-byte slot
   static constexpr int SLOTS = 4;   // slots per 32-element chunk row
-  static constexpr int ROWB = 64;   // LDS bytes per row
+  static constexpr int ROWB = 64;   // LDS bytes per row (DMA needs rows contiguous)
 };
 template <> struct Tile<float> {
   static constexpr int EPS = 4;
   static constexpr int SLOTS = 8;
-  static constexpr int ROWB = 144;  // 128 + 16 pad
+  static constexpr int ROWB = 144;  // 128 + 16 pad (register staging)
 };
 
-// 16-byte slot swizzle for 64-byte rows: f = {0,2,3,1}[(row>>2)&3]; with it the four ds_read_b128 lane groups
+// 16-byte slot swizzle for 64-byte rows: slot ^ {0,2,3,1}[(row>>2)&3]; with it the four ds_read_b128 lane groups
 // {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... each touch 16 distinct slots of the 256-byte bank row.
 __device__ __forceinline__ int swz(int row, int slot) {
   int r = (row >> 2) & 3;
-  int f = (0x78 >> (r * 2)) & 3;  // table {0,2,3,1} packed two bits per entry
-  return slot ^ f;
+  return slot ^ ((0x78 >> (r * 2)) & 3);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KPS>
-__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
-  using TL = Tile<T>;
-  constexpr int NT = WM * WN * 64;
-  constexpr int EPS = TL::EPS, SLOTS = TL::SLOTS, ROWB = TL::ROWB;
+#define OOB_OFFSET 0x80000000u
+
+// ---- epilogue shared by both kernels: lane holds channels n..n+3 of pixel m for every (i, j) fragment ----------
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
+                                              int lg, int hw) {
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  T* __restrict__ yg = a.y ? (T*)a.y + (int64_t)blockIdx.y * a.y_bstride : nullptr;
+  const T* __restrict__ rg = (const T*)a.res;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int m = m_base + i * 16 + lr;
+    if (m >= a.M) continue;
+    int b = m / hw;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      int n = n_base + j * 16 + lg * 4;
+      if (n >= a.Cout) continue;
+      f32x4 v = acc[i][j];
+      if (a.ws != nullptr) {  // split-K partial slab [z][M][Cout], summed by splitk_finish_kernel
+        *reinterpret_cast<f32x4*>(a.ws + ((int64_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
+        continue;
+      }
+      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)b * a.emb_stride + n);
+      if (rg) {
+        const T* p = rg + (int64_t)m * a.Cout + n;
+        if constexpr (IS_BF16) {
+          bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+        } else {
+          v += *reinterpret_cast<const f32x4*>(p);
+        }
+      }
+      v *= a.out_scale;
+      if (a.y_nchw) {
+        int r = m - b * hw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.y_nchw[((int64_t)b * a.Cout + n + e) * hw + r] = v[e];
+      } else {
+        T* p = yg + (int64_t)m * a.Cout + n;
+        if constexpr (IS_BF16) {
+          bf16x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x4*>(p) = t;
+        } else {
+          *reinterpret_cast<f32x4*>(p) = v;
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// bf16 production kernel: NST-deep LDS ring filled by LDS-DMA, counted vmcnt, one raw barrier per stage.
+//
+//   prologue : issue the DMA of stages 0 .. NST-2
+//   stage s  : s_waitcnt vmcnt(L * ahead)   - this wave's DMA of stage s has landed (later stages stay in flight)
+//              s_barrier                    - everybody's has, and everybody is done reading buffer (s-1) % NST
+//              issue the DMA of stage s+NST-1 into buffer (s-1) % NST
+//              ds_read fragments of buffer s % NST, MFMA
+//   Every wave issues exactly L = KPS * (ceil(BM/16/NW) + ceil(BN/16/NW)) DMA instructions per stage (row groups a
+//   wave does not own become out-of-range loads into a scratch KiB), so the vmcnt immediates are wave-independent.
+// =====================================================================================================
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int KPS, int NST>
+__global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
+  using T = bf16_t;
+  constexpr int NT = WM * WN * 64, NW = WM * WN;
+  constexpr int EPS = 8, SLOTS = 4, ROWB = 64, SZ = 2;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16");
-  constexpr int A_ITEMS = KPS * BM * SLOTS, B_ITEMS = KPS * BN * SLOTS;
-  constexpr int A_IT = (A_ITEMS + NT - 1) / NT, B_IT = (B_ITEMS + NT - 1) / NT;
+  static_assert(TM % 16 == 0 && TN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "tiles must be multiples of 16");
+  constexpr int GA = BM / 16, GB = BN / 16;                  // 16-row DMA groups per chunk
+  constexpr int A_PER = (GA + NW - 1) / NW, B_PER = (GB + NW - 1) / NW;
+  constexpr int L = KPS * (A_PER + B_PER);                   // DMA instructions per wave per stage
+  static_assert(L * (NST - 2) <= 63, "vmcnt immediate overflow");
   constexpr int A_BYTES = KPS * BM * ROWB, B_BYTES = KPS * BN * ROWB;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int SCRATCH = NST * STAGE_BYTES;                 // + wave * 1024: landing zone of dummy DMAs
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const T* __restrict__ xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
-  const T* __restrict__ wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
   const int Ktot = a.KH * a.KW * a.Cin;
   const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
+  const int hw = a.Hout * a.Wout;
 
-  // ---- per-thread gather descriptors (fixed over the K loop) ---------------------------------------
-  int a_ih0[A_IT], a_iw0[A_IT], a_lds[A_IT], a_chunk[A_IT], a_coff[A_IT];
-  int64_t a_base[A_IT];
-  bool a_ok[A_IT];
+  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
+  const T* wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes, 0x00020000);
+  auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  // ---- per-lane gather descriptors (fixed over the K loop); lane owns PHYSICAL slot lane&3 of row lane>>2 ----
+  int a_ih0[A_PER], a_iw0[A_PER], a_base[A_PER], a_coff[A_PER], a_pix[A_PER];
+  int a_ok[A_PER];
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    int idx = tid + i * NT;
-    int chunk = idx / (BM * SLOTS);
-    int rem = idx - chunk * (BM * SLOTS);
-    int row = rem / SLOTS, slot = rem - row * SLOTS;
+  for (int i = 0; i < A_PER; ++i) {
+    int row = (i * NW + wave) * 16 + (lane >> 2);
+    int slot = swz(row, lane & 3);
     int m = m0 + row;
-    bool ok = (idx < A_ITEMS) && (m < a.M);
-    int hw = a.Hout * a.Wout;
+    int ok = (row < BM) & (m < a.M);
     int b = ok ? m / hw : 0;
     int r = ok ? m - b * hw : 0;
     int oh = r / a.Wout, ow = r - oh * a.Wout;
     a_ok[i] = ok;
     a_ih0[i] = oh * a.stride - a.pad;
     a_iw0[i] = ow * a.stride - a.pad;
-    a_base[i] = (int64_t)b * a.Hin * a.Win * a.Cin;
-    a_chunk[i] = chunk;
     a_coff[i] = slot * EPS;
-    a_lds[i] = chunk * (BM * ROWB) + row * ROWB + (IS_BF16 ? swz(row, slot) : slot) * 16;
+    a_pix[i] = b * a.Hin * a.Win;
+    a_base[i] = ((a_pix[i] + a_ih0[i] * a.Win + a_iw0[i]) * a.Cin + a_coff[i]) * SZ;
   }
-  int b_lds[B_IT], b_chunk[B_IT], b_coff[B_IT];
-  int64_t b_base[B_IT];
-  bool b_ok[B_IT];
+  int b_base[B_PER], b_coff[B_PER], b_ok[B_PER];
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    int idx = tid + i * NT;
-    int chunk = idx / (BN * SLOTS);
-    int rem = idx - chunk * (BN * SLOTS);
-    int row = rem / SLOTS, slot = rem - row * SLOTS;
+  for (int i = 0; i < B_PER; ++i) {
+    int row = (i * NW + wave) * 16 + (lane >> 2);
+    int slot = swz(row, lane & 3);
     int n = n0 + row;
-    b_ok[i] = (idx < B_ITEMS) && (n < a.Cout);
-    b_base[i] = (int64_t)n * Ktot;
-    b_chunk[i] = chunk;
+    b_ok[i] = (row < BN) & (n < a.Cout);
     b_coff[i] = slot * EPS;
-    b_lds[i] = A_BYTES + chunk * (BN * ROWB) + row * ROWB + (IS_BF16 ? swz(row, slot) : slot) * 16;
+    b_base[i] = (n * Ktot + b_coff[i]) * SZ;
   }
 
-  uint4 ra[A_IT], rb[B_IT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  // ---- wave-uniform walk over (tap, channel-chunk) ------------------------------------------------------------
+  const int s_begin = blockIdx.z * a.SPS;
+  const int s_end = min(a.NS, s_begin + a.SPS);
+  int kc_next = s_begin * KPS;
+  const int taps = a.KH * a.KW;
+  // two walk orders over (tap, channel chunk): channel-major keeps the 9 shifted reads of one channel chunk adjacent
+  // in time (L1/L2 reuse of the activation rows); tap-major streams each tap's weights contiguously.
+  int q_ci, q_tap;
+  if (a.chan_major) {
+    q_ci = kc_next / taps;
+    q_tap = kc_next - q_ci * taps;
+  } else {
+    q_tap = kc_next / a.CPT;
+    q_ci = kc_next - q_tap * a.CPT;
+  }
+  int q_kh = q_tap / a.KW, q_kw = q_tap - q_kh * a.KW;
 
-  auto load_stage = [&](int s) {
+  auto load_stage = [&](int buf) {
+    unsigned char* sbase = smem + buf * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int kc = s * KPS + a_chunk[i];
-      int tap = kc / a.CPT;
-      int c = (kc - tap * a.CPT) * 32 + a_coff[i];
-      int kh = tap / a.KW, kw = tap - kh * a.KW;
-      int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-      bool ok = a_ok[i] && kc < a.NK && c < a.Cin && ih >= 0 && ih < Hlim && iw >= 0 && iw < Wlim;
-      if (a.ups) { ih >>= 1; iw >>= 1; }
-      const T* p = xg + a_base[i] + ((int64_t)ih * a.Win + iw) * a.Cin + c;
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(p) : zero4;
+    for (int c = 0; c < KPS; ++c) {
+      const int kvalid = kc_next < a.NK;
+      const int c0 = q_ci * 32;
+      const int a_delta = ((q_kh * a.Win + q_kw) * a.Cin + c0) * SZ;
+      const int b_delta = ((q_kh * a.KW + q_kw) * a.Cin + c0) * SZ;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        int ih = a_ih0[i] + q_kh, iw = a_iw0[i] + q_kw;
+        int ok = a_ok[i] & kvalid & (c0 + a_coff[i] < a.Cin) & ((unsigned)ih < (unsigned)Hlim) &
+                 ((unsigned)iw < (unsigned)Wlim);
+        int off = a_base[i] + a_delta;
+        if (a.ups) off = ((a_pix[i] + (ih >> 1) * a.Win + (iw >> 1)) * a.Cin + c0 + a_coff[i]) * SZ;
+        unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
+        const int g = i * NW + wave;  // wave-uniform
+        unsigned char* dst = g < GA ? sbase + c * (BM * ROWB) + g * 1024 : smem + SCRATCH + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        int ok = b_ok[i] & kvalid & (c0 + b_coff[i] < a.Cin);
+        unsigned voff = ok ? (unsigned)(b_base[i] + b_delta) : OOB_OFFSET;
+        const int g = i * NW + wave;
+        unsigned char* dst = g < GB ? sbase + A_BYTES + c * (BN * ROWB) + g * 1024 : smem + SCRATCH + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+      }
+      ++kc_next;
+      if (a.chan_major) {
+        if (++q_kw == a.KW) {
+          q_kw = 0;
+          if (++q_kh == a.KH) {
+            q_kh = 0;
+            ++q_ci;
+          }
+        }
+      } else if (++q_ci == a.CPT) {
+        q_ci = 0;
+        if (++q_kw == a.KW) {
+          q_kw = 0;
+          ++q_kh;
+        }
+      }
     }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int kc = s * KPS + b_chunk[i];
-      int tap = kc / a.CPT;
-      int c = (kc - tap * a.CPT) * 32 + b_coff[i];
-      bool ok = b_ok[i] && kc < a.NK && c < a.Cin;
-      const T* p = wg + b_base[i] + (int64_t)tap * a.Cin + c;
-      rb[i] = ok ? *reinterpret_cast<const uint4*>(p) : zero4;
-    }
-  };
-  auto store_stage = [&](int buf) {
-    unsigned char* base = smem + buf * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      if (tid + i * NT < A_ITEMS) *reinterpret_cast<uint4*>(base + a_lds[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      if (tid + i * NT < B_ITEMS) *reinterpret_cast<uint4*>(base + b_lds[i]) = rb[i];
   };
 
   f32x4 acc[FM][FN];
@@ -167,19 +266,213 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int lr = lane & 15, lg = lane >> 4;
+
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (s_begin + p < s_end) load_stage(p);
+
+  int buf = 0;  // buffer of stage s
+  for (int s = s_begin; s < s_end; ++s) {
+    // stages issued after s and still allowed in flight
+    const int ahead = min(NST - 2, s_end - 1 - s);
+    if (ahead >= NST - 2) wait_vmcnt<L*(NST - 2)>();
+    else if (NST > 3 && ahead == NST - 3) wait_vmcnt<(NST > 3 ? L * (NST - 3) : 0)>();
+    else if (NST > 4 && ahead == NST - 4) wait_vmcnt<(NST > 4 ? L * (NST - 4) : 0)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + NST - 1 < s_end) load_stage(buf == 0 ? NST - 1 : buf - 1);  // refill the buffer stage s-1 just released
+
+    const unsigned char* sa = smem + buf * STAGE_BYTES;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int c = 0; c < KPS; ++c) {
+      bf16x8 xf[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        int row = wm * TM + i * 16 + lr;
+        xf[i] = *reinterpret_cast<const bf16x8*>(sa + c * (BM * ROWB) + row * ROWB + swz(row, lg) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int row = wn * TN + j * 16 + lr;
+        wf[j] = *reinterpret_cast<const bf16x8*>(sb + c * (BN * ROWB) + row * ROWB + swz(row, lg) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    buf = buf + 1 == NST ? 0 : buf + 1;
+  }
+  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KPS>
+__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
+  using TL = Tile<T>;
+  constexpr int NT = WM * WN * 64, NW = WM * WN;
+  constexpr int EPS = TL::EPS, SLOTS = TL::SLOTS, ROWB = TL::ROWB;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16");
+  static_assert(BM % 16 == 0 && BN % 16 == 0, "block tile must be a multiple of 16");
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int SZ = (int)sizeof(T);
+  // per chunk: rows x SLOTS 16-byte items; item j of a chunk -> (row = j / SLOTS, slot = j % SLOTS).
+  // bf16: item j is written by DMA lane (j % 64) of row-group (j / 64); fp32: by thread (j % NT), iteration j / NT.
+  constexpr int A_CH_ITEMS = BM * SLOTS, B_CH_ITEMS = BN * SLOTS;
+  constexpr int A_PER = IS_BF16 ? (BM / 16 + NW - 1) / NW : (A_CH_ITEMS + NT - 1) / NT;  // loads per thread per chunk
+  constexpr int B_PER = IS_BF16 ? (BN / 16 + NW - 1) / NW : (B_CH_ITEMS + NT - 1) / NT;
+  constexpr int A_BYTES = KPS * BM * ROWB, B_BYTES = KPS * BN * ROWB;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int Ktot = a.KH * a.KW * a.Cin;
+  const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
+  const int hw = a.Hout * a.Wout;
+
+  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
+  const T* wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes, 0x00020000);
+  auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  // ---- per-thread gather descriptors (fixed over the K loop) ---------------------------------------
+  // A rows (pixels)
+  int a_ih0[A_PER], a_iw0[A_PER], a_base[A_PER], a_coff[A_PER], a_pix[A_PER];
+  bool a_ok[A_PER];
+  int a_lds[A_PER];  // fp32 path: LDS byte offset inside a chunk
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    int j = IS_BF16 ? (i * NW + wave) * 64 + lane : i * NT + tid;
+    int row = j / SLOTS, pslot = j % SLOTS;
+    int slot = IS_BF16 ? swz(row, pslot) : pslot;  // DMA: lane owns PHYSICAL slot pslot, fetch the logical one
+    int m = m0 + row;
+    bool ok = (j < A_CH_ITEMS) && (m < a.M);
+    int b = ok ? m / hw : 0;
+    int r = ok ? m - b * hw : 0;
+    int oh = r / a.Wout, ow = r - oh * a.Wout;
+    a_ok[i] = ok;
+    a_ih0[i] = oh * a.stride - a.pad;
+    a_iw0[i] = ow * a.stride - a.pad;
+    a_coff[i] = slot * EPS;
+    a_pix[i] = b * a.Hin * a.Win;  // pixel index of the sample's first pixel
+    a_base[i] = ((a_pix[i] + a_ih0[i] * a.Win + a_iw0[i]) * a.Cin + a_coff[i]) * SZ;
+    a_lds[i] = row * ROWB + pslot * 16;
+  }
+  // B rows (output channels)
+  int b_base[B_PER], b_coff[B_PER], b_lds[B_PER];
+  bool b_ok[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    int j = IS_BF16 ? (i * NW + wave) * 64 + lane : i * NT + tid;
+    int row = j / SLOTS, pslot = j % SLOTS;
+    int slot = IS_BF16 ? swz(row, pslot) : pslot;
+    int n = n0 + row;
+    b_ok[i] = (j < B_CH_ITEMS) && (n < a.Cout);
+    b_coff[i] = slot * EPS;
+    b_base[i] = (n * Ktot + b_coff[i]) * SZ;
+    b_lds[i] = row * ROWB + pslot * 16;
+  }
+
+  // ---- wave-uniform walk over (tap, channel-chunk) -------------------------------------------------------
   const int s_begin = blockIdx.z * a.SPS;
   const int s_end = min(a.NS, s_begin + a.SPS);
+  int kc_next = s_begin * KPS;  // first chunk of the next stage to load
+  int q_tap = kc_next / a.CPT;
+  int q_ci = kc_next - q_tap * a.CPT;
+  int q_kh = q_tap / a.KW, q_kw = q_tap - q_kh * a.KW;
+
+  u32x4 ra[KPS][A_PER], rb[KPS][B_PER];  // fp32 register staging only
+
+  // issue the loads of one stage into LDS buffer `buf` (bf16: DMA) or into registers (fp32)
+  auto load_stage = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < KPS; ++c) {
+      const bool kvalid = kc_next < a.NK;
+      const int c0 = q_ci * 32;
+      const int a_delta = ((q_kh * a.Win + q_kw) * a.Cin + c0) * SZ;
+      const int b_delta = ((q_kh * a.KW + q_kw) * a.Cin + c0) * SZ;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        int ih = a_ih0[i] + q_kh, iw = a_iw0[i] + q_kw;
+        bool ok = a_ok[i] && kvalid && (c0 + a_coff[i] < a.Cin) && (unsigned)ih < (unsigned)Hlim &&
+                  (unsigned)iw < (unsigned)Wlim;
+        int off = a_base[i] + a_delta;
+        if (a.ups) off = ((a_pix[i] + (ih >> 1) * a.Win + (iw >> 1)) * a.Cin + c0 + a_coff[i]) * SZ;
+        unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
+        if constexpr (IS_BF16) {
+          if ((i * NW + wave) * 16 < BM) {  // wave-uniform: this row group exists
+            unsigned char* dst = smem + buf * STAGE_BYTES + c * (BM * ROWB) + (i * NW + wave) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+          }
+        } else {
+          ra[c][i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, voff, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        bool ok = b_ok[i] && kvalid && (c0 + b_coff[i] < a.Cin);
+        unsigned voff = ok ? (unsigned)(b_base[i] + b_delta) : OOB_OFFSET;
+        if constexpr (IS_BF16) {
+          if ((i * NW + wave) * 16 < BN) {
+            unsigned char* dst = smem + buf * STAGE_BYTES + A_BYTES + c * (BN * ROWB) + (i * NW + wave) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+          }
+        } else {
+          rb[c][i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff, 0, 0);
+        }
+      }
+      // advance the uniform walk by one chunk
+      ++kc_next;
+      if (++q_ci == a.CPT) {
+        q_ci = 0;
+        if (++q_kw == a.KW) {
+          q_kw = 0;
+          ++q_kh;
+        }
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {  // fp32 path: registers -> LDS
+    if constexpr (!IS_BF16) {
+      unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+      for (int c = 0; c < KPS; ++c) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+          if (i * NT + tid < A_CH_ITEMS) *reinterpret_cast<u32x4*>(base + c * (BM * ROWB) + a_lds[i]) = ra[c][i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+          if (i * NT + tid < B_CH_ITEMS)
+            *reinterpret_cast<u32x4*>(base + A_BYTES + c * (BN * ROWB) + b_lds[i]) = rb[c][i];
+      }
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   const int lr = lane & 15, lg = lane >> 4;
 
   if (s_begin < s_end) {
-    load_stage(s_begin);
+    load_stage(0);
     store_stage(0);
   }
-  __syncthreads();
+  __syncthreads();  // (waits for the DMA: an LDS-DMA in flight makes the barrier's fence a vmcnt(0))
 
   for (int s = s_begin; s < s_end; ++s) {
     const int buf = (s - s_begin) & 1;
-    if (s + 1 < s_end) load_stage(s + 1);
+    if (s + 1 < s_end) load_stage(buf ^ 1);  // bf16: DMA straight into the other buffer, overlapping the MFMAs below
     const unsigned char* sa = smem + buf * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
@@ -229,63 +522,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds channels n..n+3 of pixel m for every (i, j) fragment --------------------
-  const int hw = a.Hout * a.Wout;
-  T* __restrict__ yg = a.y ? (T*)a.y + (int64_t)blockIdx.y * a.y_bstride : nullptr;
-  const T* __restrict__ rg = (const T*)a.res;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    int m = m0 + wm * TM + i * 16 + lr;
-    if (m >= a.M) continue;
-    int b = m / hw;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      int n = n0 + wn * TN + j * 16 + lg * 4;
-      if (n >= a.Cout) continue;
-      f32x4 v = acc[i][j];
-      if (a.ws != nullptr) {  // split-K partial slab [z][M][Cout], summed by splitk_finish_kernel
-        *reinterpret_cast<f32x4*>(a.ws + ((int64_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
-        continue;
-      }
-      if (a.bias) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n);
-        v += t;
-      }
-      if (a.emb) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(a.emb + (int64_t)b * a.emb_stride + n);
-        v += t;
-      }
-      if (rg) {
-        const T* p = rg + (int64_t)m * a.Cout + n;
-        if constexpr (IS_BF16) {
-          bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
-        } else {
-          v += *reinterpret_cast<const f32x4*>(p);
-        }
-      }
-      v *= a.out_scale;
-      if (a.y_nchw) {
-        int r = m - b * hw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a.y_nchw[((int64_t)b * a.Cout + n + e) * hw + r] = v[e];
-      } else {
-        T* p = yg + (int64_t)m * a.Cout + n;
-        if constexpr (IS_BF16) {
-          bf16x4 t;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(p) = t;
-        } else {
-          *reinterpret_cast<f32x4*>(p) = v;
-        }
-      }
-    }
-  }
+  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
 }
 
-// y = (ws + bias + emb + res) * scale, one thread per 4 channels
+// y = (sum_z ws[z] + bias + emb + res) * scale, one thread per 4 channels
 template <typename T>
 __global__ void __launch_bounds__(256) splitk_finish_kernel(ConvK a) {
   int64_t nvec = (int64_t)a.M * a.Cout / 4;
@@ -321,27 +561,56 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(ConvK a) {
 // ------------------------------------------------------------------------------------------------------
 // host side: tile selection and launch
 // ------------------------------------------------------------------------------------------------------
-struct TileCfg { int bm, bn; };
+// ---- configurations ------------------------------------------------------------------------------------
+// bf16 ring kernel: id -> <BM, BN, WM, WN, KPS, NST>
+struct RingCfg { int bm, bn, kps; };
+static const RingCfg kRing[] = {
+    {128, 112, 1},  // 0: <128,112,4,1,1,5>  77 KB LDS -> 2 workgroups / CU
+    {128, 112, 2},  // 1: <128,112,4,1,2,4> 123 KB
+    {256, 112, 2},  // 2: <256,112,8,1,2,3> 146 KB, 8 waves
+    {128, 224, 2},  // 3: <128,224,4,2,2,3> 140 KB, 8 waves
+    {128, 128, 2},  // 4: <128,128,2,2,2,4> 132 KB
+    {128, 64, 2},   // 5: <128, 64,4,1,2,4>  100 KB
+    {64, 128, 2},   // 6: < 64,128,2,2,2,4>  100 KB
+    {64, 64, 2},    // 7: < 64, 64,2,2,2,4>   68 KB
+    {256, 128, 2},  // 8: <256,128,4,2,2,3> 152 KB, 8 waves
+    {128, 224, 1},  // 9: <128,224,2,2,1,3>  72 KB, per-wave 64x112
+    {256, 112, 1},  // 10: <256,112,4,1,1,3> 75 KB, per-wave 64x112
+    {256, 224, 1},  // 11: <256,224,4,2,1,4> 131 KB, 8 waves, per-wave 64x112
+    {128, 224, 1},  // 12: <128,224,2,2,1,4>  94 KB
+};
+static const int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
+struct TileCfg { int bm, bn, kps, id; };  // id < 0: fp32 kernel tile
+static int g_force_bm = 0, g_force_bn = 0;  // diagnostics (ddmi_bench_conv): bn == -1 -> bm is a ring config id
+void conv_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
-static TileCfg pick_tile(int M, int Cout) {
+static TileCfg pick_tile(int M, int Cout, int dt, int cfg = 0) {
+  if (dt == DT_BF16) {
+    int id;
+    if (cfg > 0 && cfg <= kNumRing) id = cfg - 1;
+    else if (g_force_bn == -1 && g_force_bm >= 0 && g_force_bm < kNumRing) id = g_force_bm;
+    else if (Cout % 112 == 0) id = cdiv(M, 128) * cdiv(Cout, 224) >= 384 ? 11 : 3;
+    else if (Cout <= 64) id = cdiv(M, 128) >= 64 ? 5 : 7;
+    else id = cdiv(M, 128) * cdiv(Cout, 128) >= 128 ? 4 : 6;
+    return {kRing[id].bm, kRing[id].bn, kRing[id].kps, id};
+  }
   int bn;
   if (Cout % 112 == 0) bn = 112;
   else if (Cout % 128 == 0) bn = 128;
   else if (Cout <= 64) bn = 64;
   else {
-    // least padding among the compiled widths
-    int best = 128, waste = cdiv(Cout, 128) * 128 - Cout;
+    int best = 128, waste = cdiv(Cout, 128) * 128 - Cout;  // least padding among the compiled widths
     int w112 = cdiv(Cout, 112) * 112 - Cout, w64 = cdiv(Cout, 64) * 64 - Cout;
     if (w112 < waste) { best = 112; waste = w112; }
     if (w64 < waste) { best = 64; waste = w64; }
     bn = best;
   }
   int tiles128 = cdiv(M, 128) * cdiv(Cout, bn);
-  int bm = tiles128 >= 256 ? 128 : 64;
-  return {bm, bn};
+  int bm = (tiles128 >= 128 || bn == 112) ? 128 : 64;
+  return {bm, bn, 1, -1};
 }
 
-static ConvK make_k(const ConvArgs& a, int kps, int splitk) {
+static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   ConvK k{};
   k.x = a.x; k.w = a.w; k.bias = a.bias; k.emb = a.emb; k.res = a.res; k.y = a.y; k.y_nchw = a.y_nchw;
   k.ws = splitk > 1 ? a.splitk_ws : nullptr;
@@ -354,19 +623,31 @@ static ConvK make_k(const ConvArgs& a, int kps, int splitk) {
   k.NS = cdiv(k.NK, kps);
   k.SPS = cdiv(k.NS, splitk);
   k.out_scale = a.out_scale;
-  return k;
+  uint64_t xb = (uint64_t)a.B * a.Hin * a.Win * a.Cin * dt_size(dt);
+  uint64_t wb = (uint64_t)a.Cout * a.KH * a.KW * a.Cin * dt_size(dt);
+  DDMI_REQUIRE(xb < 0x80000000ull && wb < 0x80000000ull, "conv: tensor exceeds the 2 GiB buffer-descriptor range");
+  k.x_bytes = (unsigned)xb;
+  k.w_bytes = (unsigned)wb;
+  *out = k;
+  return DDMI_OK;
 }
 
 int conv_pick_splitk(const ConvArgs& a, int dt) {
   int M = a.B * a.Hout * a.Wout;
-  TileCfg t = pick_tile(M, a.Cout);
+  TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   int tiles = cdiv(M, t.bm) * cdiv(a.Cout, t.bn);
-  int kps = dt == DT_BF16 ? 2 : 1;
-  int NS = cdiv(cdiv(a.Cin, 32) * a.KH * a.KW, kps);
+  int NS = cdiv(cdiv(a.Cin, 32) * a.KH * a.KW, t.kps);
   if (tiles >= 192 || NS < 16) return 1;
   int want = cdiv(384, tiles);
   int maxs = std::max(1, NS / 8);
   return std::max(1, std::min(std::min(want, maxs), 16));
+}
+
+static void conv_work(const ConvK& k, int batch, int esz, double* flops, double* bytes) {
+  // algorithmic work of one launch: 2*M*N*K flops; operands + output once
+  const double Kdim = (double)k.KH * k.KW * k.Cin, Mtot = (double)k.M * batch;
+  *flops = 2.0 * Mtot * k.Cout * Kdim;
+  *bytes = esz * ((double)batch * k.B * k.Hin * k.Win * k.Cin + (double)k.Cout * Kdim * (k.w_bstride ? batch : 1) + Mtot * k.Cout);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KPS>
@@ -382,11 +663,10 @@ static int launch_cfg(ConvK k, int splitk, int batch, hipStream_t s) {
     attr_set = true;
   }
   {
-    // algorithmic work of this launch: 2*M*N*K flops; operands + output once
-    const double Kdim = (double)k.KH * k.KW * k.Cin, Mtot = (double)k.M * batch;
-    const double flops = 2.0 * Mtot * k.Cout * Kdim;
-    const double bytes = sizeof(T) * ((double)batch * k.B * k.Hin * k.Win * k.Cin + (double)k.Cout * Kdim * (k.w_bstride ? batch : 1) + Mtot * k.Cout);
-    static const std::string name = std::string("conv_igemm<") + (sizeof(T) == 2 ? "bf16" : "f32") + "," + std::to_string(BM) + "x" + std::to_string(BN) + ">";
+    double flops, bytes;
+    conv_work(k, batch, sizeof(T), &flops, &bytes);
+    static const std::string name = std::string("conv_igemm<") + (sizeof(T) == 2 ? "bf16" : "f32") + "," +
+                                    std::to_string(BM) + "x" + std::to_string(BN) + ">";
     PROF_SCOPE(name.c_str(), flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), 2 * stage, s, k);
   }
@@ -394,14 +674,54 @@ static int launch_cfg(ConvK k, int splitk, int batch, hipStream_t s) {
   return DDMI_OK;
 }
 
-template <typename T, int KPS>
-static int dispatch_tile(const ConvK& k, TileCfg t, int splitk, int batch, hipStream_t s) {
-  if (t.bm == 128 && t.bn == 112) return launch_cfg<T, 128, 112, 4, 1, KPS>(k, splitk, batch, s);
-  if (t.bm == 64 && t.bn == 112) return launch_cfg<T, 64, 112, 4, 1, KPS>(k, splitk, batch, s);
-  if (t.bm == 128 && t.bn == 128) return launch_cfg<T, 128, 128, 2, 2, KPS>(k, splitk, batch, s);
-  if (t.bm == 64 && t.bn == 128) return launch_cfg<T, 64, 128, 2, 2, KPS>(k, splitk, batch, s);
-  if (t.bm == 128 && t.bn == 64) return launch_cfg<T, 128, 64, 4, 1, KPS>(k, splitk, batch, s);
-  if (t.bm == 64 && t.bn == 64) return launch_cfg<T, 64, 64, 2, 2, KPS>(k, splitk, batch, s);
+template <int BM, int BN, int WM, int WN, int KPS, int NST>
+static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
+  constexpr int lds = NST * KPS * (BM + BN) * 64 + WM * WN * 1024;
+  static_assert(lds <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  k.tiles_n = cdiv(k.Cout, BN);
+  dim3 grid(cdiv(k.M, BM) * k.tiles_n, batch, splitk);
+  auto kern = conv_ring_kernel<BM, BN, WM, WN, KPS, NST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  {
+    double flops, bytes;
+    conv_work(k, batch, 2, &flops, &bytes);
+    static const std::string name = "conv_ring<bf16," + std::to_string(BM) + "x" + std::to_string(BN) + ",k" +
+                                    std::to_string(KPS * 32) + "x" + std::to_string(NST) + ">";
+    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hipStream_t s) {
+  if (dt == DT_BF16) {
+    switch (t.id) {
+      case 0: return launch_ring<128, 112, 4, 1, 1, 5>(k, splitk, batch, s);
+      case 1: return launch_ring<128, 112, 4, 1, 2, 4>(k, splitk, batch, s);
+      case 2: return launch_ring<256, 112, 8, 1, 2, 3>(k, splitk, batch, s);
+      case 3: return launch_ring<128, 224, 4, 2, 2, 3>(k, splitk, batch, s);
+      case 4: return launch_ring<128, 128, 2, 2, 2, 4>(k, splitk, batch, s);
+      case 5: return launch_ring<128, 64, 4, 1, 2, 4>(k, splitk, batch, s);
+      case 6: return launch_ring<64, 128, 2, 2, 2, 4>(k, splitk, batch, s);
+      case 7: return launch_ring<64, 64, 2, 2, 2, 4>(k, splitk, batch, s);
+      case 8: return launch_ring<256, 128, 4, 2, 2, 3>(k, splitk, batch, s);
+      case 9: return launch_ring<128, 224, 2, 2, 1, 3>(k, splitk, batch, s);
+      case 10: return launch_ring<256, 112, 4, 1, 1, 3>(k, splitk, batch, s);
+      case 11: return launch_ring<256, 224, 4, 2, 1, 4>(k, splitk, batch, s);
+      case 12: return launch_ring<128, 224, 2, 2, 1, 4>(k, splitk, batch, s);
+    }
+    return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
+  }
+  if (t.bm == 128 && t.bn == 112) return launch_cfg<float, 128, 112, 4, 1, 1>(k, splitk, batch, s);
+  if (t.bm == 128 && t.bn == 128) return launch_cfg<float, 128, 128, 2, 2, 1>(k, splitk, batch, s);
+  if (t.bm == 64 && t.bn == 128) return launch_cfg<float, 64, 128, 2, 2, 1>(k, splitk, batch, s);
+  if (t.bm == 128 && t.bn == 64) return launch_cfg<float, 128, 64, 4, 1, 1>(k, splitk, batch, s);
+  if (t.bm == 64 && t.bn == 64) return launch_cfg<float, 64, 64, 2, 2, 1>(k, splitk, batch, s);
   return ddmi_fail(DDMI_ERR_INVALID, "conv: no tile configuration");
 }
 
@@ -425,23 +745,22 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   int splitk = std::max(1, a.splitk);
   DDMI_REQUIRE(splitk == 1 || a.splitk_ws, "conv: split-K needs a workspace");
   int M = a.B * a.Hout * a.Wout;
-  TileCfg t = pick_tile(M, a.Cout);
-  if (dt == DT_BF16) {
-    ConvK k = make_k(a, 2, splitk);
-    DDMI_TRY((dispatch_tile<bf16_t, 2>(k, t, splitk, 1, s)));
-  } else {
-    ConvK k = make_k(a, 1, splitk);
-    DDMI_TRY((dispatch_tile<float, 1>(k, t, splitk, 1, s)));
-  }
+  TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
+  ConvK k;
+  DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
+  k.chan_major = a.order == 2 || (a.order == 0 && a.KH * a.KW > 1 && splitk == 1);
+  DDMI_TRY(dispatch(k, t, dt, splitk, 1, s));
   if (splitk > 1) DDMI_TRY(launch_splitk_finish(a, dt, s));
   return DDMI_OK;
 }
 
 int launch_splitk_finish(const ConvArgs& a, int dt, hipStream_t s) {
-  ConvK k = make_k(a, 1, 2);
+  ConvK k;
+  DDMI_TRY(make_k(a, dt, 1, 2, &k));
   k.SPS = a.splitk;  // number of slabs to sum
   int64_t nvec = (int64_t)k.M * k.Cout / 4;
   int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 8);
+  PROF_SCOPE("splitk_finish", 0, (double)(a.splitk * 4 + dt_size(dt)) * k.M * k.Cout, s);
   if (dt == DT_BF16)
     hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, k);
   else
@@ -457,13 +776,61 @@ int launch_gemm_nt(const void* A, const void* Bm, void* C, int dt, int batch, in
   a.B = 1; a.Hin = 1; a.Win = M; a.Cin = K; a.Hout = 1; a.Wout = M; a.Cout = N;
   a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.out_scale = alpha; a.splitk = 1;
   DDMI_TRY(check_conv(a, dt));
-  TileCfg t = pick_tile(M * batch, N);
-  if (dt == DT_BF16) {
-    ConvK k = make_k(a, 2, 1);
-    k.x_bstride = strideA; k.w_bstride = strideB; k.y_bstride = strideC;
-    return dispatch_tile<bf16_t, 2>(k, t, 1, batch, s);
-  }
-  ConvK k = make_k(a, 1, 1);
+  TileCfg t = pick_tile(M * batch, N, dt);
+  ConvK k;
+  DDMI_TRY(make_k(a, dt, t.kps, 1, &k));
   k.x_bstride = strideA; k.w_bstride = strideB; k.y_bstride = strideC;
-  return dispatch_tile<float, 1>(k, t, 1, batch, s);
+  return dispatch(k, t, dt, 1, batch, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// autotune: the best (tile configuration, K order, split-K) differs per shape (SURVEY.md Appendix A has 46 distinct
+// conv shapes in the AFHQ UNet alone) - time the candidates once at finalize on the real buffers.
+// ------------------------------------------------------------------------------------------------------
+int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPlan* best) {
+  *best = ConvPlan{};
+  if (dt != DT_BF16) return DDMI_OK;
+  DDMI_TRY(check_conv(a0, dt));
+  const int M = a0.B * a0.Hout * a0.Wout;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best_us = 1e30f;
+  static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  for (int id = 0; id < kNumRing; ++id) {
+    const RingCfg& rc = kRing[id];
+    // prune: tile width must fit Cout without more than ~15 % padding; tile height not larger than 2x the problem
+    int padded = cdiv(a0.Cout, rc.bn) * rc.bn;
+    if (padded * 100 > a0.Cout * 115 && !(a0.Cout <= 64 && rc.bn == 64)) continue;
+    if (rc.bm > 2 * M && rc.bm > 64) continue;
+    int tiles = cdiv(M, rc.bm) * cdiv(a0.Cout, rc.bn);
+    int NS = cdiv(cdiv(a0.Cin, 32) * a0.KH * a0.KW, rc.kps);
+    for (int sk : kSplits) {
+      if (sk > 1 && (tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
+      if ((size_t)sk * M * a0.Cout * sizeof(float) > ws_bytes && sk > 1) continue;
+      for (int order = 1; order <= (a0.KH * a0.KW > 1 ? 2 : 1); ++order) {
+        ConvArgs a = a0;
+        a.cfg = id + 1; a.order = order; a.splitk = sk; a.splitk_ws = ws;
+        int rc2 = DDMI_OK;
+        for (int i = 0; i < 2 && rc2 == DDMI_OK; ++i) rc2 = launch_conv(a, dt, 0);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < 4 && rc2 == DDMI_OK; ++i) rc2 = launch_conv(a, dt, 0);
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess || rc2 != DDMI_OK) {
+          (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+          return rc2 != DDMI_OK ? rc2 : ddmi_fail(DDMI_ERR_HIP, "conv_autotune: launch failed");
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        float us = ms * 250.f;
+        if (us < best_us) {
+          best_us = us;
+          *best = ConvPlan{id + 1, order, sk, us};
+        }
+      }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return DDMI_OK;
 }

@@ -78,54 +78,57 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ pa
   }
 }
 
-// grid (nsplit, B); block 256.  dynamic LDS: 2*C floats (scale, shift); nsplit_stats = grid.x of the stats launch
+// grid (nsplit, B); block = NV * R threads like the stats kernel: every thread owns ONE 16-byte channel vector for all
+// its pixels, so its scale/shift live in registers (no per-element index math, no LDS in the streaming loop).
 template <typename T>
-__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                       const double* __restrict__ part, int nsplit_stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, int silu, int HW, int C) {
+__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ part,
+                                int nsplit_stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float eps, int silu, int HW, int C, int NV, int R) {
   constexpr int VN = Vec16<T>::N;
-  extern __shared__ float ss[];  // scale[C], shift[C]
-  __shared__ double tot[GN_GROUPS * 2];
-  float* scale = ss;
-  float* shift = ss + C;
+  __shared__ float mr[GN_GROUPS * 2];  // mean, rstd per group
   int b = blockIdx.y;
+  int tid = threadIdx.x;
   int cpg = C / GN_GROUPS;
-  double cnt = (double)HW * cpg;
-  if (threadIdx.x < GN_GROUPS * 2) {
-    double acc = 0.0;
-    for (int sidx = 0; sidx < nsplit_stats; ++sidx)
-      acc += part[((int64_t)b * GN_MAXSPLIT + sidx) * (GN_GROUPS * 2) + threadIdx.x];
-    tot[threadIdx.x] = acc;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    int g = c / cpg;
-    double m = tot[g * 2] / cnt;
-    double var = tot[g * 2 + 1] / cnt - m * m;
+  if (tid < GN_GROUPS) {
+    double s1 = 0.0, s2 = 0.0;
+    const double* p = part + (int64_t)b * GN_MAXSPLIT * (GN_GROUPS * 2) + tid * 2;
+    for (int sidx = 0; sidx < nsplit_stats; ++sidx) {
+      s1 += p[(int64_t)sidx * (GN_GROUPS * 2)];
+      s2 += p[(int64_t)sidx * (GN_GROUPS * 2) + 1];
+    }
+    double cnt = (double)HW * cpg;
+    double m = s1 / cnt;
+    double var = s2 / cnt - m * m;
     if (var < 0) var = 0;
-    float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float sc = rstd * gamma[c];
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)m * sc;
+    mr[tid * 2] = (float)m;
+    mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
-  int NV = C / VN;
+  int v = tid % NV, r = tid / NV;
+  if (r >= R) return;
+  float sc[VN], sh[VN];
+#pragma unroll
+  for (int i = 0; i < VN; ++i) {
+    int c = v * VN + i;
+    int g = c / cpg;
+    float s = mr[g * 2 + 1] * gamma[c];
+    sc[i] = s;
+    sh[i] = beta[c] - mr[g * 2] * s;
+  }
   int per = cdiv(HW, gridDim.x);
   int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
-  int64_t n = (int64_t)(p1 - p0) * NV;
-  const T* xb = x + ((int64_t)b * HW + p0) * C;
-  T* yb = y + ((int64_t)b * HW + p0) * C;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    int v = (int)(i % NV);
+  const T* xb = x + (int64_t)b * HW * C + (int64_t)v * VN;
+  T* yb = y + (int64_t)b * HW * C + (int64_t)v * VN;
+  for (int p = p0 + r; p < p1; p += R) {
     float t[VN];
-    Vec16<T>::load(xb + i * VN, t);
+    Vec16<T>::load(xb + (int64_t)p * C, t);
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
-      float r = t[j] * scale[v * VN + j] + shift[v * VN + j];
-      t[j] = silu ? silu_precise(r) : r;
+      float q = t[j] * sc[j] + sh[j];
+      if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
+      t[j] = q;
     }
-    Vec16<T>::store(yb + i * VN, t);
+    Vec16<T>::store(yb + (int64_t)p * C, t);
   }
 }
 
@@ -156,16 +159,19 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
 
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s) {
-  dim3 g(gn_splits(B, HW), B);
+  int vn = dt == DT_F32 ? 4 : 8;
+  int NV = C / vn;
+  int R = std::max(1, 256 / NV);
+  int threads = std::max(64, cdiv(NV * R, 64) * 64);
   int ns = gn_splits(B, HW);
-  size_t lds = (size_t)2 * C * sizeof(float);
+  dim3 g(ns, B);
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(256), lds, s, (const float*)x, (float*)y, stats, ns, gamma, beta,
-                       eps, silu, HW, C);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (float*)y, stats, ns, gamma,
+                       beta, eps, silu, HW, C, NV, R);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, stats, ns, gamma,
-                       beta, eps, silu, HW, C);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, stats, ns, gamma,
+                       beta, eps, silu, HW, C, NV, R);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

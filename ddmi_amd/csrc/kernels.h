@@ -55,11 +55,18 @@ struct ConvArgs {
   int emb_stride;
   int splitk;
   float out_scale;    // y = (acc + bias + emb + res) * out_scale
+  int cfg;            // bf16 ring-kernel configuration id + 1 (0 = heuristic), see k_conv.hip kRing
+  int order;          // K walk: 0 = heuristic, 1 = tap-major, 2 = channel-major (taps innermost)
 };
+struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // result of conv_autotune (0 = heuristic)
+// times the candidate (configuration, K order, split-K) triples on the real buffers and returns the fastest;
+// `ws`/`ws_bytes`: split-K slab scratch for the trials.  Synchronises; only called at finalize.
+int conv_autotune(const ConvArgs& a, int dt, float* ws, size_t ws_bytes, ConvPlan* best);
 int launch_conv(const ConvArgs& a, int dt, hipStream_t s);
 // split-K finish: y = (ws + bias + emb + res) * scale
 int launch_splitk_finish(const ConvArgs& a, int dt, hipStream_t s);
 int conv_pick_splitk(const ConvArgs& a, int dt);
+void conv_force_tile(int bm, int bn);  // diagnostics: 0,0 = automatic
 
 // batched plain GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * Bm[b][n][k]  (both K-contiguous), dtype dt in/out
 int launch_gemm_nt(const void* A, const void* Bm, void* C, int dt, int batch, int M, int N, int K, int64_t strideA,

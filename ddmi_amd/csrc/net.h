@@ -48,6 +48,7 @@ struct Op {
   int gn_slot = -1;   // index into the GN statistics arena
   int tmp0 = -1, tmp1 = -1, tmp2 = -1;  // scratch tensors (OP_ATTN_FULL)
   float scale = 1.f;
+  ConvPlan tuned;     // OP_CONV: autotuned launch plan for B == max_batch (cfg 0 = heuristic)
 };
 
 struct TensorDesc {
@@ -62,6 +63,8 @@ struct Net {
   int dt = DT_F32;
   int max_batch = 1;
   bool finalized = false;
+  bool autotune = true;                     // bf16 only; DDMI_AUTOTUNE=0 disables
+  double tune_seconds = 0;
   std::map<std::string, HostTensor> host;   // raw state-dict tensors (fp32) until finalize
   std::vector<ConvW> convs;
   std::vector<GNW> gns;

@@ -1,7 +1,9 @@
 // Network executor: weight packing, liveness-planned activation arena, op dispatch (see net.h).
 #include "net.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local std::string g_last_error;
@@ -250,6 +252,69 @@ int Net::plan() {
     HIP_TRY(hipMalloc((void**)&splitk_ws, splitk_bytes));
     dev_allocs.push_back(splitk_ws);
   }
+  // ---- autotune every distinct conv shape at max_batch (bf16 perf mode only) -----------------------------
+  const char* env = getenv("DDMI_AUTOTUNE");
+  if (env && env[0] == '0') autotune = false;
+  if (autotune && dt == DT_BF16) {
+    auto t0 = std::chrono::steady_clock::now();
+    size_t tws_bytes = std::max<size_t>(splitk_bytes, (size_t)256 << 20);
+    float* tws = nullptr;
+    HIP_TRY(hipMalloc((void**)&tws, tws_bytes));
+    std::map<std::vector<int>, ConvPlan> cache;
+    int rc = DDMI_OK;
+    for (Op& o : ops) {
+      if (o.kind != OP_CONV) continue;
+      ConvArgs a;
+      fill_conv_args(*this, o, max_batch, &a);
+      a.y = tptr(o.out);  // timing only: results are overwritten by the real run
+      std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups};
+      auto it = cache.find(key);
+      if (it == cache.end()) {
+        ConvPlan p;
+        rc = conv_autotune(a, dt, tws, tws_bytes, &p);
+        if (rc != DDMI_OK) break;
+        it = cache.emplace(key, p).first;
+      }
+      o.tuned = it->second;
+      if (o.tuned.splitk > 1)
+        splitk_bytes = std::max(splitk_bytes, (size_t)o.tuned.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipFree(tws);
+    if (rc != DDMI_OK) return rc;
+    if (splitk_bytes) {  // re-size the slabs for the tuned splits
+      if (splitk_ws) {
+        (void)hipFree(splitk_ws);
+        dev_allocs.erase(std::remove(dev_allocs.begin(), dev_allocs.end(), (void*)splitk_ws), dev_allocs.end());
+      }
+      HIP_TRY(hipMalloc((void**)&splitk_ws, splitk_bytes));
+      dev_allocs.push_back(splitk_ws);
+    }
+    tune_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (dt == DT_BF16 && autotune) {
+    // slabs must also cover smaller batches run with the tuned tile and a heuristic split
+    size_t need = splitk_bytes;
+    for (const Op& o : ops) {
+      if (o.kind != OP_CONV) continue;
+      for (int B = 1; B < max_batch; ++B) {
+        ConvArgs a;
+        fill_conv_args(*this, o, B, &a);
+        a.cfg = o.tuned.cfg;
+        int sk = conv_pick_splitk(a, dt);
+        if (sk > 1) need = std::max(need, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
+      }
+    }
+    if (need > splitk_bytes) {
+      if (splitk_ws) {
+        (void)hipFree(splitk_ws);
+        dev_allocs.erase(std::remove(dev_allocs.begin(), dev_allocs.end(), (void*)splitk_ws), dev_allocs.end());
+      }
+      splitk_bytes = need;
+      HIP_TRY(hipMalloc((void**)&splitk_ws, splitk_bytes));
+      dev_allocs.push_back(splitk_ws);
+    }
+  }
   host.clear();  // raw fp32 copies are no longer needed
   finalized = true;
   return DDMI_OK;
@@ -286,7 +351,12 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           a.emb = emb + o.emb_off;
           a.emb_stride = emb_stride;
         }
-        a.splitk = conv_pick_splitk(a, dt);
+        if (B == max_batch && o.tuned.cfg > 0) {
+          a.cfg = o.tuned.cfg; a.order = o.tuned.order; a.splitk = o.tuned.splitk;
+        } else {
+          a.cfg = o.tuned.cfg;  // keep the tuned tile, re-derive the split for this batch size
+          a.splitk = conv_pick_splitk(a, dt);
+        }
         a.splitk_ws = splitk_ws;
         if (a.splitk > 1)
           DDMI_REQUIRE((size_t)a.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");

@@ -72,7 +72,7 @@ class ImagePipeline:
             self._coords = generation_coords(self.test_resolution)
         return self._coords
 
-    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False):
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, events=None):
         """One batch of finished samples for the given GLOBAL sample indices.  Every chain draws x_T and its per-step
         noise from its own device generator seeded by (base_seed, index), so results do not depend on how indices are
         sharded over GPUs or batched."""
@@ -94,7 +94,11 @@ class ImagePipeline:
 
         x_T = draw(-1).clone()
         z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
+        if events:
+            events[0].record()
         planes = self.vae.decode(z)
+        if events:
+            events[1].record()
         img = self.mlp(self.coords(), hdbf=planes, si=get_scale_injection(self.test_resolution))
         img = img.clamp_(-1.0, 1.0)
         return (img, z) if return_latent else img

@@ -145,6 +145,10 @@ int ddmi_mlp2d_destroy(ddmi_mlp2d* h);
 /* F.conv2d(x, w, b, stride, padding=k/2) optionally preceded by nearest x2 upsampling; k in {1,3} */
 int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                    int Cout, int k, int stride, int upsample, int numerics, int splitk);
+/* micro-benchmark of one convolution shape on device-resident pseudo-random data (average ms per launch);
+ * force_bm/force_bn = 0 lets the library pick the tile; splitk = 0 lets it pick the split */
+int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, int upsample, int numerics, int splitk,
+                    int force_bm, int force_bn, int iters, double* ms_out, int* splitk_used);
 /* GroupNorm(32 groups, eps) [+ SiLU] over [B,C,HW] */
 int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
                       int silu, int numerics);

@@ -51,7 +51,7 @@ def test_unet_golden(golden, name, cfgname, numerics, tol):
     assert rel_err(eps, u2[f"{name}.eps"]) < tol
     # batch-size independence + determinism: sample 1 alone gives the same row
     eps1 = unet(x[1:2].contiguous(), t[1:2].contiguous())
-    assert rel_err(eps1, eps[1:2]) < (1e-5 if numerics == "fp32" else 1e-2)  # other tiles / split-K at B=1
+    assert rel_err(eps1, eps[1:2]) < (1e-5 if numerics == "fp32" else tol)  # other tiles / split-K at B=1
     assert torch.equal(unet(x, t), eps)  # no atomics anywhere: bit-identical from run to run
 
 
