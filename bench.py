@@ -45,7 +45,9 @@ def cpu_baseline(threads=None):
     from ddmi_amd import initweights as iw
     from ddmi_amd.unet import unet_manifest
     from oracle import ddmi_oracle as O
-    cores = threads or os.cpu_count() or 1
+    # physical cores: SMT siblings only oversubscribe the fp32 GEMMs (measured: 256 threads are 3x slower than 128
+    # on the 2 x 64-core host of the GPU box)
+    cores = threads or max(1, (os.cpu_count() or 2) // 2)
     torch.set_num_threads(cores)
     cfg = AFHQ["unetconfig"]
     st = O.to_state(iw.fill_state("afhq.unet", unet_manifest(**cfg)))
@@ -58,6 +60,25 @@ def cpu_baseline(threads=None):
     return {"value": 1.0 / (NFE * dt), "unit": "samples/sec", "cores": cores, "kind": "port",
             "sample": f"1 of {NFE} UNet evaluations at B=1, 64x64x64 latent ({dt:.2f} s), x{NFE}; decode+MLP (1.2 % of the work) not included",
             "unet_eval_s": dt}
+
+
+def pmc_traffic(live_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied)."""
+    import glob
+    import re
+    m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)>", live_name or "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not m or not files:
+        return None
+    bm, bn, kk, nst = (int(v) for v in m.groups())
+    pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}>")
+    with open(files[-1]) as f:
+        table = json.load(f)["kernels"]
+    for name, v in table.items():
+        if pat.search(name):
+            return v["hbm_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -138,7 +159,8 @@ def main():
             d = conv[dom]
             ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_timed": d["launches"],
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_timed": d["launches"],
                     "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
                     "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
         tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0

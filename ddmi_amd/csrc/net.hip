@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -261,6 +262,22 @@ int Net::plan() {
     float* tws = nullptr;
     HIP_TRY(hipMalloc((void**)&tws, tws_bytes));
     std::map<std::vector<int>, ConvPlan> cache;
+    // optional persistent plan cache (DDMI_TUNE_FILE): one line per shape "B Hin Win Cin Cout K stride ups cfg order splitk us"
+    const char* tune_file = getenv("DDMI_TUNE_FILE");
+    if (tune_file) {
+      if (FILE* f = fopen(tune_file, "r")) {
+        int v[11];
+        float us;
+        while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7],
+                      &v[8], &v[9], &v[10], &us) == 12) {
+          ConvPlan p;
+          p.cfg = v[8]; p.order = v[9]; p.splitk = v[10]; p.us = us;
+          cache[std::vector<int>(v, v + 8)] = p;
+        }
+        fclose(f);
+      }
+    }
+    size_t cached_before = cache.size();
     int rc = DDMI_OK;
     for (Op& o : ops) {
       if (o.kind != OP_CONV) continue;
@@ -282,6 +299,15 @@ int Net::plan() {
     (void)hipDeviceSynchronize();
     (void)hipFree(tws);
     if (rc != DDMI_OK) return rc;
+    if (tune_file && cache.size() != cached_before) {
+      if (FILE* f = fopen(tune_file, "w")) {
+        for (auto& kv : cache) {
+          for (int x : kv.first) fprintf(f, "%d ", x);
+          fprintf(f, "%d %d %d %.2f\n", kv.second.cfg, kv.second.order, kv.second.splitk, kv.second.us);
+        }
+        fclose(f);
+      }
+    }
     if (splitk_bytes) {  // re-size the slabs for the tuned splits
       if (splitk_ws) {
         (void)hipFree(splitk_ws);

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's surface: `python main.py --exp ldm --configs configs/ldm/afhq.yaml [--seed 777]`
+(reference main.py:54-65), also under `accelerate launch` / `torch.distributed.run` (one process per GPU).
+
+Only the generation path is implemented (`data.mode: gen | eval` of the `ldm` experiment, image domain): gen writes a
+grid of `test_batch_size` samples like tools/ldm/image.py:225-249; eval runs the sample-parallel 10k-image loop of
+evals/eval.py:215-234 (images written as PNG shards; Inception scoring needs downloaded weights and is out of scope).
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(args):
+    if args.exp != "ldm":
+        raise SystemExit("only --exp ldm (generation) is implemented; stage-1 training is out of scope (SURVEY.md 8)")
+    import numpy as np
+    import torch
+    from ddmi_amd import dist as D
+    from ddmi_amd.config import load_ldm_args
+    from ddmi_amd.coords import random_seed
+    from ddmi_amd.pipeline import ImagePipeline
+
+    args = load_ldm_args(args.configs, args)
+    if args.domain != "image" or args.DiT:
+        raise SystemExit(f"domain '{args.domain}' / DiT are later rows of the scope table")
+    random_seed(args.seed)
+    rank, local_rank, world = D.init_process_group()
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    dc = args.data_config
+    B = int(dc.test_batch_size)
+    pipe = ImagePipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
+                         test_resolution=int(dc.test_resolution), numerics=args.numerics, max_batch=B, device=dev)
+    ckpt = os.path.join(dc.save_pth, "ldm-last.pt")
+    if os.path.exists(ckpt):
+        print("Loading Pretrained Models!")
+        pipe.load_checkpoint(ckpt)
+    else:
+        print(f"{ckpt} not found: using named-seed synthetic weights")
+        pipe.load_named_seed("afhq")
+    pipe.finalize()
+    out_dir = os.path.join(dc.save_pth, "results")
+    os.makedirs(out_dir, exist_ok=True)
+    if args.mode == "gen":
+        print("Random image generation!")
+        img = D.generate_sharded(lambda idx: pipe.generate(idx, base_seed=args.seed), world * B, B, rank, world)
+        if rank == 0:
+            u8 = ((img + 1) / 2 * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+            np.save(os.path.join(out_dir, "generation.npy"), u8)
+            try:
+                from PIL import Image
+                grid = np.concatenate(list(u8), axis=1)
+                Image.fromarray(grid).save(os.path.join(out_dir, "generation.jpg"))
+            except ImportError:
+                pass
+            print("Finished generating images!")
+    elif args.mode == "eval":
+        total = int(os.environ.get("DDMI_EVAL_SAMPLES", 10000)) // (world * B) * (world * B)
+        img = D.generate_sharded(lambda idx: pipe.generate(idx, base_seed=args.seed), total, B, rank, world)
+        if rank == 0:
+            u8 = ((img + 1) / 2 * 255).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+            np.save(os.path.join(out_dir, "fid_samples.npy"), u8)
+            print(f"wrote {total} samples")
+    else:
+        raise SystemExit("data.mode must be gen or eval (training is out of scope)")
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--exp", type=str, required=True, choices=["d2c-vae", "ldm"])
+    parser.add_argument("--configs", type=str)
+    parser.add_argument("--seed", type=int, default=777)
+    parser.add_argument("--numerics", type=str, default="bf16", choices=["bf16", "fp32"])
+    main(parser.parse_args())

@@ -1,0 +1,74 @@
+"""World-size-2 `gloo` test of the sample-parallel path (ddmi_amd/dist.py): sharding, per-sample seeds, all-gather and
+re-ordering give the same sample set as a single process."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fake_generate(indices, base_seed=777):
+    """Stands in for ImagePipeline.generate on CPU: each sample is a pure function of (base_seed, global index)."""
+    from ddmi_amd.dist import sample_seed
+    rows = []
+    for i in indices:
+        g = torch.Generator().manual_seed(sample_seed(base_seed, i))
+        rows.append(torch.randn((3, 4, 4), generator=g))
+    return torch.stack(rows)
+
+
+def _worker(rank, world, port, total, b_local, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ddmi_amd import dist as D
+    r, _, w = D.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    full = D.generate_sharded(fake_generate, total, b_local, r, w)
+    t = D.max_over_ranks(float(rank + 1), "cpu")
+    assert t == float(world)
+    D.barrier()
+    torch.save(full, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_generation_matches_single_process(tmp_path):
+    from ddmi_amd import dist as D
+    total, b_local, world = 12, 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), total, b_local, str(tmp_path)), nprocs=world, join=True)
+    ref = fake_generate(list(range(total)))
+    for rank in range(world):
+        got = torch.load(os.path.join(tmp_path, f"rank{rank}.pt"))
+        assert torch.equal(got, ref), rank  # every rank ends with the full, index-ordered set
+    # single-process path uses the same code
+    assert torch.equal(D.generate_sharded(fake_generate, total, b_local, 0, 1), ref)
+
+
+def test_shard_helpers():
+    from ddmi_amd import dist as D
+    assert D.shard_indices(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((D.shard_indices(16, r, 8) for r in range(8)), [])) == list(range(16))
+    assert D.sample_seed(777, 5) == 777 * 2 ** 32 + 5
+    g = torch.arange(12).reshape(12, 1)            # rank-major gather of world=3, b_local=4: row r*4+j = index j*3+r
+    idx = torch.tensor([[j * 3 + r] for r in range(3) for j in range(4)])
+    assert torch.equal(D.reorder_rank_major(idx, 3, 4), g)
+
+
+def test_config_loader_reads_reference_schema():
+    from ddmi_amd.config import load_ldm_args
+    a = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "afhq.yaml"))
+    assert a.unetconfig.model_channels == 224 and a.ddpmconfig.timesteps == a.ddpmconfig.sampling_timesteps == 250
+    assert a.data_config.test_resolution == 256 and a.mode == "gen" and a.domain == "image"
+    from ddmi_amd.ddpm import DDPM
+    assert not DDPM(model=None, **a.ddpmconfig).is_ddim_sampling          # -> p_sample_loop
+    b = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "afhq_ddim50.yaml"))
+    assert DDPM(model=None, **b.ddpmconfig).is_ddim_sampling
