@@ -18,6 +18,7 @@
 //   channels of one pixel: bias / time-embedding / residual / store are 8- or 16-byte vector accesses.
 // * epilogue fuses + bias[n] + emb[b][n] + residual, * out_scale, optional fp32-NCHW store, optional split-K
 //   (fp32 partial slabs [z][M][Cout] written with plain 16-byte stores, summed by splitk_finish_kernel).
+#include <cstdlib>
 #include "kernels.h"
 #include "prof.h"
 
@@ -43,6 +44,7 @@ struct ConvK {
   int SPS;      // stages per split
   int tiles_n;
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
+  int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier
   float out_scale;
   unsigned x_bytes, w_bytes;                // buffer extents (per batch entry) for the range check
   int64_t x_bstride, w_bstride, y_bstride;  // element strides for blockIdx.y (batched GEMM mode)
@@ -203,21 +205,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   const int taps = a.KH * a.KW;
   // two walk orders over (tap, channel chunk): channel-major keeps the 9 shifted reads of one channel chunk adjacent
   // in time (L1/L2 reuse of the activation rows); tap-major streams each tap's weights contiguously.
-  int q_ci, q_tap;
-  if (a.chan_major) {
-    q_ci = kc_next / taps;
-    q_tap = kc_next - q_ci * taps;
-  } else {
-    q_tap = kc_next / a.CPT;
-    q_ci = kc_next - q_tap * a.CPT;
-  }
-  int q_kh = q_tap / a.KW, q_kw = q_tap - q_kh * a.KW;
+  // mixed-radix counter: channel-major (kw, kh, ci) radices (KW, KH); tap-major (ci, kw, kh) radices (CPT, KW)
+  const int r0 = a.chan_major ? a.KW : a.CPT, r1 = a.chan_major ? a.KH : a.KW;
+  int d0 = kc_next % r0, d1 = (kc_next / r0) % r1, d2 = kc_next / (r0 * r1);
 
   auto load_stage = [&](int buf) {
     unsigned char* sbase = smem + buf * STAGE_BYTES;
 #pragma unroll
     for (int c = 0; c < KPS; ++c) {
       const int kvalid = kc_next < a.NK;
+      const int q_kw = a.chan_major ? d0 : d1, q_kh = a.chan_major ? d1 : d2, q_ci = a.chan_major ? d2 : d0;
       const int c0 = q_ci * 32;
       const int a_delta = ((q_kh * a.Win + q_kw) * a.Cin + c0) * SZ;
       const int b_delta = ((q_kh * a.KW + q_kw) * a.Cin + c0) * SZ;
@@ -242,19 +239,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
       }
       ++kc_next;
-      if (a.chan_major) {
-        if (++q_kw == a.KW) {
-          q_kw = 0;
-          if (++q_kh == a.KH) {
-            q_kh = 0;
-            ++q_ci;
-          }
-        }
-      } else if (++q_ci == a.CPT) {
-        q_ci = 0;
-        if (++q_kw == a.KW) {
-          q_kw = 0;
-          ++q_kh;
+      if (++d0 == r0) {
+        d0 = 0;
+        if (++d1 == r1) {
+          d1 = 0;
+          ++d2;
         }
       }
     }
@@ -270,7 +259,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
 
 #pragma unroll
   for (int p = 0; p < NST - 1; ++p)
-    if (s_begin + p < s_end) load_stage(p);
+    if (s_begin + p < s_end && !(a.dbg & 1)) load_stage(p);
 
   int buf = 0;  // buffer of stage s
   for (int s = s_begin; s < s_end; ++s) {
@@ -280,11 +269,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     else if (NST > 3 && ahead == NST - 3) wait_vmcnt<(NST > 3 ? L * (NST - 3) : 0)>();
     else if (NST > 4 && ahead == NST - 4) wait_vmcnt<(NST > 4 ? L * (NST - 4) : 0)>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (s + NST - 1 < s_end) load_stage(buf == 0 ? NST - 1 : buf - 1);  // refill the buffer stage s-1 just released
+    if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
+    if (s + NST - 1 < s_end && !(a.dbg & 1)) load_stage(buf == 0 ? NST - 1 : buf - 1);  // refill the released buffer
 
     const unsigned char* sa = smem + buf * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int c = 0; c < KPS; ++c) {
       bf16x8 xf[FM], wf[FN];
@@ -305,6 +295,186 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
+  }
+  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+}
+
+// =====================================================================================================
+// bf16 production kernel v2 ("pipe"): 64-channel stages with 128-byte LDS rows, software-pipelined fragments.
+//
+// What the ablation of the ring kernel showed (224->224 3x3 @64x64, B=32, 256x224 tile): DMA alone 122 us, LDS reads +
+// MFMA alone 101 us, both 159 us - (a) every DMA wave-instruction fetched 16 half cache lines (64-byte row pieces),
+// (b) all waves read their fragments and then all ran MFMAs, so the LDS read phase was never hidden.  Hence:
+//   * a stage = 64 channels of one tap; one DMA instruction moves 8 rows x 128 B = 8 whole cache lines;
+//     LDS rows are 128 B with the slot swizzle  pslot = slot ^ ((row >> 1) & 7)  (slot = 16-byte unit, 0..7 = two
+//     32-channel chunks x 4 k-groups), conflict-free for every ds_read_b128 lane group; applied on the DMA source side.
+//   * fragments of chunk q+1 are read into a second register set while the MFMAs of chunk q run; the single barrier
+//     of a stage sits between its two chunks:
+//         [A] read frags(2s+1) || MFMA(2s)        wait vmcnt(0); s_barrier   -> stage s+1 landed, buffer s%2 is free
+//             issue DMA(stage s+2 -> buffer s%2)
+//         [B] read frags(2s+2) || MFMA(2s+1)
+//     Two LDS buffers; the DMA of stage s+2 has one full stage of MFMA time to land.
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
+  using T = bf16_t;
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(TM % 16 == 0 && TN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "bad tile");
+  constexpr int GA = BM / 8, GB = BN / 8;  // 8-row DMA groups per stage
+  constexpr int A_PER = (GA + NW - 1) / NW, B_PER = (GB + NW - 1) / NW;
+  constexpr int ROWB = 128, SZ = 2;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int SCRATCH = 2 * STAGE_BYTES;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int Ktot = a.KH * a.KW * a.Cin;
+  const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
+  const int hw = a.Hout * a.Wout;
+  const int taps = a.KH * a.KW;
+  const int NCB = (a.Cin + 63) >> 6;  // 64-channel blocks per tap
+
+  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
+  const T* wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes, 0x00020000);
+  auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  // ---- per-lane gather descriptors: lane owns physical slot lane&7 of row (lane>>3) of its 8-row group --------
+  // (row >> 1) & 7 == (4*(group & 1) + (lane >> 4)) & 7 and group parity == wave parity (NW is even), so the logical
+  // slot - hence the channel offset - is ONE per-lane constant for every load of both operands.
+  static_assert(NW % 2 == 0, "slot constant needs an even wave count");
+  const int coff = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 8;
+  int a_ih0[A_PER], a_iw0[A_PER], a_pb[A_PER];  // invalid rows get ih0 = -2^20 so the bounds test rejects them
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    int row = (i * NW + wave) * 8 + (lane >> 3);
+    int m = m0 + row;
+    bool ok = (row < BM) && (m < a.M);
+    int b = ok ? m / hw : 0;
+    int r = ok ? m - b * hw : 0;
+    int oh = r / a.Wout, ow = r - oh * a.Wout;
+    a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
+    a_iw0[i] = ow * a.stride - a.pad;
+    a_pb[i] = (b * a.Hin * a.Win * a.Cin + coff) * SZ;
+  }
+  int b_base[B_PER];  // invalid rows: negative
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    int row = (i * NW + wave) * 8 + (lane >> 3);
+    int n = n0 + row;
+    b_base[i] = ((row < BN) && (n < a.Cout)) ? (n * Ktot + coff) * SZ : -1;
+  }
+
+  // ---- wave-uniform walk over stages: (tap, 64-channel block) in tap-major or channel-major order ----------------
+  const int s_begin = blockIdx.z * a.SPS;
+  const int s_end = min(a.NS, s_begin + a.SPS);
+  int st_next = s_begin;
+  // mixed-radix counter d0 (fastest) / d1 / d2 with radices r0, r1:
+  //   channel-major: (kw, kh, cb) radices (KW, KH);   tap-major: (cb, kw, kh) radices (NCB, KW)
+  const int r0 = a.chan_major ? a.KW : NCB, r1 = a.chan_major ? a.KH : a.KW;
+  int d0 = st_next % r0, d1 = (st_next / r0) % r1, d2 = st_next / (r0 * r1);
+
+  auto load_stage = [&](int buf) {
+    unsigned char* sbase = smem + buf * STAGE_BYTES;
+    const int kvalid = st_next < a.NS;
+    const int q_kw = a.chan_major ? d0 : d1, q_kh = a.chan_major ? d1 : d2, q_cb = a.chan_major ? d2 : d0;
+    const int c0 = q_cb * 64;
+    const int cvalid = kvalid & (c0 + coff < a.Cin);
+    const int b_delta = ((q_kh * a.KW + q_kw) * a.Cin + c0) * SZ;
+    const int rowb = a.Cin * SZ, c0b = c0 * SZ;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      int ih = a_ih0[i] + q_kh, iw = a_iw0[i] + q_kw;
+      int ok = cvalid & ((unsigned)ih < (unsigned)Hlim) & ((unsigned)iw < (unsigned)Wlim);
+      if (a.ups) { ih >>= 1; iw >>= 1; }
+      int off = a_pb[i] + (ih * a.Win + iw) * rowb + c0b;
+      unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
+      const int g = i * NW + wave;
+      unsigned char* dst = g < GA ? sbase + g * 1024 : smem + SCRATCH + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      int ok = cvalid & (b_base[i] >= 0);
+      unsigned voff = ok ? (unsigned)(b_base[i] + b_delta) : OOB_OFFSET;
+      const int g = i * NW + wave;
+      unsigned char* dst = g < GB ? sbase + A_BYTES + g * 1024 : smem + SCRATCH + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+    }
+    ++st_next;
+    if (++d0 == r0) {
+      d0 = 0;
+      if (++d1 == r1) {
+        d1 = 0;
+        ++d2;
+      }
+    }
+  };
+
+  const int lr = lane & 15, lg = lane >> 4;
+  // LDS byte offset of this lane's first fragment row per operand; further fragments are +16 rows = +2048 B (the
+  // swizzle term ((row >> 1) & 7) is the same for rows 16 apart, and TM/2, TN/2 are multiples of 8); the second
+  // 32-channel chunk is the same address with bit 6 flipped (logical slot + 4).
+  static_assert((TM / 2) % 8 == 0 && (TN / 2) % 8 == 0, "fragment offsets must be swizzle-periodic");
+  const int xoff0 = (wm * TM + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
+  const int woff0 = A_BYTES + (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
+  auto read_frags = [&](int buf, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+    const unsigned char* px = smem + buf * STAGE_BYTES + (xoff0 ^ (c << 6));
+    const unsigned char* pw = smem + buf * STAGE_BYTES + (woff0 ^ (c << 6));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(px + i * 2048);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+  };
+
+  bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];  // even / odd chunk register sets
+  constexpr int L = A_PER + B_PER;
+
+  if (s_begin < s_end) {
+    load_stage(0);
+    if (s_begin + 1 < s_end) {
+      load_stage(1);
+      wait_vmcnt<L>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, xa, wa);
+  }
+  int buf = 0;
+  for (int s = s_begin; s < s_end; ++s) {
+    // is the second 32-channel chunk of this stage inside Cin?  (Cin % 64 == 32 leaves a half stage per tap)
+    const int cb = a.chan_major ? s / taps : s % NCB;
+    const bool c1 = cb * 64 + 32 < a.Cin;
+    // [A] chunk 2s on set a, prefetch chunk 2s+1 into set b
+    read_frags(buf, 1, xb, wb);
+    mma(xa, wa);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // stage s+1 has landed everywhere; every wave has finished reading buffer `buf`
+    if (s + 2 < s_end) load_stage(buf);
+    // [B] chunk 2s+1 on set b, prefetch chunk 0 of stage s+1 into set a
+    if (s + 1 < s_end) read_frags(buf ^ 1, 0, xa, wa);
+    if (c1) mma(xb, wb);
+    buf ^= 1;
   }
   conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
 }
@@ -578,6 +748,12 @@ static const RingCfg kRing[] = {
     {256, 112, 1},  // 10: <256,112,4,1,1,3> 75 KB, per-wave 64x112
     {256, 224, 1},  // 11: <256,224,4,2,1,4> 131 KB, 8 waves, per-wave 64x112
     {128, 224, 1},  // 12: <128,224,2,2,1,4>  94 KB
+    {256, 224, -1},  // 13: pipe<256,224,4,2> 8 waves, per-wave 64x112, 124 KB   (kps -1: pipe kernel, 64-channel stages)
+    {128, 224, -1},  // 14: pipe<128,224,2,2> 4 waves, per-wave 64x112,  92 KB
+    {256, 112, -1},  // 15: pipe<256,112,4,1> 4 waves, per-wave 64x112,  96 KB
+    {256, 128, -1},  // 16: pipe<256,128,4,2> 8 waves, per-wave 64x64,  104 KB
+    {128, 128, -1},  // 17: pipe<128,128,2,2> 4 waves, per-wave 64x64,   68 KB
+    {128, 64, -1},   // 18: pipe<128, 64,2,1> 2 waves, per-wave 64x64,   50 KB
 };
 static const int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 struct TileCfg { int bm, bn, kps, id; };  // id < 0: fp32 kernel tile
@@ -587,7 +763,9 @@ void conv_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 static TileCfg pick_tile(int M, int Cout, int dt, int cfg = 0) {
   if (dt == DT_BF16) {
     int id;
+    static const int env_cfg = getenv("DDMI_CONV_CFG") ? atoi(getenv("DDMI_CONV_CFG")) : -1;  // diagnostics
     if (cfg > 0 && cfg <= kNumRing) id = cfg - 1;
+    else if (env_cfg >= 0 && env_cfg < kNumRing) id = env_cfg;
     else if (g_force_bn == -1 && g_force_bm >= 0 && g_force_bm < kNumRing) id = g_force_bm;
     else if (Cout % 112 == 0) id = cdiv(M, 128) * cdiv(Cout, 224) >= 384 ? 11 : 3;
     else if (Cout <= 64) id = cdiv(M, 128) >= 64 ? 5 : 7;
@@ -620,9 +798,11 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.M = a.B * a.Hout * a.Wout;
   k.CPT = cdiv(a.Cin, 32);
   k.NK = k.CPT * a.KH * a.KW;
-  k.NS = cdiv(k.NK, kps);
+  k.NS = kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(k.NK, kps);
   k.SPS = cdiv(k.NS, splitk);
   k.out_scale = a.out_scale;
+  static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
+  k.dbg = dbg;
   uint64_t xb = (uint64_t)a.B * a.Hin * a.Win * a.Cin * dt_size(dt);
   uint64_t wb = (uint64_t)a.Cout * a.KH * a.KW * a.Cin * dt_size(dt);
   DDMI_REQUIRE(xb < 0x80000000ull && wb < 0x80000000ull, "conv: tensor exceeds the 2 GiB buffer-descriptor range");
@@ -636,7 +816,7 @@ int conv_pick_splitk(const ConvArgs& a, int dt) {
   int M = a.B * a.Hout * a.Wout;
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   int tiles = cdiv(M, t.bm) * cdiv(a.Cout, t.bn);
-  int NS = cdiv(cdiv(a.Cin, 32) * a.KH * a.KW, t.kps);
+  int NS = t.kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(cdiv(a.Cin, 32) * a.KH * a.KW, t.kps);
   if (tiles >= 192 || NS < 16) return 1;
   int want = cdiv(384, tiles);
   int maxs = std::max(1, NS / 8);
@@ -698,6 +878,29 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
   return DDMI_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * 128 + WM * WN * 1024;
+  static_assert(lds <= 160 * 1024, "pipe tile does not fit the 160 KiB LDS");
+  k.tiles_n = cdiv(k.Cout, BN);
+  dim3 grid(cdiv(k.M, BM) * k.tiles_n, batch, splitk);
+  auto kern = conv_pipe_kernel<BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  {
+    double flops, bytes;
+    conv_work(k, batch, 2, &flops, &bytes);
+    static const std::string name = "conv_pipe<bf16," + std::to_string(BM) + "x" + std::to_string(BN) + ">";
+    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hipStream_t s) {
   if (dt == DT_BF16) {
     switch (t.id) {
@@ -714,6 +917,12 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 10: return launch_ring<256, 112, 4, 1, 1, 3>(k, splitk, batch, s);
       case 11: return launch_ring<256, 224, 4, 2, 1, 4>(k, splitk, batch, s);
       case 12: return launch_ring<128, 224, 2, 2, 1, 4>(k, splitk, batch, s);
+      case 13: return launch_pipe<256, 224, 4, 2>(k, splitk, batch, s);
+      case 14: return launch_pipe<128, 224, 2, 2>(k, splitk, batch, s);
+      case 15: return launch_pipe<256, 112, 4, 1>(k, splitk, batch, s);
+      case 16: return launch_pipe<256, 128, 4, 2>(k, splitk, batch, s);
+      case 17: return launch_pipe<128, 128, 2, 2>(k, splitk, batch, s);
+      case 18: return launch_pipe<128, 64, 2, 1>(k, splitk, batch, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -804,7 +1013,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     if (padded * 100 > a0.Cout * 115 && !(a0.Cout <= 64 && rc.bn == 64)) continue;
     if (rc.bm > 2 * M && rc.bm > 64) continue;
     int tiles = cdiv(M, rc.bm) * cdiv(a0.Cout, rc.bn);
-    int NS = cdiv(cdiv(a0.Cin, 32) * a0.KH * a0.KW, rc.kps);
+    int NS = rc.kps < 0 ? cdiv(a0.Cin, 64) * a0.KH * a0.KW : cdiv(cdiv(a0.Cin, 32) * a0.KH * a0.KW, rc.kps);
     for (int sk : kSplits) {
       if (sk > 1 && (tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
       if ((size_t)sk * M * a0.Cout * sizeof(float) > ws_bytes && sk > 1) continue;

@@ -39,6 +39,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, nargs="+", default=[4, 8])
     ap.add_argument("--numerics", default="bf16")
     ap.add_argument("--decoder", action="store_true")
+    ap.add_argument("--only", default="", help="substring filter on shape names")
     ap.add_argument("--tiles", default="", help="comma list of BMxBN to force, e.g. 128x112,128x128")
     ap.add_argument("--cfgs", default="", help="comma list of bf16 ring config ids to force (k_conv.hip kRing)")
     args = ap.parse_args()
@@ -47,6 +48,8 @@ if __name__ == "__main__":
     if args.cfgs:
         tiles = [(int(c), -1) for c in args.cfgs.split(",")]
     shapes = DEC_SHAPES if args.decoder else UNET_SHAPES
+    if args.only:
+        shapes = [s for s in shapes if args.only in s[0]]
     for B in args.batch:
         tot_ms = tot_fl = 0.0
         for sh in shapes:
