@@ -446,6 +446,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
   };
 
+  auto mma_rows_impl = [&](int i0, int i1, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      if (i >= i0 && i < i1) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+      }
+  };
+#define mma_rows_helper(I0, I1, X, W) mma_rows_impl((I0), (I1), (X), (W))
   bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];  // even / odd chunk register sets
   constexpr int L = A_PER + B_PER;
 
@@ -468,8 +478,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     // [A] chunk 2s on set a, prefetch chunk 2s+1 into set b
     read_frags(buf, 1, xb, wb);
     mma(xa, wa);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // stage s+1 has landed everywhere; every wave has finished reading buffer `buf`
+    // lgkmcnt(0): this wave's ds_reads of `buf` are retired before it arrives at the barrier, so the DMA that any wave
+    // issues into `buf` afterwards cannot overtake a read (WAR); vmcnt(0): this wave's share of stage s+1 has landed.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (s + 2 < s_end) load_stage(buf);
     // [B] chunk 2s+1 on set b, prefetch chunk 0 of stage s+1 into set a
     if (s + 1 < s_end) read_frags(buf ^ 1, 0, xa, wa);
