@@ -60,6 +60,7 @@ SYMBOLS = {
     "ddmi_unet_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
     "ddmi_unet_finalize": (_I, [_VP]),
     "ddmi_unet_forward": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    "ddmi_unet_set_uniform_t": (_I, [_VP, _I]),
     "ddmi_unet_destroy": (_I, [_VP]),
     "ddmi_unet_memory": (_I, [_VP, C.POINTER(C.c_uint64 * 3)]),
     "ddmi_ddpm_step": (_I, [_VP, _VP, _VP, _VP, C.POINTER(StepCoefs), _I, _I, _VP, _VP, _I, _I, _I, _VP]),

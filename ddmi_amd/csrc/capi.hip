@@ -73,6 +73,11 @@ int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps
   DDMI_REQUIRE(h, "null handle");
   return unet_forward(h->u, x, t, eps_out, B, (hipStream_t)stream);
 }
+int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled) {
+  DDMI_REQUIRE(h, "null handle");
+  h->u.uniform_t = enabled != 0;
+  return DDMI_OK;
+}
 int ddmi_unet_destroy(ddmi_unet* h) {
   delete h;
   return DDMI_OK;

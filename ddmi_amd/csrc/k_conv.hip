@@ -46,7 +46,8 @@ struct ConvK {
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
   int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier
   float out_scale;
-  unsigned x_bytes, w_bytes;                // buffer extents (per batch entry) for the range check
+  uint64_t x_bytes;                         // activation extent in bytes (per batch entry); may exceed 2 GiB
+  unsigned w_bytes;                         // weight extent (per batch entry) for the range check
   int64_t x_bstride, w_bstride, y_bstride;  // element strides for blockIdx.y (batched GEMM mode)
 };
 
@@ -163,9 +164,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
   const int hw = a.Hout * a.Wout;
 
-  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
+  // descriptors address at most 2 GiB: rebase the activation descriptor at the first sample this tile touches
+  const int b_first = m0 / hw;
+  const int64_t x_sample = (int64_t)a.Hin * a.Win * a.Cin;
+  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride + (int64_t)b_first * x_sample;
+  const uint64_t x_rem = a.x_bytes - (uint64_t)b_first * x_sample * sizeof(T);
+  const unsigned x_extent = x_rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)x_rem;
   const T* wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
-  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes, 0x00020000);
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_extent, 0x00020000);
   auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
 
   // ---- per-lane gather descriptors (fixed over the K loop); lane owns PHYSICAL slot lane&3 of row lane>>2 ----
@@ -184,7 +190,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     a_ih0[i] = oh * a.stride - a.pad;
     a_iw0[i] = ow * a.stride - a.pad;
     a_coff[i] = slot * EPS;
-    a_pix[i] = b * a.Hin * a.Win;
+    a_pix[i] = (ok ? b - b_first : 0) * a.Hin * a.Win;
     a_base[i] = ((a_pix[i] + a_ih0[i] * a.Win + a_iw0[i]) * a.Cin + a_coff[i]) * SZ;
   }
   int b_base[B_PER], b_coff[B_PER], b_ok[B_PER];
@@ -340,9 +346,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   const int taps = a.KH * a.KW;
   const int NCB = (a.Cin + 63) >> 6;  // 64-channel blocks per tap
 
-  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
+  // descriptors address at most 2 GiB: rebase the activation descriptor at the first sample this tile touches
+  const int b_first = m0 / hw;
+  const int64_t x_sample = (int64_t)a.Hin * a.Win * a.Cin;
+  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride + (int64_t)b_first * x_sample;
+  const uint64_t x_rem = a.x_bytes - (uint64_t)b_first * x_sample * sizeof(T);
+  const unsigned x_extent = x_rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)x_rem;
   const T* wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
-  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes, 0x00020000);
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_extent, 0x00020000);
   auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
 
   // ---- per-lane gather descriptors: lane owns physical slot lane&7 of row (lane>>3) of its 8-row group --------
@@ -361,7 +372,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     int oh = r / a.Wout, ow = r - oh * a.Wout;
     a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
     a_iw0[i] = ow * a.stride - a.pad;
-    a_pb[i] = (b * a.Hin * a.Win * a.Cin + coff) * SZ;
+    a_pb[i] = ((ok ? b - b_first : 0) * a.Hin * a.Win * a.Cin + coff) * SZ;
   }
   int b_base[B_PER];  // invalid rows: negative
 #pragma unroll
@@ -520,9 +531,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
   const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
   const int hw = a.Hout * a.Wout;
 
-  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride;
+  // descriptors address at most 2 GiB: rebase the activation descriptor at the first sample this tile touches
+  const int b_first = m0 / hw;
+  const int64_t x_sample = (int64_t)a.Hin * a.Win * a.Cin;
+  const T* xg = (const T*)a.x + (int64_t)blockIdx.y * a.x_bstride + (int64_t)b_first * x_sample;
+  const uint64_t x_rem = a.x_bytes - (uint64_t)b_first * x_sample * sizeof(T);
+  const unsigned x_extent = x_rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)x_rem;
   const T* wg = (const T*)a.w + (int64_t)blockIdx.y * a.w_bstride;
-  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes, 0x00020000);
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_extent, 0x00020000);
   auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
 
   // ---- per-thread gather descriptors (fixed over the K loop) ---------------------------------------
@@ -544,7 +560,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
     a_ih0[i] = oh * a.stride - a.pad;
     a_iw0[i] = ow * a.stride - a.pad;
     a_coff[i] = slot * EPS;
-    a_pix[i] = b * a.Hin * a.Win;  // pixel index of the sample's first pixel
+    a_pix[i] = (ok ? b - b_first : 0) * a.Hin * a.Win;  // pixel index of the sample's first pixel
     a_base[i] = ((a_pix[i] + a_ih0[i] * a.Win + a_iw0[i]) * a.Cin + a_coff[i]) * SZ;
     a_lds[i] = row * ROWB + pslot * 16;
   }
@@ -817,8 +833,11 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.dbg = dbg;
   uint64_t xb = (uint64_t)a.B * a.Hin * a.Win * a.Cin * dt_size(dt);
   uint64_t wb = (uint64_t)a.Cout * a.KH * a.KW * a.Cin * dt_size(dt);
-  DDMI_REQUIRE(xb < 0x80000000ull && wb < 0x80000000ull, "conv: tensor exceeds the 2 GiB buffer-descriptor range");
-  k.x_bytes = (unsigned)xb;
+  // weights and the few samples one tile can touch must fit a 2 GiB descriptor; the whole activation need not
+  uint64_t per_sample = (uint64_t)a.Hin * a.Win * a.Cin * dt_size(dt);
+  uint64_t span = (uint64_t)(256 / std::max(1, a.Hout * a.Wout) + 2) * per_sample;
+  DDMI_REQUIRE(wb < 0x80000000ull && (span < 0x7FFFFFFFull || xb < 0x7FFFFFFFull), "conv: tensor exceeds the 2 GiB buffer-descriptor range");
+  k.x_bytes = xb;
   k.w_bytes = (unsigned)wb;
   *out = k;
   return DDMI_OK;

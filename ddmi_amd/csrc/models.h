@@ -7,6 +7,7 @@ struct UNet {
   Net net;
   int emb_dim = 0;
   int emb_total = 0;             // sum of ResBlock out channels: width of the concatenated emb projection
+  bool uniform_t = false;        // caller promises t[0] == t[b] for all b: the embedding path runs for one row
   std::vector<float> emb_w_host, emb_b_host;
   float *freqs = nullptr, *te_w0 = nullptr, *te_b0 = nullptr, *te_w1 = nullptr, *te_b1 = nullptr;
   float *emb_w = nullptr, *emb_b = nullptr;

@@ -195,13 +195,15 @@ int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int 
   float* e1 = temb + (size_t)B * mc;          // [B][E]
   float* e2 = e1 + (size_t)B * E;             // [B][E]
   float* eall = e2 + (size_t)B * E;           // [B][emb_total]
-  DDMI_TRY(launch_timestep_embedding(t, u.freqs, temb, B, mc, s));
-  DDMI_TRY(launch_linear_small(temb, mc, u.te_w0, u.te_b0, e1, E, B, mc, E, 0, s));
-  DDMI_TRY(launch_linear_small(e1, E, u.te_w1, u.te_b1, e2, E, B, E, E, 1, s));
+  // all chains of a sampling batch share the timestep (ddpm.py:294, 349): one embedding row, broadcast by stride 0
+  const int Be = u.uniform_t ? 1 : B;
+  DDMI_TRY(launch_timestep_embedding(t, u.freqs, temb, Be, mc, s));
+  DDMI_TRY(launch_linear_small(temb, mc, u.te_w0, u.te_b0, e1, E, Be, mc, E, 0, s));
+  DDMI_TRY(launch_linear_small(e1, E, u.te_w1, u.te_b1, e2, E, Be, E, E, 1, s));
   // every ResBlock's emb_layers = Linear(SiLU(emb)) (openaimodel.py:219-225) in one launch
-  DDMI_TRY(launch_linear_small(e2, E, u.emb_w, u.emb_b, eall, u.emb_total, B, E, u.emb_total, 1, s));
+  DDMI_TRY(launch_linear_small(e2, E, u.emb_w, u.emb_b, eall, u.emb_total, Be, E, u.emb_total, 1, s));
   void* ext[2] = {(void*)x, (void*)eps_out};
-  return n.run(B, ext, eall, u.emb_total, s);
+  return n.run(B, ext, eall, u.uniform_t ? 0 : u.emb_total, s);
 }
 
 // =====================================================================================================

@@ -204,6 +204,8 @@ class DDPM:
         eps = torch.empty_like(img)
         tt = torch.empty((B,), device=device, dtype=torch.int64)
         intermediates = [img.clone()] if return_intermediates else None
+        if hasattr(self.model, "set_uniform_t"):
+            self.model.set_uniform_t(True)  # torch.full((b,), i): every chain shares the timestep (ddpm.py:294)
         for n, i in enumerate(reversed(range(self.num_timesteps))):
             tt.fill_(i)
             self.model(img, tt, cond, out=eps, enable_mask=False)
@@ -212,6 +214,8 @@ class DDPM:
             img, nxt = nxt, img
             if return_intermediates:
                 intermediates.append(img.clone())
+        if hasattr(self.model, "set_uniform_t"):
+            self.model.set_uniform_t(False)
         return (img, intermediates) if return_intermediates else img
 
     def ddim_sample(self, shape, cond=None, clip_denoised=False, noise=None, enable_mask=False, step_noise=None,
@@ -227,6 +231,8 @@ class DDPM:
         nxt = torch.empty_like(img)
         eps = torch.empty_like(img)
         tt = torch.empty((B,), device=device, dtype=torch.int64)
+        if hasattr(self.model, "set_uniform_t"):
+            self.model.set_uniform_t(True)  # ddpm.py:349
         for n, (t, t_next) in enumerate(ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)):
             tt.fill_(t)
             self.model(img, tt, cond, out=eps, enable_mask=enable_mask)
@@ -237,6 +243,8 @@ class DDPM:
                 nz = draw(n) if (k.sigma != 0.0 or step_noise is not None) else None
                 self._step(img, eps, nz, k, _lib.STEP_DDIM, nxt, clip_denoised)
             img, nxt = nxt, img
+        if hasattr(self.model, "set_uniform_t"):
+            self.model.set_uniform_t(False)
         return img
 
     def sample(self, shape, cond=None, return_intermediates=False, noise=None, enable_mask=False, **kw):

@@ -180,6 +180,8 @@ class UNetModel:
             raise
         self._handle = h
         self._state = {}  # packed on device now
+        if getattr(self, "_uniform_t", False):
+            _lib.check(L.ddmi_unet_set_uniform_t(h, 1))
         return self
 
     def memory(self):
@@ -188,6 +190,13 @@ class UNetModel:
         return {"weights": int(out[0]), "arena": int(out[1]), "splitk": int(out[2])}
 
     # ---- forward ----------------------------------------------------------------------------------------
+    def set_uniform_t(self, enabled: bool):
+        """Sampling loops feed the same timestep to every chain of the batch; tell the library so."""
+        self._uniform_t = bool(enabled)
+        if self._handle is not None:
+            _lib.check(_lib.lib().ddmi_unet_set_uniform_t(self._handle, int(enabled)))
+        return self
+
     def forward(self, x, timesteps=None, context=None, y=None, out=None, **kwargs):
         import torch
         assert context is None and y is None, "unconditional sampling only (ddpm.py:304-308)"

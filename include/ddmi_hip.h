@@ -68,6 +68,9 @@ int ddmi_unet_load_weight(ddmi_unet* h, const char* key, const float* data, cons
 int ddmi_unet_finalize(ddmi_unet* h);      /* packs weights for MFMA, plans the workspace; frees host copies */
 /* x [B,Cin,S,S] fp32, t [B] int64 (device), eps_out [B,Cout,S,S] fp32 */
 int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps_out, int B, void* stream);
+/* promise that every element of `t` equals t[0] in the following forwards (true for every sampling loop of
+ * diffusion/ddpm.py: :294, :349): the time-embedding path then runs for one row instead of B */
+int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled);
 int ddmi_unet_destroy(ddmi_unet* h);
 /* bytes held by the handle: [0] packed weights, [1] activation arena, [2] split-K slabs */
 int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]);
