@@ -541,3 +541,123 @@ def generate(unet_p: State, unet_cfg: Mapping, vae_p: State, ddconfig: Mapping, 
     planes = vae_decode(vae_p, ddconfig, z)
     img = image_mlp(mlp_p, generate_coords(res), planes, scale_injection(res))
     return {"z": z, "planes": planes, "img": img.clamp(-1.0, 1.0)}
+
+
+# ======================================================================================
+# a16, a21, a23  occupancy path: tri-plane decoder, tri-plane plane sampling, MLP3D, query grid
+# ======================================================================================
+
+def make_3d_grid(bb_min, bb_max, shape) -> Tensor:
+    """convocc/src/common.py:145-164: x slowest, z fastest; fp32 linspace per axis."""
+    size = shape[0] * shape[1] * shape[2]
+    pxs = torch.from_numpy(linspace_f32(bb_min[0], bb_max[0], shape[0]))
+    pys = torch.from_numpy(linspace_f32(bb_min[1], bb_max[1], shape[1]))
+    pzs = torch.from_numpy(linspace_f32(bb_min[2], bb_max[2], shape[2]))
+    pxs = pxs.view(-1, 1, 1).expand(*shape).contiguous().view(size)
+    pys = pys.view(1, -1, 1).expand(*shape).contiguous().view(size)
+    pzs = pzs.view(1, 1, -1).expand(*shape).contiguous().view(size)
+    return torch.stack([pxs, pys, pzs], dim=1)
+
+
+def occupancy_query_points(nx: int, padding: float = 0.1) -> Tensor:
+    """convocc/src/conv_onet/generation.py:87-94: (1 + padding) * make_3d_grid((-.5,)*3, (.5,)*3, (nx,)*3)."""
+    return (1 + padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+
+
+_PLANE_AXES = {"xz": (0, 2), "xy": (0, 1), "yz": (1, 2)}
+
+
+def normalize_coordinate(p: Tensor, plane: str, padding: float = 0.1) -> Tensor:
+    """gu:71-94: u = p[axes] / (1 + padding + 10e-6) + 0.5; u >= 1 -> 1 - 10e-6; u < 0 -> 0.  p [B,N,3] -> [B,N,2]."""
+    a0, a1 = _PLANE_AXES[plane]
+    xy = torch.stack((p[..., a0], p[..., a1]), dim=-1)
+    xy_new = xy / (1 + padding + 10e-6) + 0.5
+    xy_new = torch.where(xy_new >= 1, torch.full_like(xy_new, 1 - 10e-6), xy_new)
+    xy_new = torch.where(xy_new < 0, torch.zeros_like(xy_new), xy_new)
+    return xy_new
+
+
+def triplane_features_add(planes_xy: Tensor, planes_yz: Tensor, planes_xz: Tensor, p: Tensor) -> Tensor:
+    """gu:115-119 (sample_plane_feature) + gu:126-131 (mode 'add'): sum over the three planes of bilinear samples
+    (align_corners=True, border) at grid 2u-1.  planes [B,C,S,S], p [B,N,3] -> [B,N,C]."""
+    out = None
+    for pl, name in ((planes_xy, "xy"), (planes_yz, "yz"), (planes_xz, "xz")):
+        u = normalize_coordinate(p.clone(), name)
+        g = 2.0 * u.float() - 1.0
+        f = bilinear_border(_t(pl), g[..., 0], g[..., 1], align_corners=True)  # [B,C,N]
+        out = f if out is None else out + f
+    return out.transpose(1, 2)
+
+
+def resnet_block_fc(p: State, pre: str, x: Tensor) -> Tensor:
+    """blocks:707-716: x_s + fc_1(relu(fc_0(relu(x)))), bias-free shortcut when size_in != size_out."""
+    net = F.linear(F.relu(x), p[pre + "fc_0.weight"], p[pre + "fc_0.bias"])
+    dx = F.linear(F.relu(net), p[pre + "fc_1.weight"], p[pre + "fc_1.bias"])
+    xs = F.linear(x, p[pre + "shortcut.weight"]) if (pre + "shortcut.weight") in p else x
+    return xs + dx
+
+
+def mlp3d(p: State, coords: Tensor, hdbf: Sequence[Sequence[Tensor]]) -> Tensor:
+    """MLP3D.forward mlp.py:82-111.  coords [B,N,3]; hdbf = (xy, yz, xz), each a list of 3 planes coarse -> fine.
+    Returns the Bernoulli logits [B,N]."""
+    coords = _t(coords)
+    xy, yz, xz = hdbf
+    feats = [triplane_features_add(xy[i], yz[i], xz[i], coords) for i in range(3)]
+    x = F.linear(coords, p["net_p.weight"], p["net_p.bias"]) + resnet_block_fc(p, "net_res1.", feats[0])
+    x = resnet_block_fc(p, "net_res2.", torch.cat((x, feats[1]), dim=-1))
+    x = resnet_block_fc(p, "net_res3.", torch.cat((x, feats[2]), dim=-1))
+    x = resnet_block_fc(p, "net_res4.", x)
+    return F.linear(x, p["net_out.weight"], p["net_out.bias"]).squeeze(-1)
+
+
+def vae3d_decode(p: State, ddconfig: Mapping, embed_dim: int, z: Tensor):
+    """Autoencoder3D.decode ae:907-916 + Decoder_triplane.forward ae:1461-1564.  z [B, 3*embed_dim, S, S] with channel
+    blocks (xy | xz | yz); per-plane post_quant convs; returns (xy, yz, xz), each a list of planes coarse -> fine."""
+    z = _t(z)
+    e = embed_dim
+    xy, xz, yz = z[:, :e], z[:, e:2 * e], z[:, 2 * e:]
+    hs = [F.conv2d(xy, p["post_quant_conv_xy.weight"], p["post_quant_conv_xy.bias"]),
+          F.conv2d(yz, p["post_quant_conv_yz.weight"], p["post_quant_conv_yz.bias"]),
+          F.conv2d(xz, p["post_quant_conv_xz.weight"], p["post_quant_conv_xz.bias"])]  # decoder((xy, yz, xz))
+    d = "decoder."
+    ch_mult = list(ddconfig["ch_mult"])
+    nres, nrb = len(ch_mult), ddconfig["num_res_blocks"]
+    attn_res = set(ddconfig.get("attn_resolutions", []))
+    hdbf_res = set(ddconfig["hdbf_resolutions"])
+    inter_res = set(ddconfig["inter_attn_resolutions"])
+    curr = ddconfig["resolution"] // 2 ** (nres - 1)
+
+    def per_plane(fn):
+        return [fn(h) for h in hs]
+
+    def inter(hs, names):
+        ch = hs[0].shape[1]
+        h = torch.cat(hs, dim=1)
+        h = vae_resnet_block(p, names[0], h)
+        h = vae_attn_block(p, names[1], h)
+        h = vae_resnet_block(p, names[2], h)
+        return [h[:, :ch], h[:, ch:2 * ch], h[:, 2 * ch:]]
+
+    hs = per_plane(lambda h: F.conv2d(h, p[d + "conv_in.weight"], p[d + "conv_in.bias"], padding=1))
+    hs = per_plane(lambda h: vae_resnet_block(p, d + "mid.block_2.",
+                                              vae_attn_block(p, d + "mid.attn_1.", vae_resnet_block(p, d + "mid.block_1.", h))))
+    hs = inter(hs, (d + "mid.block_3.", d + "mid_attn.", d + "mid.block_4."))
+    outs = [[], [], []]
+    for lvl in reversed(range(nres)):
+        for ib in range(nrb + 1):
+            hs = per_plane(lambda h: vae_resnet_block(p, f"{d}up.{lvl}.block.{ib}.", h))
+            if curr in attn_res:
+                hs = per_plane(lambda h: vae_attn_block(p, f"{d}up.{lvl}.attn.{ib}.", h))
+        if curr in inter_res:
+            hs = inter(hs, (f"{d}up.{lvl}.inter_attn.0.", f"{d}up.{lvl}.inter_attn.1.", f"{d}up.{lvl}.inter_attn.2."))
+        if curr in hdbf_res:
+            for i, h in enumerate(hs):
+                outs[i].append(F.conv2d(h, p[f"{d}up.{lvl}.hdbf.0.weight"], p[f"{d}up.{lvl}.hdbf.0.bias"]))
+        if lvl != 0:
+            hs = per_plane(lambda h: F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"),
+                                              p[f"{d}up.{lvl}.upsample.conv.weight"], p[f"{d}up.{lvl}.upsample.conv.bias"], padding=1))
+            curr *= 2
+    for i, h in enumerate(hs):
+        h = silu(group_norm(h, p[d + "norm_out.weight"], p[d + "norm_out.bias"], 1e-6))
+        outs[i].append(F.conv2d(h, p[d + "conv_out.weight"], p[d + "conv_out.bias"], padding=1))
+    return tuple(outs)  # (xy, yz, xz)

@@ -122,6 +122,12 @@ TOY_DD = dict(double_z=True, z_channels=32, resolution=32, in_channels=3, out_ch
               num_res_blocks=2, attn_resolutions=[], hdbf_resolutions=[16, 8], dropout=0.0, attn_type="vanilla")
 TOY_EMBED = 64
 MLP_CFG = dict(in_ch=2, out_ch=3, ch=256, latent_dim=64)
+# occupancy (config 4) toys: tri-plane decoder on a 4x4 latent -> planes 4^2, 8^2, 16^2; MLP3D at its real size
+TOY_DD3 = dict(double_z=True, z_channels=32, resolution=16, in_channels=32, out_ch=64, ch=32, ch_mult=[1, 2, 4],
+               num_res_blocks=2, attn_resolutions=[], hdbf_resolutions=[8, 4], inter_attn_resolutions=[16, 8, 4],
+               dropout=0.0, attn_type="vanilla")
+TOY_EMBED3 = 16
+MLP3D_CFG = dict(in_ch=3, out_ch=1, ch=256, latent_dim=64)
 
 
 def main():
@@ -310,6 +316,35 @@ def main():
             g1[f"{name}.img"] = np32(img)
     np.savez(os.path.join(OUT, "G1_generate.npz"), **g1)
 
+    # ---------------- O1: occupancy path (Autoencoder3D.decode, MLP3D, query grid) ----------------
+    from models.d2c_vae.autoencoder_unet import Autoencoder3D
+    from models.d2c_vae.mlp import MLP3D
+    ae3 = Autoencoder3D(ddconfig=TOY_DD3, embed_dim=TOY_EMBED3)
+    full3 = load_named(ae3, "O1.vae3d")
+    manifests["O1.vae3d"] = {k: v for k, v in full3.items() if k.startswith("decoder.") or k.startswith("post_quant_conv")}
+    z3 = iw.normal("O1", "z", (2, 3 * TOY_EMBED3, 4, 4))
+    xy, yz, xz = ae3.decode(torch.from_numpy(z3))
+    o1 = {"z": z3}
+    for name, lst in (("xy", xy), ("yz", yz), ("xz", xz)):
+        for i, pl in enumerate(lst):
+            o1[f"{name}{i}"] = np32(pl)
+    mlp3 = MLP3D(**MLP3D_CFG)
+    manifests["O1.mlp3d"] = load_named(mlp3, "O1.mlp3d")
+    pts = iw.normal("O1", "points", (2, 4096, 3), 0.0, 0.35)      # |p| up to ~1.5: exercises both clamp branches
+    pts[0, :8] = np.array([[0.55, -0.55, 0.0], [0.6, 0.6, 0.6], [-0.7, 0.2, 0.1], [0.5500055, 0, 0], [-0.5500055, 0, 0],
+                           [0.0, 0.0, 0.0], [0.549, 0.549, -0.549], [10.0, -10.0, 3.0]], dtype=np.float32)
+    o1["points"] = pts
+    o1["logits"] = np32(mlp3(torch.from_numpy(pts), (xy, yz, xz)).logits)
+    # the dense query grid of generate_mesh_fromdiffusion (generation.py:87-94) at nx = 6, through eval_points' chunking
+    nx = 6
+    lin = lambda n: torch.linspace(-0.5, 0.5, n)
+    grid = 1.1 * torch.stack([lin(nx).view(-1, 1, 1).expand(nx, nx, nx).reshape(-1), lin(nx).view(1, -1, 1).expand(nx, nx, nx).reshape(-1),
+                              lin(nx).view(1, 1, -1).expand(nx, nx, nx).reshape(-1)], dim=1)
+    o1["grid6"] = np32(grid)
+    one = tuple([pl[:1] for pl in lst] for lst in (xy, yz, xz))
+    o1["grid6_logits"] = np32(mlp3(grid[None], one).logits[0])
+    np.savez(os.path.join(OUT, "O1_occupancy.npz"), **o1)
+
     # ---------------- C1: coordinate grids -------------------------------------------------------
     c1 = {}
     for R in (4, 64, 256):
@@ -331,7 +366,7 @@ def main():
         json.dump(manifests, f)
     with open(os.path.join(OUT, "configs.json"), "w") as f:
         json.dump({"TOY_UNET": TOY_UNET, "TOY_UNET_B": TOY_UNET_B, "TOY_DD": TOY_DD, "TOY_EMBED": TOY_EMBED,
-                   "MLP_CFG": MLP_CFG}, f)
+                   "MLP_CFG": MLP_CFG, "TOY_DD3": TOY_DD3, "TOY_EMBED3": TOY_EMBED3, "MLP3D_CFG": MLP3D_CFG}, f)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, f"({tot / 1e6:.2f} MB)")
 

@@ -105,3 +105,46 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DdmiError, match="no fallback"):
         _lib.lib()
+
+
+def test_checkpoint_ingestion_maps_reference_keys(tmp_path):
+    """`ldm-last.pt` layout of tools/ldm/image.py:104-119: 'vaemodel' (full Autoencoder incl. encoder keys), 'mlp',
+    'diffusion' (model.* + buffers + mixing_logit), 'ema' (ema_pytorch: ema_model.* + bookkeeping).  EMA weights win."""
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.pipeline import ImagePipeline
+    ucfg = dict(image_size=8, in_channels=64, model_channels=32, out_channels=64, attention_resolutions=[2],
+                num_res_blocks=1, channel_mult=[1, 2], num_head_channels=32)
+    dd = dict(double_z=True, z_channels=32, resolution=32, in_channels=3, out_ch=64, ch=32, ch_mult=[1, 2, 4],
+              num_res_blocks=2, attn_resolutions=[], hdbf_resolutions=[16, 8], dropout=0.0, attn_type="vanilla")
+    ddpm = dict(timesteps=1000, sampling_timesteps=50, ddim_sampling_eta=0.0, image_size=8, channels=64)
+    pipe = ImagePipeline(ucfg, dd, dict(in_ch=2, out_ch=3, ch=256, latent_dim=64), ddpm, 64, test_resolution=32,
+                         numerics="fp32", max_batch=2, device="cuda:0")
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    unet_raw = iw.fill_state("ck.unet.raw", pipe.unet.manifest())
+    unet_ema = iw.fill_state("ck.unet.ema", pipe.unet.manifest())
+    vae = iw.fill_state("ck.vae", pipe.vae.manifest())
+    vae_full = dict(vae)
+    vae_full["encoder.conv_in.weight"] = np.zeros((32, 3, 3, 3), np.float32)   # training-only keys are tolerated
+    vae_full["quant_conv.weight"] = np.zeros((128, 64, 1, 1), np.float32)
+    mlp = iw.fill_state("ck.mlp", pipe.mlp.manifest())
+    sched = {k: getattr(pipe.ddpm, k) for k in ("betas", "alphas_cumprod", "posterior_mean_coef1")}
+    diffusion = {**{"model." + k: v for k, v in unet_raw.items()}, **sched, "mixing_logit": np.full((1, 64, 1, 1), -6, np.float32)}
+    ema = {**{"ema_model.model." + k: v for k, v in unet_ema.items()}, **{"ema_model." + k: v for k, v in sched.items()},
+           "ema_model.mixing_logit": np.full((1, 64, 1, 1), -5.5, np.float32),
+           "initted": np.array([1.0], np.float32), "step": np.array([1234.0], np.float32)}
+    path = tmp_path / "ldm-last.pt"
+    torch.save({"args": None, "step": 3, "current_iters": 7, "vaemodel": t(vae_full), "mlp": t(mlp),
+                "diffusion": t(diffusion), "ema": t(ema), "dae_opt": {}, "scaler": None}, path)
+    pipe.load_checkpoint(str(path))
+    k = "input_blocks.1.0.in_layers.2.weight"
+    assert np.array_equal(pipe.unet._state[k], unet_ema[k])                    # EMA weights, prefix stripped
+    assert float(pipe.ddpm.mixing_logit.reshape(-1)[0]) == -5.5
+    assert np.array_equal(pipe.vae._state["decoder.conv_in.weight"], vae["decoder.conv_in.weight"])
+    assert "encoder.conv_in.weight" not in pipe.vae._state
+    pipe.load_checkpoint(str(path), use_ema=False)
+    assert np.array_equal(pipe.unet._state[k], unet_raw[k])
+    bad = dict(diffusion)
+    bad["betas"] = sched["betas"] * 1.5                                         # a checkpoint of another schedule
+    torch.save({"vaemodel": t(vae_full), "mlp": t(mlp), "diffusion": t(bad)}, path)
+    with pytest.raises(ValueError, match="schedule buffer"):
+        pipe.load_checkpoint(str(path))

@@ -156,3 +156,24 @@ def test_generate_chain(golden, name, T, S, eta):
     planes = O.vae_decode(state(golden, "D1.vae"), cfgs["TOY_DD"], z)
     img = O.image_mlp(state(golden, "M1.mlp"), O.generate_coords(32), planes, O.scale_injection(32)).clamp(-1, 1)
     assert rel_err(img, g1[f"{name}.img"]) < 1e-4
+
+
+def test_occupancy_decoder_and_mlp3d(golden):
+    """Config-4 path: Autoencoder3D.decode, tri-plane 'add' sampling incl. both clamp branches
+    of normalize_coordinate, MLP3D logits, and the dense query grid."""
+    o1 = golden.npz("O1_occupancy.npz")
+    cfgs = golden.json("configs.json")
+    xy, yz, xz = O.vae3d_decode(state(golden, "O1.vae3d"), cfgs["TOY_DD3"], cfgs["TOY_EMBED3"], torch.from_numpy(o1["z"]))
+    assert [tuple(p.shape[2:]) for p in xy] == [(4, 4), (8, 8), (16, 16)]
+    for name, lst in (("xy", xy), ("yz", yz), ("xz", xz)):
+        for i, pl in enumerate(lst):
+            assert rel_err(pl, o1[f"{name}{i}"]) < TOL, (name, i)
+    ref_planes = tuple([torch.from_numpy(o1[f"{n}{i}"]) for i in range(3)] for n in ("xy", "yz", "xz"))
+    pts = torch.from_numpy(o1["points"])
+    assert (pts.abs() > 0.56).any()  # clamp branches exercised
+    logits = O.mlp3d(state(golden, "O1.mlp3d"), pts, ref_planes)
+    assert rel_err(logits, o1["logits"]) < TOL
+    grid = O.occupancy_query_points(6)
+    assert rel_err(grid, o1["grid6"]) < 2e-7
+    one = tuple([pl[:1] for pl in lst] for lst in ref_planes)
+    assert rel_err(O.mlp3d(state(golden, "O1.mlp3d"), grid[None], one)[0], o1["grid6_logits"]) < TOL
