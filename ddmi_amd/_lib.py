@@ -75,6 +75,17 @@ SYMBOLS = {
     "ddmi_mlp2d_finalize": (_I, [_VP]),
     "ddmi_hdpe_mlp2d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _F, _VP, _VP, _I, _I, _VP]),
     "ddmi_mlp2d_destroy": (_I, [_VP]),
+    "ddmi_decoder3d_create": (_I, [C.POINTER(Decoder2dCfg), C.POINTER(_I), _I, C.POINTER(_VP)]),
+    "ddmi_decoder3d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_decoder3d_finalize": (_I, [_VP]),
+    "ddmi_decoder3d_num_scales": (_I, [_VP, C.POINTER(_I), C.POINTER(_I * 4)]),
+    "ddmi_decoder3d_forward": (_I, [_VP, _VP, C.POINTER(_VP), _I, _I, _VP]),
+    "ddmi_decoder3d_destroy": (_I, [_VP]),
+    "ddmi_mlp3d_create": (_I, [C.POINTER(Mlp2dCfg), C.POINTER(_VP)]),
+    "ddmi_mlp3d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_mlp3d_finalize": (_I, [_VP]),
+    "ddmi_hdpe_mlp3d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _VP, _I, _I, _VP]),
+    "ddmi_mlp3d_destroy": (_I, [_VP]),
     "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),

@@ -9,6 +9,8 @@ const char* ddmi_error_cstr();
 struct ddmi_unet { UNet u; };
 struct ddmi_decoder2d { Decoder2d d; };
 struct ddmi_mlp2d { Mlp2d m; };
+struct ddmi_decoder3d { Decoder3d d; };
+struct ddmi_mlp3d { Mlp3d m; };
 
 static int numerics_to_dt(int numerics, int* dt) {
   if (numerics == DDMI_PARITY_FP32) { *dt = DT_F32; return DDMI_OK; }
@@ -179,6 +181,81 @@ int ddmi_hdpe_mlp2d(ddmi_mlp2d* h, const void* const* planes, const int* plane_h
   return mlp2d_forward(h->m, planes, plane_hw, layout, coords, si, noise, rgb_out, B, N, (hipStream_t)stream);
 }
 int ddmi_mlp2d_destroy(ddmi_mlp2d* h) {
+  delete h;
+  return DDMI_OK;
+}
+
+// ---- occupancy: tri-plane decoder + fused MLP3D ---------------------------------------------------------------
+int ddmi_decoder3d_create(const ddmi_decoder2d_cfg* cfg, const int* inter_attn_resolutions, int n_inter, ddmi_decoder3d** out) {
+  DDMI_REQUIRE(cfg && out && n_inter >= 0 && n_inter <= 8, "decoder3d_create: bad argument");
+  DDMI_REQUIRE(cfg->max_batch >= 1, "decoder3d_create: max_batch must be >= 1");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_decoder3d* h = new (std::nothrow) ddmi_decoder3d();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->d.cfg = *cfg;
+  h->d.n_inter = n_inter;
+  for (int i = 0; i < n_inter; ++i) h->d.inter_attn_resolutions[i] = inter_attn_resolutions[i];
+  h->d.net.dt = dt;
+  h->d.net.max_batch = cfg->max_batch;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_decoder3d_load_weight(ddmi_decoder3d* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h, "null handle");
+  return h->d.net.add_host(key, data, shape, ndim);
+}
+int ddmi_decoder3d_finalize(ddmi_decoder3d* h) {
+  DDMI_REQUIRE(h, "null handle");
+  if (h->d.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "already finalized");
+  return decoder3d_finalize(h->d);
+}
+int ddmi_decoder3d_num_scales(ddmi_decoder3d* h, int* n, int plane_hw[4]) {
+  DDMI_REQUIRE(h && n && plane_hw, "null argument");
+  if (!h->d.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "decoder not finalized");
+  *n = h->d.n_scales;
+  for (int i = 0; i < h->d.n_scales; ++i) plane_hw[i] = h->d.plane_hw[i];
+  return DDMI_OK;
+}
+int ddmi_decoder3d_forward(ddmi_decoder3d* h, const float* z, void* const* planes, int layout, int B, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return decoder3d_forward(h->d, z, planes, layout, B, (hipStream_t)stream);
+}
+int ddmi_decoder3d_destroy(ddmi_decoder3d* h) {
+  delete h;
+  return DDMI_OK;
+}
+
+int ddmi_mlp3d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp3d** out) {
+  DDMI_REQUIRE(cfg && out, "mlp3d_create: null argument");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_mlp3d* h = new (std::nothrow) ddmi_mlp3d();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->m.cfg = *cfg;
+  h->m.dt = dt;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_mlp3d_load_weight(ddmi_mlp3d* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h && key && data && ndim >= 0 && ndim <= 8, "mlp3d_load_weight: bad arguments");
+  if (h->m.finalized) return ddmi_fail(DDMI_ERR_STATE, "load_weight after finalize");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  h->m.host[key] = std::move(t);
+  return DDMI_OK;
+}
+int ddmi_mlp3d_finalize(ddmi_mlp3d* h) {
+  DDMI_REQUIRE(h, "null handle");
+  return mlp3d_finalize(h->m);
+}
+int ddmi_hdpe_mlp3d(ddmi_mlp3d* h, const void* const* planes, const int* plane_hw, int layout, const float* points,
+                    float* logits_out, int B, int N, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return mlp3d_forward(h->m, planes, plane_hw, layout, points, logits_out, B, N, (hipStream_t)stream);
+}
+int ddmi_mlp3d_destroy(ddmi_mlp3d* h) {
   delete h;
   return DDMI_OK;
 }

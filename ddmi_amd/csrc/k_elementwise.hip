@@ -325,3 +325,32 @@ int launch_upsample2x(const void* src, void* dst, int dt, int B, int H, int W, i
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
+
+// =====================================================================================================
+// tri-plane channel concat / split: planes [P][Bn][HW][C] <-> [Bn][HW][P*C]  (autoencoder_unet.py:1512, 1517-1519)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) planes_channels_kernel(uint4* __restrict__ planes, uint4* __restrict__ chans,
+                                                              int64_t npix, int vc, int P, int reverse) {
+  int64_t n = npix * vc * P;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int v = (int)(i % vc);
+    int64_t r = i / vc;
+    int pl = (int)(r % P);
+    int64_t pix = r / P;  // b * HW + hw
+    int64_t pi = ((int64_t)pl * npix + pix) * vc + v;
+    if (reverse) planes[pi] = chans[i];
+    else chans[i] = planes[pi];
+  }
+}
+
+int launch_planes_channels(const void* planes, void* chans, int dt, int Bn, int HW, int C, int P, int reverse, hipStream_t s) {
+  int per = dt == DT_F32 ? 4 : 8;
+  DDMI_REQUIRE(C % per == 0, "planes_channels: channels must be a multiple of the 16-byte vector");
+  int64_t npix = (int64_t)Bn * HW;
+  int64_t n = npix * (C / per) * P;
+  int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  hipLaunchKernelGGL(planes_channels_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)planes, (uint4*)chans, npix, C / per, P, reverse);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

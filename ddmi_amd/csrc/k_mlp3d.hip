@@ -1,0 +1,349 @@
+// Fused tri-plane HDPE sampling + occupancy MLP (replaces models/d2c_vae/mlp.py:82-111 `MLP3D.forward` at inference):
+//   sample_plane_feature x3 (utils/general_utils.py:115-119, normalize_coordinate :71-94 with both clamp branches),
+//   triplane_positional_encoding(mode='add') at three scales (:126-131: bilinear, align_corners=True, border),
+//   net_p + four ResnetBlockFC (blocks.py:673-716) + net_out  ->  Bernoulli logits.
+//
+// Same shape as the image kernel (k_mlp2d.hip): one workgroup = 4 waves = a tile of P query points that never leaves
+// the CU; wave w owns output channels [64w, 64w+64) of every 256-wide layer, weights stream L2 -> registers, activations
+// live in LDS.  ResnetBlockFC needs relu(x) for fc_0 and raw x for the shortcut, so block outputs are stored twice
+// (raw + rectified); the hidden activation is stored rectified only.  0.628 MMAC per point; the nine planes of a shape
+// are 2.1 MB bf16 (L2-resident), so the kernel is MFMA-bound (~1 B/pt of plane traffic).
+#include "kernels.h"
+#include "prof.h"
+
+// packed weight matrices (row-major [N][K], storage dtype), in execution order
+//  0 r1.fc_0 [64][64]   1 r1.fc_1 [256][64]   2 r1.shortcut [256][64]
+//  3 r2.fc_0 [256][320] 4 r2.fc_1 [256][256]  5 r2.shortcut [256][320]
+//  6 r3.fc_0 [256][320] 7 r3.fc_1 [256][256]  8 r3.shortcut [256][320]
+//  9 r4.fc_0 [256][256] 10 r4.fc_1 [256][256] 11 net_out [16 (1 used)][256]
+__host__ __device__ constexpr int m3_rows(int i) { return i == 0 ? 64 : i == 11 ? 16 : 256; }
+__host__ __device__ constexpr int m3_k(int i) { return i <= 2 ? 64 : (i == 3 || i == 5 || i == 6 || i == 8) ? 320 : 256; }
+__host__ __device__ constexpr int m3_off(int i) {
+  int o = 0;
+  for (int j = 0; j < i; ++j) o += m3_rows(j) * m3_k(j);
+  return o;
+}
+size_t mlp3d_weight_elems() { return (size_t)m3_off(12); }
+// fp32 constants: biases  r1.fc_0[64] | r1.fc_1[256] | r2.fc_0 | r2.fc_1 | r3.fc_0 | r3.fc_1 | r4.fc_0 | r4.fc_1 (256 each)
+//                 net_p weight [256][4 (3 used)] | net_p bias [256] | net_out bias [4]
+#define M3_B_R1FC0 0
+#define M3_B(i) (64 + (i) * 256)  // i = 0: r1.fc_1, 1: r2.fc_0, 2: r2.fc_1, 3: r3.fc_0, 4: r3.fc_1, 5: r4.fc_0, 6: r4.fc_1
+#define M3_WP (64 + 7 * 256)
+#define M3_BP (M3_WP + 1024)
+#define M3_BOUT (M3_BP + 256)
+size_t mlp3d_fb_elems() { return M3_BOUT + 4; }
+
+template <typename T> struct M3L;
+template <> struct M3L<bf16_t> { static constexpr int P = 64, XP = 272, FP = 72; };
+template <> struct M3L<float> { static constexpr int P = 32, XP = 260, FP = 68; };
+
+struct Mlp3dK {
+  const void* planes[9];  // [plane j = xy,yz,xz][scale i]: index j*3 + i, each [B][S_i][S_i][64] NHWC
+  int hw[3];
+  const float* pts;       // [B][N][3]
+  const void* w;
+  const float* fb;
+  float* logits;          // [B][N]
+  int B, N;
+  int64_t total;
+};
+
+// acc[mf][nf] += W[nbase + 16 nf + r][koff + k] * SRC[16 (m_first + mf) + r][k],  k in [0, K)
+template <typename T, int MF, int NF, int K>
+__device__ __forceinline__ void m3_gemm(const T* __restrict__ src, int pitch, const T* __restrict__ W, int ldw, int koff,
+                                        int nbase, int m_first, f32x4 (&acc)[MF][NF]) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+#pragma unroll 2
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 wf[NF], xf[MF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        wf[nf] = *reinterpret_cast<const bf16x8*>(W + (int64_t)(nbase + 16 * nf + lr) * ldw + koff + k0 + 8 * lg);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+        xf[mf] = *reinterpret_cast<const bf16x8*>(src + (16 * (m_first + mf) + lr) * pitch + k0 + 8 * lg);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[mf][nf], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 wf[NF], xf[MF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          wf[nf] = *reinterpret_cast<const f32x4*>(W + (int64_t)(nbase + 16 * nf + lr) * ldw + koff + k0 + 16 * h + 4 * lg);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          xf[mf] = *reinterpret_cast<const f32x4*>(src + (16 * (m_first + mf) + lr) * pitch + k0 + 16 * h + 4 * lg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nf][e], xf[mf][e], acc[mf][nf], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <typename T> __device__ __forceinline__ void st4(T* dst, const float* v) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x4*>(dst) = q;
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+}
+
+// normalize_coordinate (general_utils.py:86-93) followed by grid = 2u-1 and the align_corners=True un-normalisation
+__device__ __forceinline__ float m3_texcoord(float p, int S) {
+  float u = p / (1.0f + 0.1f + 10e-6f) + 0.5f;
+  if (u >= 1.0f) u = 1.0f - 10e-6f;
+  if (u < 0.0f) u = 0.0f;
+  float g = 2.0f * u - 1.0f;
+  float ix = (g + 1.0f) * 0.5f * (float)(S - 1);
+  return fminf(fmaxf(ix, 0.f), (float)(S - 1));
+}
+
+// features of scale `sc`: sum over the three planes of bilinear samples -> FR (raw) and FA (rectified)
+template <typename T>
+__device__ __forceinline__ void m3_gather(const Mlp3dK& a, int sc, int64_t tile0, T* FR, T* FA) {
+  constexpr int P = M3L<T>::P, FP = M3L<T>::FP;
+  constexpr int EPS = sizeof(T) == 2 ? 8 : 4;
+  constexpr int CG = 64 / EPS;
+  const int S = a.hw[sc];
+  for (int it = threadIdx.x; it < P * CG; it += 256) {
+    int pi = it / CG, cg = it - pi * CG;
+    int64_t gp = tile0 + pi;
+    float v[EPS];
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) v[e] = 0.f;
+    if (gp < a.total) {
+      int b = (int)(gp / a.N);
+      const float* pt = a.pts + gp * 3;
+      float c3[3] = {pt[0], pt[1], pt[2]};
+      // plane j: xy -> axes (0,1), yz -> (1,2), xz -> (0,2)   (general_utils.py:79-84)
+      const int ax0[3] = {0, 1, 0}, ax1[3] = {1, 2, 2};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float ix = m3_texcoord(c3[ax0[j]], S), iy = m3_texcoord(c3[ax1[j]], S);
+        float x0f = floorf(ix), y0f = floorf(iy);
+        float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        int x0 = (int)x0f, y0 = (int)y0f;
+        int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);
+        const T* base = (const T*)a.planes[j * 3 + sc] + (int64_t)b * S * S * 64 + cg * EPS;
+        const T* p00 = base + ((int64_t)y0 * S + x0) * 64;
+        const T* p01 = base + ((int64_t)y0 * S + x1) * 64;
+        const T* p10 = base + ((int64_t)y1 * S + x0) * 64;
+        const T* p11 = base + ((int64_t)y1 * S + x1) * 64;
+        float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 t00 = *reinterpret_cast<const bf16x8*>(p00), t01 = *reinterpret_cast<const bf16x8*>(p01);
+          bf16x8 t10 = *reinterpret_cast<const bf16x8*>(p10), t11 = *reinterpret_cast<const bf16x8*>(p11);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] += (float)t00[e] * w00 + (float)t01[e] * w01 + (float)t10[e] * w10 + (float)t11[e] * w11;
+        } else {
+          f32x4 t00 = *reinterpret_cast<const f32x4*>(p00), t01 = *reinterpret_cast<const f32x4*>(p01);
+          f32x4 t10 = *reinterpret_cast<const f32x4*>(p10), t11 = *reinterpret_cast<const f32x4*>(p11);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += t00[e] * w00 + t01[e] * w01 + t10[e] * w10 + t11[e] * w11;
+        }
+      }
+    }
+    float r[EPS];
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) r[e] = fmaxf(v[e], 0.f);
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 o, q;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { o[e] = (bf16_t)v[e]; q[e] = (bf16_t)r[e]; }
+      *reinterpret_cast<bf16x8*>(FR + pi * FP + cg * EPS) = o;
+      *reinterpret_cast<bf16x8*>(FA + pi * FP + cg * EPS) = q;
+    } else {
+      *reinterpret_cast<f32x4*>(FR + pi * FP + cg * EPS) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(FA + pi * FP + cg * EPS) = f32x4{r[0], r[1], r[2], r[3]};
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1) mlp3d_kernel(Mlp3dK a) {
+  constexpr int P = M3L<T>::P, XP = M3L<T>::XP, FP = M3L<T>::FP;
+  constexpr int MF = P / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* XR = (T*)smem;          // block output, raw        [P][XP]
+  T* XA = XR + P * XP;       // block output, rectified
+  T* NET = XA + P * XP;      // hidden activation, rectified
+  T* FR = NET + P * XP;      // features of the current scale, raw   [P][FP]
+  T* FA = FR + P * FP;       // ... rectified
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int nbase = 64 * wave;
+  const int64_t tile0 = (int64_t)blockIdx.x * P;
+  const T* W = (const T*)a.w;
+  const float* fb = a.fb;
+
+  f32x4 acc[MF][4], xs[MF][4];
+  auto zero = [&](f32x4(&r)[MF][4]) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // NET <- relu(acc + bias)
+  auto store_hidden = [&](const float* bias) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        int n = nbase + 16 * nf + 4 * lg;
+        f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[mf][nf][e] + b4[e], 0.f);
+        st4<T>(NET + (16 * mf + lr) * XP + n, o);
+      }
+  };
+  // x = xs + acc + bias (+ extra) -> XR, XA ; xs <- x
+  auto store_block = [&](const float* bias, bool with_netp) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int row = 16 * mf + lr;
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (with_netp) {
+        int64_t gp = tile0 + row;
+        if (gp < a.total) { px = a.pts[gp * 3]; py = a.pts[gp * 3 + 1]; pz = a.pts[gp * 3 + 2]; }
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        int n = nbase + 16 * nf + 4 * lg;
+        f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n);
+        float o[4], r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = xs[mf][nf][e] + acc[mf][nf][e] + b4[e];
+          if (with_netp) {  // net_p(coords): Linear(3 -> 256)  (mlp.py:103)
+            const float* wp = fb + M3_WP + (n + e) * 4;
+            v += wp[0] * px + wp[1] * py + wp[2] * pz + fb[M3_BP + n + e];
+          }
+          o[e] = v;
+          r[e] = fmaxf(v, 0.f);
+        }
+        xs[mf][nf] = f32x4{o[0], o[1], o[2], o[3]};
+        st4<T>(XR + row * XP + n, o);
+        st4<T>(XA + row * XP + n, r);
+      }
+    }
+  };
+
+  // ================= block 1: x = net_p(p) + RB(64 -> 256)(f0), hidden width 64 =================================
+  m3_gather<T>(a, 0, tile0, FR, FA);
+  __syncthreads();
+  {
+    f32x4 h[MF][1];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) h[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m3_gemm<T, MF, 1, 64>(FA, FP, W + m3_off(0), 64, 0, 16 * wave, 0, h);  // fc_0: 64 -> 64, 16 channels per wave
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int n = 16 * wave + 4 * lg;
+      f32x4 b4 = *reinterpret_cast<const f32x4*>(fb + M3_B_R1FC0 + n);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(h[mf][0][e] + b4[e], 0.f);
+      st4<T>(NET + (16 * mf + lr) * XP + n, o);
+    }
+  }
+  zero(xs);
+  m3_gemm<T, MF, 4, 64>(FR, FP, W + m3_off(2), 64, 0, nbase, 0, xs);        // shortcut(f0), bias-free
+  __syncthreads();
+  zero(acc);
+  m3_gemm<T, MF, 4, 64>(NET, XP, W + m3_off(1), 64, 0, nbase, 0, acc);      // fc_1(relu(net))
+  store_block(fb + M3_B(0), true);
+  m3_gather<T>(a, 1, tile0, FR, FA);  // f0 is dead: every wave is past the barrier that followed its last read
+  __syncthreads();
+  // ================= blocks 2, 3: x = RB(320 -> 256)([x | f_k]) ===================================================
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const int m0 = 3 + 3 * blk;  // fc_0, fc_1, shortcut matrices of this block
+    zero(acc);
+    m3_gemm<T, MF, 4, 256>(XA, XP, W + m3_off(m0), 320, 0, nbase, 0, acc);
+    m3_gemm<T, MF, 4, 64>(FA, FP, W + m3_off(m0), 320, 256, nbase, 0, acc);
+    zero(xs);
+    m3_gemm<T, MF, 4, 256>(XR, XP, W + m3_off(m0 + 2), 320, 0, nbase, 0, xs);
+    m3_gemm<T, MF, 4, 64>(FR, FP, W + m3_off(m0 + 2), 320, 256, nbase, 0, xs);
+    store_hidden(fb + M3_B(1 + 2 * blk));
+    __syncthreads();  // NET complete; XR/XA/F no longer read
+    zero(acc);
+    m3_gemm<T, MF, 4, 256>(NET, XP, W + m3_off(m0 + 1), 256, 0, nbase, 0, acc);
+    store_block(fb + M3_B(2 + 2 * blk), false);
+    if (blk == 0) m3_gather<T>(a, 2, tile0, FR, FA);
+    __syncthreads();
+  }
+  // ================= block 4: x = x + fc_1(relu(fc_0(relu(x)))) ====================================================
+  zero(acc);
+  m3_gemm<T, MF, 4, 256>(XA, XP, W + m3_off(9), 256, 0, nbase, 0, acc);
+  store_hidden(fb + M3_B(5));
+  __syncthreads();
+  zero(acc);
+  m3_gemm<T, MF, 4, 256>(NET, XP, W + m3_off(10), 256, 0, nbase, 0, acc);
+  store_block(fb + M3_B(6), false);  // xs (= x3, fp32 in registers) + dx
+  __syncthreads();
+  // ================= net_out: 256 -> 1 (rows padded to 16), points split over the waves ============================
+  {
+    constexpr int MFW = MF >= 4 ? MF / 4 : 1;
+    if (wave * MFW < MF) {
+      f32x4 r[MFW][1];
+#pragma unroll
+      for (int i = 0; i < MFW; ++i) r[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      m3_gemm<T, MFW, 1, 256>(XR, XP, W + m3_off(11), 256, 0, 0, wave * MFW, r);
+      if (lg == 0) {
+        float bo = fb[M3_BOUT];
+#pragma unroll
+        for (int i = 0; i < MFW; ++i) {
+          int64_t gp = tile0 + 16 * (wave * MFW + i) + lr;
+          if (gp < a.total) a.logits[gp] = r[i][0][0] + bo;
+        }
+      }
+    }
+  }
+}
+
+int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s) {
+  Mlp3dK k{};
+  for (int i = 0; i < 9; ++i) k.planes[i] = a.planes[i];
+  for (int i = 0; i < 3; ++i) k.hw[i] = a.plane_hw[i];
+  k.pts = a.pts; k.w = a.w; k.fb = a.fb; k.logits = a.logits;
+  k.B = a.B; k.N = a.N; k.total = (int64_t)a.B * a.N;
+  double plane_bytes = 0;
+  for (int i = 0; i < 3; ++i) plane_bytes += 3.0 * a.B * a.plane_hw[i] * a.plane_hw[i] * 64 * dt_size(dt);
+  PROF_SCOPE("mlp3d_fused", 2.0 * 627712.0 * (double)k.total, plane_bytes + 16.0 * (double)k.total, s);
+  if (dt == DT_BF16) {
+    using L = M3L<bf16_t>;
+    size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(bf16_t);
+    static bool set = false;
+    if (!set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set = true;
+    }
+    hipLaunchKernelGGL(mlp3d_kernel<bf16_t>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+  } else {
+    using L = M3L<float>;
+    size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(float);
+    static bool set = false;
+    if (!set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set = true;
+    }
+    hipLaunchKernelGGL(mlp3d_kernel<float>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

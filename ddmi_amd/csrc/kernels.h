@@ -25,6 +25,8 @@ int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int H
 int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int dt, int64_t npix, hipStream_t s);
 int launch_pack_conv_weight(const float* w_oihw, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int launch_cast_f32(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
+// planes [P*Bn][HW][C] <-> channels [Bn][HW][P*C] (reverse=1: channels -> planes); tri-plane decoders
+int launch_planes_channels(const void* planes, void* chans, int dt, int Bn, int HW, int C, int P, int reverse, hipStream_t s);
 int launch_upsample2x(const void* src, void* dst, int dt, int B, int H, int W, int C, hipStream_t s);
 
 // ---- time embedding + small dense layers (fp32) ----------------------------------------------------
@@ -96,3 +98,17 @@ struct Mlp2dArgs {
 int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s);
 size_t mlp2d_weight_elems();
 size_t mlp2d_fb_elems();
+
+// ---- fused tri-plane sampling + occupancy MLP (MLP3D) -----------------------------------------------------
+struct Mlp3dArgs {
+  const void* planes[9];   // index plane*3 + scale, plane order (xy, yz, xz), NHWC in the storage dtype
+  int plane_hw[3];
+  const float* pts;        // [B][N][3]
+  const void* w;
+  const float* fb;
+  float* logits;           // [B][N]
+  int B, N;
+};
+int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s);
+size_t mlp3d_weight_elems();
+size_t mlp3d_fb_elems();

@@ -26,6 +26,18 @@ struct Decoder2d {
 int decoder2d_finalize(Decoder2d& d);
 int decoder2d_forward(Decoder2d& d, const float* z, void* const* planes, int layout, int B, hipStream_t s);
 
+struct Decoder3d {           // tri-plane decoder (occupancy): same config block as the 2-D decoder + inter_attn_resolutions
+  ddmi_decoder2d_cfg cfg{};
+  int inter_attn_resolutions[8] = {0};
+  int n_inter = 0;
+  Net net;
+  int n_scales = 0;
+  int export_ops[3][4] = {{0}};
+  int plane_hw[4] = {0};
+};
+int decoder3d_finalize(Decoder3d& d);
+int decoder3d_forward(Decoder3d& d, const float* z, void* const* planes, int layout, int B, hipStream_t s);
+
 struct Mlp2d {
   ddmi_mlp2d_cfg cfg{};
   int dt = DT_F32;
@@ -44,3 +56,17 @@ struct Mlp2d {
 int mlp2d_finalize(Mlp2d& m);
 int mlp2d_forward(Mlp2d& m, const void* const* planes, const int* plane_hw, int layout, const float* coords, float si,
                   const float* noise, float* rgb, int B, int N, hipStream_t s);
+
+struct Mlp3d {
+  ddmi_mlp2d_cfg cfg{};   // in_ch 3, out_ch 1, ch 256, latent_dim 64
+  int dt = DT_F32;
+  bool finalized = false;
+  std::map<std::string, HostTensor> host;
+  void* w_dev = nullptr;
+  float* fb_dev = nullptr;
+  std::vector<void*> dev_allocs;
+  ~Mlp3d();
+};
+int mlp3d_finalize(Mlp3d& m);
+int mlp3d_forward(Mlp3d& m, const void* const* planes, const int* plane_hw, int layout, const float* pts, float* logits,
+                  int B, int N, hipStream_t s);

@@ -247,10 +247,11 @@ static int build_vae_attn(Net& n, const std::string& pre, int x, int* out) {
   int T = t.H * t.W;
   Op o;
   o.kind = OP_ATTN_FULL;
+  o.bmul = t.bmul;
   o.in = q; o.in2 = k; o.res = v;
-  o.out = n.new_tensor(t.C, t.H, t.W);
-  o.tmp0 = n.new_tensor(T, T, 1);        // scores [T][T]
-  o.tmp1 = n.new_tensor(t.C, t.H, t.W);  // V^T [C][T]
+  o.out = n.new_tensor(t.C, t.H, t.W, -1, t.bmul);
+  o.tmp0 = n.new_tensor(T, T, 1, -1, t.bmul);        // scores [T][T]
+  o.tmp1 = n.new_tensor(t.C, t.H, t.W, -1, t.bmul);  // V^T [C][T]
   o.scale = 1.0f / std::sqrt((float)t.C);  // int(c)**(-0.5), autoencoder_unet.py:203
   n.ops.push_back(o);
   *out = n.op_conv(o.out, cp, 1, 0, x, -1);
@@ -335,5 +336,141 @@ int decoder2d_forward(Decoder2d& d, const float* z, void* const* planes, int lay
     ext[1 + i] = planes[i];
     n.ops[d.export_ops[i]].out_nchw = layout == 0;
   }
+  return n.run(B, ext, nullptr, 0, s);
+}
+
+// =====================================================================================================
+// D2C-VAE tri-plane decoder (occupancy): Autoencoder3D.decode autoencoder_unet.py:907-916 + Decoder_triplane.forward
+// :1461-1564.  The three planes share every per-plane weight, and every per-plane op is per-sample, so the planes are
+// stacked along the batch axis (3B samples, plane-major: xy | yz | xz in the decoder's call order); the inter-plane
+// ResBlock -> Attn -> ResBlock stages run on [B, 3C] after a planes->channels copy and are split back afterwards.
+// =====================================================================================================
+static int build_inter(Net& n, const std::string& r0, const std::string& at, const std::string& r1, int h3, int* out) {
+  const TensorDesc t = n.tensors[h3];
+  Op pc;
+  pc.kind = OP_PLANES_TO_CHANNELS;
+  pc.in = h3;
+  pc.out = n.new_tensor(3 * t.C, t.H, t.W, -1, 1);
+  n.ops.push_back(pc);
+  int h = pc.out;
+  DDMI_TRY(build_vae_resblock(n, r0, h, 3 * t.C, &h));
+  DDMI_TRY(build_vae_attn(n, at, h, &h));
+  DDMI_TRY(build_vae_resblock(n, r1, h, 3 * t.C, &h));
+  Op cp;
+  cp.kind = OP_CHANNELS_TO_PLANES;
+  cp.in = h;
+  cp.out = n.new_tensor(t.C, t.H, t.W, -1, 3);
+  n.ops.push_back(cp);
+  *out = cp.out;
+  return DDMI_OK;
+}
+
+int decoder3d_finalize(Decoder3d& d) {
+  Net& n = d.net;
+  const ddmi_decoder2d_cfg& c = d.cfg;
+  DDMI_REQUIRE(c.n_mult >= 1 && c.n_mult <= 8, "bad ch_mult");
+  const int nres = c.n_mult, e = c.embed_dim;
+  int curr = c.resolution >> (nres - 1);
+  DDMI_REQUIRE(c.latent_size == curr, "latent_size must equal resolution / 2^(len(ch_mult)-1)");
+  Op in;
+  in.kind = OP_NCHW_IN;
+  in.ext = 0;
+  in.out = n.new_tensor(3 * e, curr, curr);
+  n.ops.push_back(in);
+  // post_quant_conv_{xy,yz,xz}: 1x1 convs on channel blocks (xy | xz | yz) of the latent (autoencoder_unet.py:909-914),
+  // realised as 1x1 convs over all 3e channels with zero weights outside the block, each writing one plane slot
+  const char* names[3] = {"post_quant_conv_xy.", "post_quant_conv_yz.", "post_quant_conv_xz."};
+  const int block_of[3] = {0, 2, 1};  // decoder order (xy, yz, xz) <- latent channel blocks (xy, xz, yz)
+  int stacked = n.new_tensor(c.z_channels, curr, curr, -1, 3);
+  for (int j = 0; j < 3; ++j) {
+    const HostTensor* w = n.find(std::string(names[j]) + "weight");
+    const HostTensor* b = n.find(std::string(names[j]) + "bias");
+    if (!w || !b) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, std::string("missing weight '") + names[j] + "*'");
+    DDMI_REQUIRE(w->shape.size() == 4 && w->shape[0] == c.z_channels && w->shape[1] == e, "post_quant_conv shape mismatch");
+    std::vector<float> full((size_t)c.z_channels * 3 * e, 0.f);
+    for (int o = 0; o < c.z_channels; ++o)
+      for (int i = 0; i < e; ++i) full[(size_t)o * 3 * e + block_of[j] * e + i] = w->data[(size_t)o * e + i];
+    int ci;
+    DDMI_TRY(n.make_conv_host(full, c.z_channels, 3 * e, 1, &b->data, &ci));
+    int tmp = n.op_conv(in.out, ci, 1, 0, -1, -1);
+    (void)tmp;
+    Op& o = n.ops.back();  // redirect the output into plane slot j of the stacked tensor
+    n.tensors[o.out].first = -1;
+    o.out = stacked;
+    o.out_boff = j;
+  }
+  int cin_;
+  DDMI_TRY(n.make_conv("decoder.conv_in.weight", "decoder.conv_in.bias", &cin_));
+  int h = n.op_conv(stacked, cin_, 1, 0, -1, -1);
+  int block_in = c.ch * c.ch_mult[nres - 1];
+  DDMI_TRY(build_vae_resblock(n, "decoder.mid.block_1.", h, block_in, &h));
+  DDMI_TRY(build_vae_attn(n, "decoder.mid.attn_1.", h, &h));
+  DDMI_TRY(build_vae_resblock(n, "decoder.mid.block_2.", h, block_in, &h));
+  DDMI_TRY(build_inter(n, "decoder.mid.block_3.", "decoder.mid_attn.", "decoder.mid.block_4.", h, &h));
+  d.n_scales = 0;
+  auto add_export = [&](int tensor) {
+    for (int j = 0; j < 3; ++j) {  // ext slot 1 + plane*3 + scale is fixed up after n_scales is known
+      Op ex;
+      ex.kind = OP_EXPORT;
+      ex.in = tensor;
+      ex.in_boff = j;
+      n.ops.push_back(ex);
+      d.export_ops[j][d.n_scales] = (int)n.ops.size() - 1;
+    }
+    d.plane_hw[d.n_scales] = n.tensors[tensor].H;
+    d.n_scales++;
+  };
+  for (int lvl = nres - 1; lvl >= 0; --lvl) {
+    int block_out = c.ch * c.ch_mult[lvl];
+    for (int ib = 0; ib <= c.num_res_blocks; ++ib) {
+      std::string pre = "decoder.up." + std::to_string(lvl) + ".block." + std::to_string(ib) + ".";
+      DDMI_TRY(build_vae_resblock(n, pre, h, block_out, &h));
+      if (in_list(c.attn_resolutions, c.n_attn, curr)) {
+        std::string pa = "decoder.up." + std::to_string(lvl) + ".attn." + std::to_string(ib) + ".";
+        DDMI_TRY(build_vae_attn(n, pa, h, &h));
+      }
+    }
+    if (in_list(d.inter_attn_resolutions, d.n_inter, curr)) {
+      std::string q = "decoder.up." + std::to_string(lvl) + ".inter_attn.";
+      DDMI_TRY(build_inter(n, q + "0.", q + "1.", q + "2.", h, &h));
+    }
+    if (in_list(c.hdbf_resolutions, c.n_hdbf, curr)) {
+      DDMI_REQUIRE(d.n_scales < 3, "too many HDBF planes");
+      std::string ph = "decoder.up." + std::to_string(lvl) + ".hdbf.0.";
+      int chd;
+      DDMI_TRY(n.make_conv(ph + "weight", ph + "bias", &chd));
+      add_export(n.op_conv(h, chd, 1, 0, -1, -1));
+    }
+    if (lvl != 0) {
+      std::string pu = "decoder.up." + std::to_string(lvl) + ".upsample.conv.";
+      int cu;
+      DDMI_TRY(n.make_conv(pu + "weight", pu + "bias", &cu));
+      h = n.op_conv(h, cu, 1, 1, -1, -1);
+      curr *= 2;
+    }
+  }
+  int gno, co;
+  DDMI_TRY(n.make_gn("decoder.norm_out.", &gno));
+  DDMI_TRY(n.make_conv("decoder.conv_out.weight", "decoder.conv_out.bias", &co));
+  int a = n.op_gn(h, gno, 1, 1e-6f);
+  DDMI_REQUIRE(d.n_scales < 4, "too many HDBF planes");
+  add_export(n.op_conv(a, co, 1, 0, -1, -1));
+  for (int j = 0; j < 3; ++j)
+    for (int sidx = 0; sidx < d.n_scales; ++sidx) n.ops[d.export_ops[j][sidx]].ext = 1 + j * d.n_scales + sidx;
+  return n.plan();
+}
+
+int decoder3d_forward(Decoder3d& d, const float* z, void* const* planes, int layout, int B, hipStream_t s) {
+  Net& n = d.net;
+  if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "decoder not finalized");
+  DDMI_REQUIRE(z && planes, "decoder3d_forward: null pointer");
+  DDMI_REQUIRE(layout == 0 || layout == 1, "decoder3d_forward: layout must be 0 (NCHW fp32) or 1 (NHWC native)");
+  prof_begin_forward();
+  void* ext[16] = {(void*)z};
+  for (int j = 0; j < 3; ++j)
+    for (int sidx = 0; sidx < d.n_scales; ++sidx) {
+      ext[1 + j * d.n_scales + sidx] = planes[j * d.n_scales + sidx];
+      n.ops[d.export_ops[j][sidx]].out_nchw = layout == 0;
+    }
   return n.run(B, ext, nullptr, 0, s);
 }

@@ -32,7 +32,8 @@ struct GNW {
   int C = 0;
 };
 
-enum OpKind { OP_NCHW_IN = 0, OP_GN, OP_CONV, OP_ATTN_LEGACY, OP_ATTN_FULL, OP_CONCAT, OP_EXPORT };
+enum OpKind { OP_NCHW_IN = 0, OP_GN, OP_CONV, OP_ATTN_LEGACY, OP_ATTN_FULL, OP_CONCAT, OP_EXPORT, OP_PLANES_TO_CHANNELS,
+              OP_CHANNELS_TO_PLANES };
 
 struct Op {
   int kind = 0;
@@ -49,6 +50,9 @@ struct Op {
   int tmp0 = -1, tmp1 = -1, tmp2 = -1;  // scratch tensors (OP_ATTN_FULL)
   float scale = 1.f;
   ConvPlan tuned;     // OP_CONV: autotuned launch plan for B == max_batch (cfg 0 = heuristic)
+  // tri-plane networks stack the three planes (shared weights) along the batch axis: an op runs on bmul * B samples;
+  // out_boff / in_boff select a plane (in units of B samples) inside a stacked tensor
+  int bmul = 1, in_boff = 0, out_boff = 0;
 };
 
 struct TensorDesc {
@@ -57,6 +61,7 @@ struct TensorDesc {
   int first = -1, last = -1;
   size_t off = 0;       // byte offset in the arena (for max batch)
   int dt_override = -1; // -1: network dtype
+  int bmul = 1;         // samples held = bmul * B
 };
 
 struct Net {
@@ -84,12 +89,14 @@ struct Net {
   const HostTensor* find(const std::string& key) const;
 
   // ---- build helpers -------------------------------------------------------------------------------
-  int new_tensor(int C, int H, int W, int dt_override = -1);
+  int new_tensor(int C, int H, int W, int dt_override = -1, int bmul = 1);
+  int max_bmul = 1;
   int dev_upload(const float* src, int64_t n, float** out);
   int make_conv(const std::string& wkey, const std::string& bkey, int* idx);   // [Cout,Cin,K,K] or [Cout,Cin,1] / [Cout,Cin]
   int make_gn(const std::string& prefix, int* idx);
   int op_gn(int in, int gn, int silu, float eps);
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
+  int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }
   size_t tbytes(int id, int B) const;

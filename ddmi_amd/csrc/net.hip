@@ -37,11 +37,13 @@ const HostTensor* Net::find(const std::string& key) const {
   return it == host.end() ? nullptr : &it->second;
 }
 
-int Net::new_tensor(int C, int H, int W, int dt_override) {
+int Net::new_tensor(int C, int H, int W, int dt_override, int bmul) {
   TensorDesc t;
   t.C = C; t.H = H; t.W = W;
   t.elems = (int64_t)C * H * W;
   t.dt_override = dt_override;
+  t.bmul = bmul;
+  max_bmul = std::max(max_bmul, bmul);
   tensors.push_back(t);
   return (int)tensors.size() - 1;
 }
@@ -49,7 +51,7 @@ int Net::new_tensor(int C, int H, int W, int dt_override) {
 size_t Net::tbytes(int id, int B) const {
   const TensorDesc& t = tensors[id];
   int d = t.dt_override >= 0 ? t.dt_override : dt;
-  return (size_t)B * t.elems * dt_size(d);
+  return (size_t)B * t.bmul * t.elems * dt_size(d);
 }
 
 int Net::dev_upload(const float* src, int64_t n, float** out) {
@@ -62,41 +64,50 @@ int Net::dev_upload(const float* src, int64_t n, float** out) {
   return DDMI_OK;
 }
 
-int Net::make_conv(const std::string& wkey, const std::string& bkey, int* idx) {
-  const HostTensor* w = find(wkey);
-  if (!w) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + wkey + "'");
-  DDMI_REQUIRE(w->shape.size() >= 2 && w->shape.size() <= 4, "conv weight must be 2-, 3- or 4-D: " + wkey);
+int Net::make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx) {
   ConvW c;
-  c.Cout = (int)w->shape[0];
-  c.Cin = (int)w->shape[1];
-  c.K = w->shape.size() == 4 ? (int)w->shape[2] : 1;
-  if (w->shape.size() == 4) DDMI_REQUIRE(w->shape[2] == w->shape[3], "conv kernel must be square: " + wkey);
-  if (w->shape.size() == 3) DDMI_REQUIRE(w->shape[2] == 1, "conv1d kernel must be 1: " + wkey);
-  int64_t n = w->numel();
+  c.Cout = Cout; c.Cin = Cin; c.K = K;
+  int64_t n = (int64_t)Cout * Cin * K * K;
+  DDMI_REQUIRE((int64_t)w.size() == n, "conv weight size mismatch");
   float* raw = nullptr;
   HIP_TRY(hipMalloc((void**)&raw, (size_t)n * sizeof(float)));
-  hipError_t e = hipMemcpy(raw, w->data.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight upload failed: " + wkey); }
+  hipError_t e = hipMemcpy(raw, w.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight upload failed"); }
   void* packed = nullptr;
   e = hipMalloc(&packed, (size_t)n * dt_size(dt));
-  if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight alloc failed: " + wkey); }
+  if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight alloc failed"); }
   dev_allocs.push_back(packed);
-  int rc = launch_pack_conv_weight(raw, packed, dt, c.Cout, c.Cin, c.K, c.K, 0);
+  int rc = launch_pack_conv_weight(raw, packed, dt, Cout, Cin, K, K, 0);
   hipError_t e2 = hipDeviceSynchronize();
   (void)hipFree(raw);
   if (rc != DDMI_OK) return rc;
-  if (e2 != hipSuccess) return ddmi_fail(DDMI_ERR_HIP, "weight pack failed: " + wkey);
+  if (e2 != hipSuccess) return ddmi_fail(DDMI_ERR_HIP, "weight pack failed");
   weight_bytes += (size_t)n * dt_size(dt);
   c.w = packed;
-  if (!bkey.empty()) {
-    const HostTensor* b = find(bkey);
-    if (!b) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + bkey + "'");
-    DDMI_REQUIRE(b->numel() == c.Cout, "bias size mismatch: " + bkey);
-    DDMI_TRY(dev_upload(b->data.data(), c.Cout, &c.bias));
+  if (bias) {
+    DDMI_REQUIRE((int)bias->size() == Cout, "bias size mismatch");
+    DDMI_TRY(dev_upload(bias->data(), Cout, &c.bias));
   }
   convs.push_back(c);
   *idx = (int)convs.size() - 1;
   return DDMI_OK;
+}
+
+int Net::make_conv(const std::string& wkey, const std::string& bkey, int* idx) {
+  const HostTensor* w = find(wkey);
+  if (!w) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + wkey + "'");
+  DDMI_REQUIRE(w->shape.size() >= 2 && w->shape.size() <= 4, "conv weight must be 2-, 3- or 4-D: " + wkey);
+  int K = w->shape.size() == 4 ? (int)w->shape[2] : 1;
+  if (w->shape.size() == 4) DDMI_REQUIRE(w->shape[2] == w->shape[3], "conv kernel must be square: " + wkey);
+  if (w->shape.size() == 3) DDMI_REQUIRE(w->shape[2] == 1, "conv1d kernel must be 1: " + wkey);
+  const std::vector<float>* bias = nullptr;
+  if (!bkey.empty()) {
+    const HostTensor* b = find(bkey);
+    if (!b) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + bkey + "'");
+    DDMI_REQUIRE(b->numel() == w->shape[0], "bias size mismatch: " + bkey);
+    bias = &b->data;
+  }
+  return make_conv_host(w->data, (int)w->shape[0], (int)w->shape[1], K, bias, idx);
 }
 
 int Net::make_gn(const std::string& prefix, int* idx) {
@@ -119,7 +130,8 @@ int Net::op_gn(int in, int gn, int silu, float eps) {
   Op o;
   o.kind = OP_GN;
   o.in = in;
-  o.out = new_tensor(t.C, t.H, t.W);
+  o.out = new_tensor(t.C, t.H, t.W, -1, t.bmul);
+  o.bmul = t.bmul;
   o.gn = gn;
   o.silu = silu;
   o.eps = eps;
@@ -137,7 +149,8 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
   Op o;
   o.kind = OP_CONV;
   o.in = in;
-  o.out = new_tensor(c.Cout, ho, wo);
+  o.out = new_tensor(c.Cout, ho, wo, -1, t.bmul);
+  o.bmul = t.bmul;
   o.conv = conv;
   o.stride = stride;
   o.pad = pad;
@@ -234,7 +247,7 @@ int Net::plan() {
   dev_allocs.push_back(arena);
 
   if (n_gn_slots > 0) {
-    size_t bytes = GN_STATS_DOUBLES(max_batch) * sizeof(double);  // one scratch shared by every GN op (stream order)
+    size_t bytes = GN_STATS_DOUBLES(max_batch * max_bmul) * sizeof(double);  // one scratch shared by every GN op (stream order)
     HIP_TRY(hipMalloc((void**)&gn_stats, bytes));
     dev_allocs.push_back(gn_stats);
   }
@@ -244,7 +257,7 @@ int Net::plan() {
     if (o.kind != OP_CONV) continue;
     for (int B = 1; B <= max_batch; ++B) {
       ConvArgs a;
-      fill_conv_args(*this, o, B, &a);
+      fill_conv_args(*this, o, B * o.bmul, &a);
       int sk = conv_pick_splitk(a, dt);
       if (sk > 1) splitk_bytes = std::max(splitk_bytes, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
     }
@@ -282,7 +295,7 @@ int Net::plan() {
     for (Op& o : ops) {
       if (o.kind != OP_CONV) continue;
       ConvArgs a;
-      fill_conv_args(*this, o, max_batch, &a);
+      fill_conv_args(*this, o, max_batch * o.bmul, &a);
       a.y = tptr(o.out);  // timing only: results are overwritten by the real run
       std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups};
       auto it = cache.find(key);
@@ -325,7 +338,7 @@ int Net::plan() {
       if (o.kind != OP_CONV) continue;
       for (int B = 1; B < max_batch; ++B) {
         ConvArgs a;
-        fill_conv_args(*this, o, B, &a);
+        fill_conv_args(*this, o, B * o.bmul, &a);
         a.cfg = o.tuned.cfg;
         int sk = conv_pick_splitk(a, dt);
         if (sk > 1) need = std::max(need, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
@@ -349,7 +362,12 @@ int Net::plan() {
 int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStream_t s) {
   if (!finalized) return ddmi_fail(DDMI_ERR_STATE, "network not finalized");
   DDMI_REQUIRE(B >= 1 && B <= max_batch, "batch exceeds max_batch given at create time");
+  const int Bnet = B;
   for (const Op& o : ops) {
+    const int B = Bnet * o.bmul;  // samples this op runs on
+    auto plane_ptr = [&](int id, int boff) -> void* {
+      return (unsigned char*)tptr(id) + (size_t)boff * Bnet * tensors[id].elems * dt_size(dt);
+    };
     switch (o.kind) {
       case OP_NCHW_IN: {
         const TensorDesc& t = tensors[o.out];
@@ -370,14 +388,14 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         fill_conv_args(*this, o, B, &a);
         DDMI_REQUIRE(tensors[o.in].C == a.Cin, "conv input channel mismatch");
         if (o.out_nchw) a.y_nchw = (float*)ext[o.ext];
-        else a.y = tptr(o.out);
+        else a.y = plane_ptr(o.out, o.out_boff);
         if (o.res >= 0) a.res = tptr(o.res);
         if (o.emb_off >= 0) {
           DDMI_REQUIRE(emb != nullptr, "conv needs the time embedding");
           a.emb = emb + o.emb_off;
           a.emb_stride = emb_stride;
         }
-        if (B == max_batch && o.tuned.cfg > 0) {
+        if (Bnet == max_batch && o.tuned.cfg > 0) {
           a.cfg = o.tuned.cfg; a.order = o.tuned.order; a.splitk = o.tuned.splitk;
         } else {
           a.cfg = o.tuned.cfg;  // keep the tuned tile, re-derive the split for this batch size
@@ -413,10 +431,21 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
       case OP_EXPORT: {
         const TensorDesc& t = tensors[o.in];
         if (ext[o.ext] == nullptr) break;
+        const void* src = plane_ptr(o.in, o.in_boff);
         if (o.out_nchw)
-          DDMI_TRY(launch_nhwc_to_nchw(tptr(o.in), dt, (float*)ext[o.ext], B, t.C, t.H * t.W, s));
+          DDMI_TRY(launch_nhwc_to_nchw(src, dt, (float*)ext[o.ext], Bnet, t.C, t.H * t.W, s));
         else
-          HIP_TRY(hipMemcpyAsync(ext[o.ext], tptr(o.in), tbytes(o.in, B), hipMemcpyDeviceToDevice, s));
+          HIP_TRY(hipMemcpyAsync(ext[o.ext], src, (size_t)Bnet * t.elems * dt_size(dt), hipMemcpyDeviceToDevice, s));
+        break;
+      }
+      case OP_PLANES_TO_CHANNELS: {  // [3*Bn][HW][C] (plane-major) -> [Bn][HW][3C]
+        const TensorDesc& t = tensors[o.in];
+        DDMI_TRY(launch_planes_channels(tptr(o.in), tptr(o.out), dt, Bnet, t.H * t.W, t.C, 3, 0, s));
+        break;
+      }
+      case OP_CHANNELS_TO_PLANES: {
+        const TensorDesc& t = tensors[o.out];
+        DDMI_TRY(launch_planes_channels(tptr(o.out), tptr(o.in), dt, Bnet, t.H * t.W, t.C, 3, 1, s));
         break;
       }
       default:

@@ -142,6 +142,32 @@ int ddmi_hdpe_mlp2d(ddmi_mlp2d* h, const void* const* planes, const int* plane_h
 int ddmi_mlp2d_destroy(ddmi_mlp2d* h);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Occupancy (ShapeNet) path.
+ * Tri-plane decoder: replaces Autoencoder3D.decode (models/d2c_vae/autoencoder_unet.py:907-916) = three per-plane
+ * post_quant convs + Decoder_triplane.forward (:1461-1564).  Keys: "post_quant_conv_{xy,yz,xz}.*", "decoder.*".
+ * z [B, 3*embed_dim, S, S] fp32 NCHW with channel blocks (xy | xz | yz); planes[plane*n_scales + scale], plane order
+ * (xy, yz, xz) = the tuple decode() returns, scales coarse -> fine, each [B,out_ch,P,P] in `layout`.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct ddmi_decoder3d ddmi_decoder3d;
+int ddmi_decoder3d_create(const ddmi_decoder2d_cfg* cfg, const int* inter_attn_resolutions, int n_inter, ddmi_decoder3d** out);
+int ddmi_decoder3d_load_weight(ddmi_decoder3d* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_decoder3d_finalize(ddmi_decoder3d* h);
+int ddmi_decoder3d_num_scales(ddmi_decoder3d* h, int* n, int plane_hw[4]);
+int ddmi_decoder3d_forward(ddmi_decoder3d* h, const float* z, void* const* planes, int layout, int B, void* stream);
+int ddmi_decoder3d_destroy(ddmi_decoder3d* h);
+/* Fused tri-plane sampling + occupancy MLP: replaces MLP3D.forward (models/d2c_vae/mlp.py:82-111): sample_plane_feature
+ * + normalize_coordinate (utils/general_utils.py:71-119), triplane_positional_encoding(mode='add') (:126-131, bilinear,
+ * align_corners=True, border) at 3 scales, net_p + 4 ResnetBlockFC (blocks.py:673-716) + net_out.
+ * points [B,N,3] fp32; logits_out [B,N] fp32 (the Bernoulli logits the reference wraps in dist.Bernoulli). */
+typedef struct ddmi_mlp3d ddmi_mlp3d;
+int ddmi_mlp3d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp3d** out);   /* in_ch 3, out_ch 1, ch 256, latent_dim 64 */
+int ddmi_mlp3d_load_weight(ddmi_mlp3d* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_mlp3d_finalize(ddmi_mlp3d* h);
+int ddmi_hdpe_mlp3d(ddmi_mlp3d* h, const void* const* planes, const int* plane_hw, int layout, const float* points,
+                    float* logits_out, int B, int N, void* stream);
+int ddmi_mlp3d_destroy(ddmi_mlp3d* h);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Diagnostic single-op entry points (used by the parity tests; reference-layout tensors in, reference-layout
  * tensors out; they allocate temporaries and synchronise - not for the hot path).
  * --------------------------------------------------------------------------------------------------------- */
