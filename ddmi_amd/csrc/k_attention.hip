@@ -126,20 +126,20 @@ __global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int kg = kt * ATT_KT + 16 * f + 4 * lg + j;
-        float v = kg < T_len ? sc[f][j] * scale : -INFINITY;
+        float v = kg < T_len ? sc[f][j] * (IS_BF16 ? scale * 1.44269504088896341f : scale) : -INFINITY;
         sc[f][j] = v;
         tmax = fmaxf(tmax, v);
       }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     float m_new = fmaxf(m_run, tmax);
-    float alpha = expf(m_run - m_new);
+    float alpha = IS_BF16 ? __builtin_amdgcn_exp2f(m_run - m_new) : expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float p = expf(sc[f][j] - m_new);
+        float p = IS_BF16 ? __builtin_amdgcn_exp2f(sc[f][j] - m_new) : expf(sc[f][j] - m_new);
         sc[f][j] = p;
         psum += p;
       }
