@@ -67,12 +67,18 @@ def pmc_traffic(live_name):
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied)."""
     import glob
     import re
-    m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)>", live_name or "")
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not m or not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not files or not live_name:
         return None
-    bm, bn, kk, nst = (int(v) for v in m.groups())
-    pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}>")
+    m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)>", live_name)
+    m2 = re.match(r"conv_(pipe|halo)<bf16,(\d+)x(\d+)>", live_name)
+    if m:
+        bm, bn, kk, nst = (int(v) for v in m.groups())
+        pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}>")
+    elif m2:
+        pat = re.compile(rf"conv_{m2.group(1)}_kernel<{m2.group(2)}, {m2.group(3)}, ")
+    else:
+        return None
     with open(files[-1]) as f:
         table = json.load(f)["kernels"]
     for name, v in table.items():
