@@ -88,6 +88,7 @@ SYMBOLS = {
     "ddmi_mlp3d_destroy": (_I, [_VP]),
     "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
+    "ddmi_debug_conv_config": (_I, [_I]),
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),
     "ddmi_op_attention_legacy": (_I, [_VP, _VP, _I, _I, _I, _I]),
     "ddmi_op_timestep_embedding": (_I, [_VP, _VP, _I, _I]),

@@ -365,6 +365,12 @@ int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, i
   return DDMI_OK;
 }
 
+int ddmi_debug_conv_config(int cfg_id) {
+  if (cfg_id < 0) conv_force_tile(0, 0);
+  else conv_force_tile(cfg_id, -1);
+  return DDMI_OK;
+}
+
 int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
                       int silu, int numerics) {
   int dt;

@@ -502,6 +502,164 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
 }
 
+// =====================================================================================================
+// bf16 production kernel v3 ("halo") for 3x3 / stride 1 / pad 1 convolutions on W in {16, 32, 64}.
+//
+// PMC counters of the pipe kernel: 456 MB fetched per launch against 70 MB of algorithmic reads - the nine taps re-read
+// every activation row and L2 does not absorb it.  Here a 256-pixel tile = TR whole rows of one sample, and for each
+// 64-channel block its (TR+2) x (W+2) HALO is staged in LDS once (zero-filled outside the image by out-of-range DMA
+// offsets); the nine taps of that block then read their A fragments from the halo at shifted rows, so only the
+// weight stage streams per tap.  Activation traffic per 64-channel block: 396 rows instead of 9 x 256.
+//   LDS: 2 halo buffers (400 x 128 B) + 2 weight stages (BN x 128 B) = 156 KiB at BN = 224.
+//   The halo of block cb+1 is fetched in eight pieces behind the barriers of taps 0..7 of block cb.
+// Loop structure, fragment double-buffering and the swizzle are those of the pipe kernel.
+// =====================================================================================================
+#define HALO_MAX_ROWS 400  // 6 x 66 = 396 rows at W = 64, rounded up to whole 8-row DMA groups (the tail lanes write zeros)
+template <int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
+  using T = bf16_t;
+  constexpr int BM = 256, NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(TM % 16 == 0 && TN % 16 == 0 && (TN / 2) % 8 == 0 && NW % 2 == 0, "bad tile");
+  constexpr int GB = BN / 8, B_PER = (GB + NW - 1) / NW;
+  constexpr int ROWB = 128, SZ = 2;
+  constexpr int H_BYTES = HALO_MAX_ROWS * ROWB, B_BYTES = BN * ROWB;
+  unsigned char* const smem_base = nullptr;
+  (void)smem_base;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const HB = smem;                 // [2][H_BYTES]
+  unsigned char* const BB = smem + 2 * H_BYTES;   // [2][B_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int W = a.Win, H = a.Hin, hw = H * W;
+  const int Ktot = 9 * a.Cin;
+  const int NCB = (a.Cin + 63) >> 6;
+  const int TR = BM / W, HWd = W + 2, NH = (TR + 2) * HWd, GH = (NH + 7) >> 3;
+  const int b_first = m0 / hw;
+  const int ty0 = (m0 - b_first * hw) / W;
+
+  const T* xg = (const T*)a.x + (int64_t)b_first * hw * a.Cin;
+  const T* wg = (const T*)a.w;
+  const uint64_t x_rem = a.x_bytes - (uint64_t)b_first * hw * a.Cin * sizeof(T);
+  const unsigned x_extent = x_rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)x_rem;
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_extent, 0x00020000);
+  auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  // weight rows: lane owns physical slot lane&7 of row (lane>>3) of its 8-row group; one channel offset per lane
+  const int coff = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 8;
+  const int b_row0 = wave * 8 + (lane >> 3);             // group i adds 8*NW rows (a scalar step)
+  const int b_base0 = ((n0 + b_row0) * Ktot + coff) * SZ;
+  // halo group g: 8 halo rows hr = 8g + (lane>>3); the slot swizzle depends on hr, so the channel offset does too
+  auto load_halo_group = [&](int g, int cb, int hbuf) {
+    const int hr = g * 8 + (lane >> 3);
+    const int hy = hr / HWd, hx = hr - hy * HWd;
+    const int iy = ty0 - 1 + hy, ix = hx - 1;
+    const int ch = cb * 64 + (((lane & 7) ^ ((hr >> 1) & 7)) << 3);
+    const int ok = (hr < NH) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W) & (ch < a.Cin);
+    const unsigned voff = ok ? (unsigned)(((iy * W + ix) * a.Cin + ch) * SZ) : OOB_OFFSET;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
+  };
+  auto load_b_stage = [&](int cb, int tap, int bbuf, bool valid) {
+    const int c0 = cb * 64;
+    const int cvalid = valid & (c0 + coff < a.Cin);
+    const int delta = (tap * a.Cin + c0) * SZ;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int g = i * NW + wave;
+      if (g < GB) {
+        int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + b_row0 + i * 8 * NW < a.Cout);
+        unsigned voff = ok ? (unsigned)(b_base0 + i * 8 * NW * Ktot * SZ + delta) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(BB + bbuf * B_BYTES + g * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  const int lr = lane & 15, lg = lane >> 4;
+  // A fragments: tile-local pixel m = wm*TM + 16 i + lr -> halo row of tap (0,0); 16 consecutive pixels share a row
+  // fragment i sits 16 i pixels further: + 16 i halo rows and + 2 per image row crossed (scalar, W >= 16)
+  int hr00;
+  {
+    int m = wm * TM + lr;
+    int ty = m / W, tx = m - ty * W;
+    hr00 = ty * HWd + tx;
+  }
+  const int woff0 = (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
+  // `shift` = kh*(W+2) + kw moves every A fragment to the tap's halo row; it stays a loop-carried scalar so the
+  // per-fragment swizzle (5 VALU) is recomputed per stage instead of being hoisted into ~70 loop-invariant VGPRs
+  auto read_frags = [&](int hbuf, int bbuf, int shift, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+    const unsigned char* ph = HB + hbuf * H_BYTES;
+    const int vb = hr00 + shift;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      int hr = vb + i * 16 + ((i * 16) / W) * 2;
+      xf[i] = *reinterpret_cast<const bf16x8*>(ph + ((hr * ROWB + ((lg ^ ((hr >> 1) & 7)) << 4)) ^ (c << 6)));
+    }
+    const unsigned char* pw = BB + bbuf * B_BYTES + (woff0 ^ (c << 6));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+  };
+
+  // split-K: whole 64-channel blocks per split (SPS is a multiple of 9)
+  const int cb_begin = (blockIdx.z * a.SPS) / 9;
+  const int cb_end = min(NCB, cb_begin + a.SPS / 9);
+  const int nstage = (cb_end - cb_begin) * 9;
+  bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+
+  if (nstage > 0) {
+    for (int g = wave; g < GH; g += NW) load_halo_group(g, cb_begin, 0);
+    load_b_stage(cb_begin, 0, 0, true);
+    load_b_stage(cb_begin, 1, 1, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0, 0, xa, wa);
+  }
+  // one flat stage loop; (cb, tap, kw, shift, hbuf) are scalar state so nothing per-tap gets unrolled or hoisted
+  int cb = cb_begin, tap = 0, kw = 0, shift = 0, hbuf = 0;
+#pragma unroll 1
+  for (int st = 0; st < nstage; ++st) {
+    const int bbuf = st & 1;
+    const bool c1 = cb * 64 + 32 < a.Cin;
+    // [A] chunk 0 of this stage on set a, prefetch chunk 1 into set b
+    read_frags(hbuf, bbuf, shift, 1, xb, wb);
+    mma(xa, wa);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // next weight stage + halo pieces issued a stage ago have landed; BB[bbuf] is free
+    {  // refill right behind the barrier (issuing later - e.g. staggering the two waves of a SIMD - measured 10 % slower:
+       // the pieces then land after the next barrier's vmcnt(0)): weight stage st+2 into BB[bbuf], one halo piece
+      int t2 = tap + 2, cb2 = cb;
+      if (t2 >= 9) { t2 -= 9; ++cb2; }
+      load_b_stage(cb2, t2, bbuf, cb2 < cb_end);
+      const int q = tap * NW + wave;
+      if (tap < 8 && q < GH && cb + 1 < cb_end) load_halo_group(q, cb + 1, hbuf ^ 1);
+    }
+    // advance the scalar state to the next stage
+    ++tap;
+    if (++kw == 3) { kw = 0; shift += HWd - 2; } else { ++shift; }
+    if (tap == 9) { tap = 0; shift = 0; ++cb; hbuf ^= 1; }
+    // [B] chunk 1 on set b, prefetch chunk 0 of the next stage into set a
+    if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, 0, xa, wa);
+    if (c1) mma(xb, wb);
+  }
+  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int KPS>
 __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
   using TL = Tile<T>;
@@ -782,7 +940,14 @@ static const RingCfg kRing[] = {
     {256, 128, -1},  // 16: pipe<256,128,4,2> 8 waves, per-wave 64x64,  104 KB
     {128, 128, -1},  // 17: pipe<128,128,2,2> 4 waves, per-wave 64x64,   68 KB
     {128, 64, -1},   // 18: pipe<128, 64,2,1> 2 waves, per-wave 64x64,   50 KB
+    {256, 224, -2},  // 19: halo<224,4,2> 8 waves, per-wave 64x112, 155 KB  (kps -2: halo kernel, 3x3 s1 p1, W in 16..64)
+    {256, 128, -2},  // 20: halo<128,4,2> 8 waves, per-wave 64x64,  131 KB
 };
+static bool halo_ok(const ConvArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hin == a.Win &&
+         (a.Win == 16 || a.Win == 32 || a.Win == 64) && (a.Hin * a.Win) % 256 == 0 && a.Hout == a.Hin && a.Wout == a.Win;
+}
+static const int kHaloFallback = 13;
 static const int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 struct TileCfg { int bm, bn, kps, id; };  // id < 0: fp32 kernel tile
 static int g_force_bm = 0, g_force_bn = 0;  // diagnostics (ddmi_bench_conv): bn == -1 -> bm is a ring config id
@@ -827,7 +992,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.CPT = cdiv(a.Cin, 32);
   k.NK = k.CPT * a.KH * a.KW;
   k.NS = kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(k.NK, kps);
-  k.SPS = cdiv(k.NS, splitk);
+  k.SPS = kps == -2 ? 9 * cdiv(cdiv(a.Cin, 64), splitk) : cdiv(k.NS, splitk);  // halo: whole channel blocks per split
   k.out_scale = a.out_scale;
   static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
   k.dbg = dbg;
@@ -932,6 +1097,30 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
   return DDMI_OK;
 }
 
+template <int BN, int WM, int WN>
+static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
+  constexpr int lds = 2 * HALO_MAX_ROWS * 128 + 2 * BN * 128;
+  static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
+  DDMI_REQUIRE(batch == 1, "halo kernel: no batched-GEMM mode");
+  k.tiles_n = cdiv(k.Cout, BN);
+  dim3 grid(cdiv(k.M, 256) * k.tiles_n, 1, splitk);
+  auto kern = conv_halo_kernel<BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  {
+    double flops, bytes;
+    conv_work(k, 1, 2, &flops, &bytes);
+    static const std::string name = "conv_halo<bf16,256x" + std::to_string(BN) + ">";
+    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hipStream_t s) {
   if (dt == DT_BF16) {
     switch (t.id) {
@@ -954,6 +1143,8 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 16: return launch_pipe<256, 128, 4, 2>(k, splitk, batch, s);
       case 17: return launch_pipe<128, 128, 2, 2>(k, splitk, batch, s);
       case 18: return launch_pipe<128, 64, 2, 1>(k, splitk, batch, s);
+      case 19: return launch_halo<224, 4, 2>(k, splitk, batch, s);
+      case 20: return launch_halo<128, 4, 2>(k, splitk, batch, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -986,6 +1177,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   DDMI_REQUIRE(splitk == 1 || a.splitk_ws, "conv: split-K needs a workspace");
   int M = a.B * a.Hout * a.Wout;
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
+  if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
   k.chan_major = a.order == 2 || (a.order == 0 && a.KH * a.KW > 1 && splitk == 1);
@@ -1039,6 +1231,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int id = 0; id < kNumRing; ++id) {
     const RingCfg& rc = kRing[id];
+    if (rc.kps == -2 && !halo_ok(a0)) continue;
     // prune: tile width must fit Cout without more than ~15 % padding; tile height not larger than 2x the problem
     int padded = cdiv(a0.Cout, rc.bn) * rc.bn;
     if (padded * 100 > a0.Cout * 115 && !(a0.Cout <= 64 && rc.bn == 64)) continue;
@@ -1047,8 +1240,9 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     int NS = rc.kps < 0 ? cdiv(a0.Cin, 64) * a0.KH * a0.KW : cdiv(cdiv(a0.Cin, 32) * a0.KH * a0.KW, rc.kps);
     for (int sk : kSplits) {
       if (sk > 1 && (tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
+      if (rc.kps == -2 && sk > cdiv(a0.Cin, 64)) continue;
       if ((size_t)sk * M * a0.Cout * sizeof(float) > ws_bytes && sk > 1) continue;
-      for (int order = 1; order <= (a0.KH * a0.KW > 1 ? 2 : 1); ++order) {
+      for (int order = 1; order <= ((a0.KH * a0.KW > 1 && rc.kps != -2) ? 2 : 1); ++order) {
         ConvArgs a = a0;
         a.cfg = id + 1; a.order = order; a.splitk = sk; a.splitk_ws = ws;
         int rc2 = DDMI_OK;

@@ -178,6 +178,10 @@ int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, 
  * force_bm/force_bn = 0 lets the library pick the tile; splitk = 0 lets it pick the split */
 int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, int upsample, int numerics, int splitk,
                     int force_bm, int force_bn, int iters, double* ms_out, int* splitk_used);
+/* diagnostics: pin the bf16 convolution kernel variant (index into k_conv.hip's kRing table) used by the following
+ * ddmi_op_conv2d calls of this process, so each variant can be parity-tested on its own; cfg_id < 0 restores the
+ * library's choice.  A variant that does not apply to a shape (the halo kernel outside 3x3/stride 1) falls back. */
+int ddmi_debug_conv_config(int cfg_id);
 /* GroupNorm(32 groups, eps) [+ SiLU] over [B,C,HW] */
 int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
                       int silu, int numerics);

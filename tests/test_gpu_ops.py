@@ -91,6 +91,47 @@ def test_conv2d_is_linear_at_full_size():
     assert rel_err(conv_op(x1, w, z, numerics="bf16"), ref) < 1.5e-2
 
 
+# every bf16 kernel variant the autotuner may pick (k_conv.hip kRing ids: ring 0-12, pipe 13-18, halo 19-20), pinned
+# one at a time on shapes that cover: halo-eligible W = 16 / 32 / 64, a Cin that is not a multiple of 64 (half-filled
+# last stage), a Cout tail, several samples per launch and split-K over whole channel blocks.
+VARIANT_CASES = [
+    (2, 224, 16, 16, 224, 3, 1, 0),
+    (1, 96, 32, 32, 160, 3, 1, 0),
+    (1, 192, 64, 64, 224, 3, 1, 0),
+    (2, 448, 8, 8, 224, 1, 1, 0),
+]
+_variant_cache = {}
+
+
+def _variant_case(case):
+    if case not in _variant_cache:
+        B, Cin, H, W, Cout, k, stride, ups = case
+        tag = "convv%s" % (case,)
+        x = iw.normal(tag, "x", (B, Cin, H, W))
+        w = iw.normal(tag, "w", (Cout, Cin, k, k), 0.0, 1.0 / math.sqrt(Cin * k * k))
+        b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+        ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=k // 2)
+        _variant_cache[case] = (x, w, b, ref)
+    return _variant_cache[case]
+
+
+@pytest.mark.parametrize("cfg", list(range(21)))
+def test_conv2d_every_bf16_variant(cfg):
+    L = _lib.lib()
+    try:
+        for case in VARIANT_CASES:
+            B, Cin, H, W, Cout, k, stride, ups = case
+            x, w, b, ref = _variant_case(case)
+            for splitk in (0, 2):
+                _lib.check(L.ddmi_debug_conv_config(cfg))
+                got = conv_op(x, w, b, stride, ups, "bf16", splitk)
+                assert rel_err(got, ref) < 1.5e-2, (cfg, case, splitk)
+                # a few corrupted pixels or channels hide in an RMS figure; bound the worst element as well
+                assert float((got - ref).abs().max()) < 0.03 * float(ref.abs().max()), (cfg, case, splitk)
+    finally:
+        L.ddmi_debug_conv_config(-1)
+
+
 def gn_op(x, g, b, eps, silu, numerics):
     L = _lib.lib()
     _lib.init_device(0)
