@@ -661,3 +661,244 @@ def vae3d_decode(p: State, ddconfig: Mapping, embed_dim: int, z: Tensor):
         h = silu(group_norm(h, p[d + "norm_out.weight"], p[d + "norm_out.bias"], 1e-6))
         outs[i].append(F.conv2d(h, p[d + "conv_out.weight"], p[d + "conv_out.bias"], padding=1))
     return tuple(outs)  # (xy, yz, xz)
+
+
+# ======================================================================================
+# a14, a17, a22  video path: tri-plane UNet, VideoDecoder_light, MLPVideo
+#
+# Third-party arithmetic absent from the reference tree: `xformers.ops.memory_efficient_attention`
+# (unpinned, README.md:33).  Its published semantics for 3-D inputs [batch*heads, tokens, dim] with
+# attn_bias=None are softmax(q k^T / sqrt(dim)) v, restated in `sdpa_heads` below.  The reference needs
+# xformers for the video configuration anyway ('vanilla-1d-multihead-expand' raises without it, ae:596-600),
+# so these semantics - not the C^-1/2 scale of the no-xformers fallback AttnBlock1d (ae:259) - are canonical.
+# ======================================================================================
+
+def sdpa_heads(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
+    """q, k, v [B, heads*d, N] with channel = head*d + j (ae:447-456): per head softmax(q k^T / sqrt(d)) v -> [B, heads*d, N]."""
+    B, HD, N = q.shape
+    d = HD // heads
+    qh = q.reshape(B, heads, d, N).permute(0, 1, 3, 2)  # [B,H,N,d]
+    kh = k.reshape(B, heads, d, N)
+    vh = v.reshape(B, heads, d, N).permute(0, 1, 3, 2)
+    w = torch.softmax(torch.matmul(qh, kh) * (d ** -0.5), dim=-1)  # [B,H,Nq,Nk]
+    o = torch.matmul(w, vh)  # [B,H,N,d]
+    return o.permute(0, 1, 3, 2).reshape(B, HD, N)
+
+
+def attn_block_1d(p: State, pre: str, x: Tensor, heads: int, expand: bool) -> Tensor:
+    """MemoryEfficientAttnBlock1D (ae:404-468, heads of C/heads channels) and ..._expand (ae:470-534, q/k/v project
+    C -> heads*C, head dim C) over a token sequence x [B,C,N]; GroupNorm eps 1e-6 (ae:46-47)."""
+    hn = group_norm(x, p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-6)
+    q = F.conv1d(hn, p[pre + "q.weight"], p[pre + "q.bias"])
+    k = F.conv1d(hn, p[pre + "k.weight"], p[pre + "k.bias"])
+    v = F.conv1d(hn, p[pre + "v.weight"], p[pre + "v.bias"])
+    assert q.shape[1] == (x.shape[1] * heads if expand else x.shape[1])
+    o = sdpa_heads(q, k, v, heads)
+    return x + F.conv1d(o, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
+
+
+def cat_planes(h_xy: Tensor, h_xt: Tensor, h_yt: Tensor) -> Tensor:
+    """openai:1148-1152: token order xy | xt | yt."""
+    b, c = h_xy.shape[:2]
+    return torch.cat([h_xy.reshape(b, c, -1), h_xt.reshape(b, c, -1), h_yt.reshape(b, c, -1)], dim=-1)
+
+
+def split_planes(h: Tensor, res_h: int, res_w: int, t: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """openai:1155-1157 / ae:1073-1075: xy [res_h,res_w], xt [t,res_w], yt [t,res_w] views of the token axis."""
+    b, c = h.shape[:2]
+    n_xy, n_t = res_h * res_w, t * res_w
+    return (h[:, :, :n_xy].reshape(b, c, res_h, res_w), h[:, :, n_xy:n_xy + n_t].reshape(b, c, t, res_w),
+            h[:, :, n_xy + n_t:n_xy + 2 * n_t].reshape(b, c, t, res_w))
+
+
+def unet_triplane_forward(p: State, cfg: Mapping, x: Tensor, t: Tensor) -> Tensor:
+    """UNetModel_Triplane.forward openai:1113-1221: the UNetModel blocks applied to the three planes with shared
+    weights, and a 16-head 1-D attention over the concatenated tokens after every block
+    (make_attn('vanilla-1d-multihead'), openai:955-957,1023,1082).  x [B, C, s1*s2 + s1*s3 + s2*s3]."""
+    x = _t(x)
+    nhc = cfg["num_head_channels"]
+    s1, s2, s3 = cfg["size1"], cfg["size2"], cfg["size3"]
+    inputs, outputs, _ = unet_topology(cfg)
+    emb = timestep_embedding(t, cfg["model_channels"])
+    emb = F.linear(silu(F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])),
+                   p["time_embed.2.weight"], p["time_embed.2.bias"])
+
+    def run(layers, pre, h):
+        for j, (kind, cin, cout) in enumerate(layers):
+            q = f"{pre}{j}."
+            if kind == "conv_in":
+                h = F.conv2d(h, p[q + "weight"], p[q + "bias"], padding=1)
+            elif kind == "res":
+                h = unet_resblock(p, q, h, emb)
+            elif kind == "attn":
+                h = unet_attnblock(p, q, h, nhc)
+            elif kind == "down":
+                h = F.conv2d(h, p[q + "op.weight"], p[q + "op.bias"], stride=2, padding=1)
+            elif kind == "up":
+                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                h = F.conv2d(h, p[q + "conv.weight"], p[q + "conv.bias"], padding=1)
+        return h
+
+    def inter(pre, hs):
+        if (pre + "norm.weight") not in p:  # input_attns[0] is nn.Identity (openai:912)
+            return hs
+        h_xy, h_xt, h_yt = hs
+        res_h, res_w, tt = h_xy.shape[-2], h_xy.shape[-1], h_xt.shape[-2]
+        return split_planes(attn_block_1d(p, pre, cat_planes(h_xy, h_xt, h_yt), 16, False), res_h, res_w, tt)
+
+    n_xy = s1 * s2
+    hs = (x[:, :, :n_xy].reshape(x.shape[0], x.shape[1], s1, s2),
+          x[:, :, n_xy:n_xy + s1 * s3].reshape(x.shape[0], x.shape[1], s3, s1),
+          x[:, :, n_xy + s1 * s3:n_xy + s1 * s3 + s2 * s3].reshape(x.shape[0], x.shape[1], s3, s2))
+    skips = []
+    for i, layers in enumerate(inputs):
+        hs = tuple(run(layers, f"input_blocks.{i}.", h) for h in hs)
+        hs = inter(f"input_attns.{i}.", hs)
+        skips.append(hs)
+    hs = tuple(run([("res", 0, 0), ("attn", 0, 0), ("res", 0, 0)], "middle_block.", h) for h in hs)
+    hs = inter("mid_attn.", hs)
+    for i, layers in enumerate(outputs):
+        sk = skips.pop()
+        hs = tuple(run(layers, f"output_blocks.{i}.", torch.cat([h, s], dim=1)) for h, s in zip(hs, sk))
+        hs = inter(f"output_attns.{i}.", hs)
+    outs = [F.conv2d(silu(group_norm(h, p["out.0.weight"], p["out.0.bias"], 1e-5)), p["out.2.weight"], p["out.2.bias"],
+                     padding=1) for h in hs]
+    return cat_planes(*outs)
+
+
+def vae_attn_block_mh(p: State, pre: str, x: Tensor, heads: int) -> Tensor:
+    """MemoryEfficientAttnBlock (ae:273-335) on one plane: `heads` heads of C/heads channels (make_attn
+    'vanilla-multihead' -> 16 heads, ae:568-573)."""
+    b, c, hh, ww = x.shape
+    hn = group_norm(x, p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-6)
+    q = F.conv2d(hn, p[pre + "q.weight"], p[pre + "q.bias"]).reshape(b, c, -1)
+    k = F.conv2d(hn, p[pre + "k.weight"], p[pre + "k.bias"]).reshape(b, c, -1)
+    v = F.conv2d(hn, p[pre + "v.weight"], p[pre + "v.bias"]).reshape(b, c, -1)
+    o = sdpa_heads(q, k, v, heads).reshape(b, c, hh, ww)
+    return x + F.conv2d(o, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
+
+
+_ATTN_HEADS = {"vanilla": 1, "vanilla-multihead": 16}
+
+
+def video_decoder(p: State, ddconfig: Mapping, z_xy: Tensor, z_yt: Tensor, z_xt: Tensor, pre: str = "decoder."):
+    """VideoDecoder_light.forward ae:1040-1144.  Returns (xy, yt, xt), each the list of HDBF planes coarse -> fine;
+    xy planes [res,res], yt / xt planes [t,res] (t is never upsampled, ae:1115-1118)."""
+    ch_mult = list(ddconfig["ch_mult"])
+    nres, nrb = len(ch_mult), ddconfig["num_res_blocks"]
+    attn_res = set(ddconfig.get("attn_resolutions", []))
+    hdbf_res = set(ddconfig["hdbf_resolutions"])
+    inter_res = set(ddconfig["inter_attn_resolutions"])
+    heads = _ATTN_HEADS[ddconfig.get("attn_type", "vanilla")]
+    curr = ddconfig["resolution"] // 2 ** (nres - 1)
+    d = pre
+    hs = [z_xy, z_yt, z_xt]  # the reference's processing order (ae:1051-1069)
+    hs = [F.conv2d(h, p[d + "conv_in.weight"], p[d + "conv_in.bias"], padding=1) for h in hs]
+    hs = [vae_resnet_block(p, d + "mid.block_2.",
+                           vae_attn_block_mh(p, d + "mid.attn_1.", vae_resnet_block(p, d + "mid.block_1.", h), heads))
+          for h in hs]
+
+    def inter(name, hs):
+        h_xy, h_yt, h_xt = hs
+        res_h, res_w, tt = h_xy.shape[-2], h_xy.shape[-1], h_xt.shape[-2]
+        o_xy, o_xt, o_yt = split_planes(attn_block_1d(p, name, cat_planes(h_xy, h_xt, h_yt), 8, True), res_h, res_w, tt)
+        return [o_xy, o_yt, o_xt]
+
+    hs = inter(d + "mid_attn.", hs)
+    out = ([], [], [])
+    for lvl in reversed(range(nres)):
+        for ib in range(nrb + 1):
+            hs = [vae_resnet_block(p, f"{d}up.{lvl}.block.{ib}.", h) for h in hs]
+            if curr in attn_res:
+                hs = [vae_attn_block_mh(p, f"{d}up.{lvl}.attn.{ib}.", h, heads) for h in hs]
+        if curr in inter_res:
+            hs = inter(f"{d}up.{lvl}.inter_attn.0.", hs)
+        if curr in hdbf_res:
+            for o, h in zip(out, hs):
+                o.append(F.conv2d(h, p[f"{d}up.{lvl}.hdbf.0.weight"], p[f"{d}up.{lvl}.hdbf.0.bias"]))
+        if lvl != 0:
+            w_, b_ = p[f"{d}up.{lvl}.upsample.conv.weight"], p[f"{d}up.{lvl}.upsample.conv.bias"]
+            hs = [F.conv2d(F.interpolate(hs[0], scale_factor=2.0, mode="nearest"), w_, b_, padding=1),
+                  F.conv2d(F.interpolate(hs[1], scale_factor=(1.0, 2.0), mode="nearest"), w_, b_, padding=1),
+                  F.conv2d(F.interpolate(hs[2], scale_factor=(1.0, 2.0), mode="nearest"), w_, b_, padding=1)]
+            curr *= 2
+    for o, h in zip(out, hs):
+        h = silu(group_norm(h, p[d + "norm_out.weight"], p[d + "norm_out.bias"], 1e-6))
+        o.append(F.conv2d(h, p[d + "conv_out.weight"], p[d + "conv_out.bias"], padding=1))
+    return out
+
+
+def vit_decode(p: State, ddconfig: Mapping, frames: int, z: Tensor):
+    """VITAutoencoder.decode autoencoder_vit.py:188-202: z [B, C, s*s + 2*s*frames] with s = resolution / 8;
+    xy = [s,s], xt = [frames,s], yt = [frames,s]; per-plane 1x1 post convs; decoder((xy, yt, xt))."""
+    z = _t(z)
+    s = ddconfig["resolution"] // 8
+    xy, xt, yt = split_planes(z, s, s, frames)
+    xy = F.conv2d(xy, p["post_xy.weight"], p["post_xy.bias"])
+    yt = F.conv2d(yt, p["post_yt.weight"], p["post_yt.bias"])
+    xt = F.conv2d(xt, p["post_xt.weight"], p["post_xt.bias"])
+    return video_decoder(p, ddconfig, xy, yt, xt)
+
+
+def coord_grid_3d(h: int, w: int, t: int, hstart=-1.0, hend=1.0, wstart=-1.0, wend=1.0, tstart=-1.0, tend=1.0):
+    """gu:38-52 for b=1: 'xy' = (x along W, y along H) on [h,w]; 'xt' = (t, x) on [t,w]; 'yt' = (t, y) on [t,h]."""
+    xs = torch.from_numpy(linspace_f32(wstart, wend, w))
+    ys = torch.from_numpy(linspace_f32(hstart, hend, h))
+    ts = torch.from_numpy(linspace_f32(tstart, tend, t))
+    return {"xy": torch.stack((xs.view(1, w).expand(h, w), ys.view(h, 1).expand(h, w)))[None],
+            "xt": torch.stack((ts.view(t, 1).expand(t, w), xs.view(1, w).expand(t, w)))[None],
+            "yt": torch.stack((ts.view(t, 1).expand(t, h), ys.view(1, h).expand(t, h)))[None]}
+
+
+def video_coords(res: int, frames: int = 16):
+    """tools/ldm/video.py:216-217 as written there: hstart/hend/wstart = -+(res-1)/res, wend = 255/res, t = -+15/16."""
+    e = (res - 1) / res
+    return coord_grid_3d(res, res, frames, -e, e, -e, 255 / res, -15 / 16, 15 / 16)
+
+
+def triplane_features_concat(xy: Tensor, yt: Tensor, xt: Tensor, coords: Mapping[str, Tensor]) -> Tensor:
+    """gu:134-145 (mode 'concat'): three 2-D bilinear samplings (align_corners=True, border), broadcast to (t,h,w),
+    channel-concatenated; rows ordered (b,t,h,w).  Note the grid's channel 0 is fed to grid_sample's x (plane width)
+    axis, exactly as the reference does.  -> [B*t*h*w, 3C]."""
+    b = xy.shape[0]
+
+    def sample(plane, c):
+        _, _, gh, gw = c.shape
+        g = c.expand(b, -1, -1, -1).reshape(b, 2, gh * gw)
+        return bilinear_border(_t(plane), g[:, 0], g[:, 1], align_corners=True).reshape(b, plane.shape[1], gh, gw)
+
+    x1 = sample(xy, coords["xy"])  # [b,c,h,w]
+    x2 = sample(yt, coords["yt"])  # [b,c,t,h]
+    x3 = sample(xt, coords["xt"])  # [b,c,t,w]
+    c, h, w = x1.shape[1:]
+    t = x2.shape[2]
+    x1 = x1[:, :, None].expand(b, c, t, h, w)
+    x2 = x2[:, :, :, :, None].expand(b, c, t, h, w)
+    x3 = x3[:, :, :, None, :].expand(b, c, t, h, w)
+    x = torch.cat((x1, x2, x3), dim=1).reshape(b, 3 * c, -1)
+    return x.permute(0, 2, 1).reshape(-1, 3 * c)
+
+
+def mlp_video(p: State, coords: Mapping[str, Tensor], hdbf) -> Tensor:
+    """MLPVideo.forward mlp.py:128-157.  hdbf = (xy, yt, xt), each 3 planes coarse -> fine -> [B, out_ch, t, h, w]."""
+    xy, yt, xt = hdbf
+    b, _, h, w = xy[-1].shape
+    t = yt[-1].shape[2]
+    f = [triplane_features_concat(xy[i], yt[i], xt[i], coords) for i in range(3)]
+    x = resnet_block_fc(p, "net_res1.", f[0])
+    x = resnet_block_fc(p, "net_res2.", torch.cat((x, f[1]), dim=1))
+    x = resnet_block_fc(p, "net_res3.", torch.cat((x, f[2]), dim=1))
+    x = resnet_block_fc(p, "net_res4.", x)
+    x = F.linear(F.leaky_relu(x, 0.2), p["net_out.weight"], p["net_out.bias"])
+    oc = x.shape[-1]
+    return x.reshape(b, -1, oc).permute(0, 2, 1).reshape(b, oc, t, h, w)
+
+
+def generate_video(unet_p: State, unet_cfg: Mapping, vae_p: State, ddconfig: Mapping, frames: int, mlp_p: State, sched,
+                   mixing_logit, x_T, noises, timesteps: int, sampling_timesteps: int, eta: float, coords) -> Dict[str, Tensor]:
+    """tools/ldm/video.py:214-230: sample -> VITAutoencoder.decode -> MLPVideo -> clamp."""
+    z = sample_chain(lambda x, t: unet_triplane_forward(unet_p, unet_cfg, x, t), sched, x_T, noises,
+                     timesteps, sampling_timesteps, eta, mixing_logit)
+    hdbf = vit_decode(vae_p, ddconfig, frames, z)
+    vid = mlp_video(mlp_p, coords, hdbf)
+    return {"z": z, "hdbf": hdbf, "video": vid.clamp(-1.0, 1.0)}
