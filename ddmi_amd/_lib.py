@@ -89,6 +89,8 @@ SYMBOLS = {
     "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_debug_conv_config": (_I, [_I]),
+    "ddmi_op_attention_legacy_hd": (_I, [_VP, _VP, _I, _I, _I, _I, _I]),
+    "ddmi_op_attention_mh": (_I, [_VP, _VP, _VP, _VP] + [_I] * 7),
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),
     "ddmi_op_attention_legacy": (_I, [_VP, _VP, _I, _I, _I, _I]),
     "ddmi_op_timestep_embedding": (_I, [_VP, _VP, _I, _I]),

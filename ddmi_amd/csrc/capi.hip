@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 #include "models.h"
+#include <cmath>
 #include "prof.h"
 
 const char* ddmi_error_cstr();
@@ -388,17 +389,77 @@ int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, flo
   return DDMI_OK;
 }
 
-int ddmi_op_attention_legacy(const float* qkv, float* out, int B, int heads, int T, int numerics) {
+int ddmi_op_attention_legacy_hd(const float* qkv, float* out, int B, int heads, int d, int T, int numerics) {
   int dt;
   DDMI_TRY(numerics_to_dt(numerics, &dt));
+  DDMI_REQUIRE(qkv && out && B > 0 && heads > 0 && d > 0 && T > 0, "op_attention_legacy: bad arguments");
   Scratch sc;
   void *qn, *on;
-  int C3 = heads * 96, C = heads * 32;
+  int C3 = heads * 3 * d, C = heads * d;
   DDMI_TRY(sc.get((size_t)B * C3 * T * dt_size(dt), &qn));
   DDMI_TRY(sc.get((size_t)B * C * T * dt_size(dt), &on));
   DDMI_TRY(launch_nchw_to_nhwc(qkv, qn, dt, B, C3, T, 0));
-  DDMI_TRY(launch_attention_legacy(qn, on, dt, B, T, heads, 0));
+  DDMI_TRY(launch_attention_legacy(qn, on, dt, B, T, heads, d, 0));
   DDMI_TRY(launch_nhwc_to_nchw(on, dt, out, B, C, T, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
+int ddmi_op_attention_legacy(const float* qkv, float* out, int B, int heads, int T, int numerics) {
+  return ddmi_op_attention_legacy_hd(qkv, out, B, heads, 32, T, numerics);
+}
+
+int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
+                         int seg0, int seg1, int numerics) {
+  int dt;
+  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  DDMI_REQUIRE(q && k && v && out && B > 0 && heads > 0 && d > 0 && N > 0, "op_attention_mh: bad arguments");
+  DDMI_REQUIRE(seg0 > 0 && seg1 >= 0 && seg0 + seg1 <= N, "op_attention_mh: bad segment lengths");
+  const int C = heads * d, ld = 3 * C, es = (int)dt_size(dt);
+  const int len[3] = {seg0, seg1, N - seg0 - seg1};
+  Scratch sc;
+  void *qn, *kn, *vn, *qk, *qkvn, *on;
+  DDMI_TRY(sc.get((size_t)B * N * C * es, &qn));
+  DDMI_TRY(sc.get((size_t)B * N * C * es, &kn));
+  DDMI_TRY(sc.get((size_t)B * N * C * es, &vn));
+  DDMI_TRY(sc.get((size_t)B * N * 2 * C * es, &qk));
+  DDMI_TRY(sc.get((size_t)B * N * ld * es, &qkvn));
+  DDMI_TRY(sc.get((size_t)B * N * C * es, &on));
+  DDMI_TRY(launch_nchw_to_nhwc(q, qn, dt, B, C, N, 0));
+  DDMI_TRY(launch_nchw_to_nhwc(k, kn, dt, B, C, N, 0));
+  DDMI_TRY(launch_nchw_to_nhwc(v, vn, dt, B, C, N, 0));
+  DDMI_TRY(launch_concat(qn, C, kn, C, qk, dt, (int64_t)B * N, 0));
+  DDMI_TRY(launch_concat(qk, 2 * C, vn, C, qkvn, dt, (int64_t)B * N, 0));
+  // scatter the token rows of every sample into one buffer per segment ([B * len][ld]), as the planes are stored
+  AttnArgs a{};
+  void* oseg[3] = {nullptr, nullptr, nullptr};
+  int off = 0;
+  for (int s3 = 0; s3 < 3; ++s3) {
+    a.seg_len[s3] = len[s3];
+    if (len[s3] == 0) continue;
+    void* buf;
+    DDMI_TRY(sc.get((size_t)B * len[s3] * ld * es, &buf));
+    DDMI_TRY(sc.get((size_t)B * len[s3] * C * es, &oseg[s3]));
+    HIP_TRY(hipMemcpy2DAsync(buf, (size_t)len[s3] * ld * es, (const char*)qkvn + (size_t)off * ld * es, (size_t)N * ld * es,
+                             (size_t)len[s3] * ld * es, B, hipMemcpyDeviceToDevice, 0));
+    a.qkv[s3] = buf;
+    a.out[s3] = oseg[s3];
+    off += len[s3];
+  }
+  a.ld_qkv = ld; a.ld_out = C;
+  a.q_off = 0; a.k_off = C; a.v_off = 2 * C;
+  a.hs_qkv = d; a.hs_out = d;
+  a.d = d; a.heads = heads; a.B = B;
+  a.scale = 1.0f / sqrtf((float)d);
+  DDMI_TRY(launch_attention(a, dt, 0));
+  off = 0;
+  for (int s3 = 0; s3 < 3; ++s3) {
+    if (len[s3] == 0) continue;
+    HIP_TRY(hipMemcpy2DAsync((char*)on + (size_t)off * C * es, (size_t)N * C * es, oseg[s3], (size_t)len[s3] * C * es,
+                             (size_t)len[s3] * C * es, B, hipMemcpyDeviceToDevice, 0));
+    off += len[s3];
+  }
+  DDMI_TRY(launch_nhwc_to_nchw(on, dt, out, B, C, N, 0));
   HIP_TRY(hipDeviceSynchronize());
   return DDMI_OK;
 }

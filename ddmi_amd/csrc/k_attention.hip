@@ -1,132 +1,185 @@
-// Fused self-attention for the LDM UNet's AttentionBlock (openaimodel.py:279-325 + QKVAttentionLegacy :397-422),
-// head dim 32, token-major activations.
+// Fused multi-head self-attention (online softmax, keys / values streamed through LDS), token-major activations.
 //
-//   qkv [B, T, H*96]  (per head: 32 q | 32 k | 32 v channels - the legacy "split heads before qkv" interleave)
-//   out [B, T, H*32]   out[b, t, h*32 + c] = sum_s softmax_s(q_t . k_s / sqrt(32)) v_s[c]
+// One kernel serves every attention on the path:
+//   * LDM UNet AttentionBlock + QKVAttentionLegacy (openaimodel.py:279-325, 397-422): per-head interleaved
+//     [q | k | v] channels, scale d^-1/4 on q and k = d^-1/2 on the scores
+//   * the video path's MemoryEfficientAttnBlock / ...1D / ...1D_expand (autoencoder_unet.py:273-335, 404-534; xformers
+//     semantics softmax(q k^T / sqrt(d)) v): blocked [q heads | k heads | v heads] channels, and the token sequence
+//     of one sample is the CONCATENATION of up to three row ranges (xy | xt | yt planes, openaimodel.py:1148-1157)
+//     that live in different tensors - `seg_len` / the three base pointers describe that row map, nothing is copied.
 //
-// One workgroup = 4 waves = 64 queries of one (b, head); keys/values stream through LDS in tiles of 64 with an
-// online softmax.  Everything is arranged so the QUERY sits on the MFMA lane (lane & 15):
+// One workgroup = 4 waves = 64 queries of one (sample, head[, slice of the value channels]).  Everything is arranged
+// so the QUERY sits on the MFMA lane (lane & 15):
 //   S^T = K . Q^T     A-operand = K tile rows (keys) from LDS, B-operand = Q rows (registers, loaded once)
 //                     -> lane holds scores of its query for keys 16f + 4*(lane>>4) + j  (row-max / row-sum need only
 //                        in-register reductions plus two xor-shuffles over lane>>4)
 //   O^T = V^T . P^T   A-operand = V^T rows (channels) from a transposed LDS image, B-operand = P straight from the
 //                     score registers (key order inside an MFMA k-step is permuted identically on both operands)
 //                     -> lane holds out channels 16*df + 4*(lane>>4) + j of its query: 8/16-byte vector stores.
+// Template: D = head dim rounded up to {32, 64, 128, 256, 512} (channels >= d are zero-filled), DV = value / output
+// channels handled by one workgroup (blockIdx.z walks the slices; S is recomputed per slice), KT = keys per LDS tile.
 // bf16 path: v_mfma_f32_16x16x32_bf16, fp32 softmax/accumulate.  fp32 (parity) path: v_mfma_f32_16x16x4_f32.
 #include "kernels.h"
 #include "prof.h"
 #include <math.h>
 
-#define ATT_D 32
-#define ATT_KT 64   // keys per LDS tile
 #define ATT_QB 64   // queries per workgroup
 
-template <typename T> struct AttL;
-template <> struct AttL<bf16_t> {
-  static constexpr int KROWB = 64;              // K tile row bytes (32 bf16), XOR swizzled like the conv tiles
-  static constexpr int VROWB = (ATT_KT + 4) * 2;  // V^T row bytes (64 keys + 4 pad)
-};
-template <> struct AttL<float> {
-  static constexpr int KROWB = 144;
-  static constexpr int VROWB = (ATT_KT + 4) * 4;
-};
-
-__device__ __forceinline__ int att_swz(int row, int slot) {
-  int r = (row >> 2) & 3;
-  return slot ^ ((0x78 >> (r * 2)) & 3);
+// 16-byte slot swizzle of the bf16 K tile, conflict-free for the four ds_read_b128 lane groups at every row size:
+// 64-byte rows (D = 32): slot ^ {0,2,3,1}[(row>>2)&3];  128-byte rows: slot ^ ((row>>1)&7);  >= 256-byte rows: every
+// row starts on bank 0, so the low four slot bits are XORed with row & 15.
+template <int D> __device__ __forceinline__ int att_swz(int row, int slot) {
+  if constexpr (D == 32) {
+    int r = (row >> 2) & 3;
+    return slot ^ ((0x78 >> (r * 2)) & 3);
+  } else if constexpr (D == 64) {
+    return slot ^ ((row >> 1) & 7);
+  } else {
+    return slot ^ (row & 15);
+  }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restrict__ qkv, T* __restrict__ out, int T_len,
-                                                               int heads, float scale) {
+// row r (0 .. sum seg_len) of sample b -> (segment, row inside that segment's [B * seg_len][ld] matrix)
+__device__ __forceinline__ int64_t att_row(const AttnArgs& a, int b, int n, int* seg) {
+  int s = 0;
+  if (n >= a.seg_len[0]) {
+    n -= a.seg_len[0];
+    s = 1;
+    if (n >= a.seg_len[1]) {
+      n -= a.seg_len[1];
+      s = 2;
+    }
+  }
+  *seg = s;
+  return (int64_t)b * a.seg_len[s] + n;
+}
+
+// VN consecutive channels c0.. of one token row, zero beyond the head dim d; element-wise when the row is not
+// 16-byte aligned (toy head dims 2 / 4)
+template <typename T, int VN, typename V>
+__device__ __forceinline__ V att_load(const T* p, int c0, int d, bool vec_ok) {
+  V v;
+  if (vec_ok && c0 + VN <= d) return *reinterpret_cast<const V*>(p + c0);
+#pragma unroll
+  for (int e = 0; e < VN; ++e) v[e] = c0 + e < d ? p[c0 + e] : (T)0;
+  return v;
+}
+
+template <typename T, int D, int DV, int KT>
+__global__ void __launch_bounds__(256) attention_mh_kernel(AttnArgs a) {
   constexpr bool IS_BF16 = sizeof(T) == 2;
-  constexpr int KROWB = AttL<T>::KROWB, VROWB = AttL<T>::VROWB;
-  __shared__ __attribute__((aligned(16))) unsigned char ks[ATT_KT * KROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char vs[ATT_D * VROWB];
+  constexpr int KROWB = IS_BF16 ? D * 2 : D * 4 + 16;  // fp32 rows padded by one slot
+  constexpr int VROWB = (KT + 4) * (int)sizeof(T);    // V^T row: KT keys + 4 pad
+  constexpr int NF = KT / 16;                          // score fragments per tile
+  constexpr int NDF = DV / 16;                         // output fragments
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  unsigned char* const ks = att_smem;
+  unsigned char* const vs = att_smem + KT * KROWB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
-  const int C3 = heads * 3 * ATT_D;
-  const T* base = qkv + (int64_t)b * T_len * C3 + h * 3 * ATT_D;
+  const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+  const int dv0 = blockIdx.z * DV;
+  const int d = a.d;
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  const bool vec_ok = a.vec_ok != 0;
   const int q_idx = blockIdx.x * ATT_QB + wave * 16 + lr;
-  const bool q_ok = q_idx < T_len;
+  const bool q_ok = q_idx < N;
+  const float sscale = IS_BF16 ? a.scale * 1.44269504088896341f : a.scale;  // bf16 path exponentiates in base 2
 
   // ---- Q fragment(s) in registers --------------------------------------------------------------
-  bf16x8 qb;
-  f32x4 qf[2];
-  if constexpr (IS_BF16) {
-    qb = q_ok ? *reinterpret_cast<const bf16x8*>(base + (int64_t)q_idx * C3 + 8 * lg) : bf16x8{};
-  } else {
+  bf16x8 qb[IS_BF16 ? D / 32 : 1];
+  f32x4 qf[IS_BF16 ? 1 : D / 16];
+  {
+    int seg = 0;
+    int64_t r = att_row(a, b, q_ok ? q_idx : 0, &seg);
+    const T* qp = (const T*)a.qkv[seg] + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
+    if constexpr (IS_BF16) {
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-      qf[hh] = q_ok ? *reinterpret_cast<const f32x4*>(base + (int64_t)q_idx * C3 + 16 * hh + 4 * lg) : f32x4{0, 0, 0, 0};
+      for (int kk = 0; kk < D / 32; ++kk)
+        qb[kk] = q_ok && kk * 32 + 8 * lg < d ? att_load<T, 8, bf16x8>(qp, kk * 32 + 8 * lg, d, vec_ok) : bf16x8{};
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk)
+        qf[kk] = q_ok && kk * 16 + 4 * lg < d ? att_load<T, 4, f32x4>(qp, kk * 16 + 4 * lg, d, vec_ok) : f32x4{0, 0, 0, 0};
+    }
   }
 
   float m_run = -INFINITY, l_run = 0.f;
-  f32x4 o[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+  f32x4 o[NDF];
+#pragma unroll
+  for (int df = 0; df < NDF; ++df) o[df] = f32x4{0, 0, 0, 0};
 
-  const int ntiles = (T_len + ATT_KT - 1) / ATT_KT;
+  const int ntiles = (N + KT - 1) / KT;
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();  // previous tile fully consumed
-    // ---- stage K tile [key][32] and V^T tile [32][key] ---------------------------------------------
-    if constexpr (IS_BF16) {
-      int key = tid >> 2, slot = tid & 3;  // 64 keys x 4 slots of 8 channels
-      int kg = kt * ATT_KT + key;
-      bf16x8 kv = bf16x8{}, vv = bf16x8{};
-      if (kg < T_len) {
-        const T* p = base + (int64_t)kg * C3;
-        kv = *reinterpret_cast<const bf16x8*>(p + ATT_D + 8 * slot);
-        vv = *reinterpret_cast<const bf16x8*>(p + 2 * ATT_D + 8 * slot);
-      }
-      *reinterpret_cast<bf16x8*>(ks + key * KROWB + att_swz(key, slot) * 16) = kv;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(vs + (8 * slot + e) * VROWB + key * 2) = vv[e];
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        int idx = tid + it * 256;
-        int key = idx >> 3, slot = idx & 7;  // 64 keys x 8 slots of 4 channels
-        int kg = kt * ATT_KT + key;
-        f32x4 kv = f32x4{0, 0, 0, 0}, vv = f32x4{0, 0, 0, 0};
-        if (kg < T_len) {
-          const T* p = base + (int64_t)kg * C3;
-          kv = *reinterpret_cast<const f32x4*>(p + ATT_D + 4 * slot);
-          vv = *reinterpret_cast<const f32x4*>(p + 2 * ATT_D + 4 * slot);
+    // ---- stage K tile [key][D] and V^T tile [DV][key] ----------------------------------------------
+    {
+      constexpr int VN = IS_BF16 ? 8 : 4;
+      constexpr int KSL = D / VN, VSL = DV / VN;  // 16-byte slots per key row
+      for (int idx = tid; idx < KT * KSL; idx += 256) {
+        int key = idx / KSL, slot = idx - key * KSL;
+        int kg = kt * KT + key;
+        int seg = 0;
+        int64_t r = att_row(a, b, kg < N ? kg : 0, &seg);
+        const T* kp = (const T*)a.qkv[seg] + r * a.ld_qkv + a.k_off + h * a.hs_qkv;
+        if constexpr (IS_BF16) {
+          bf16x8 kv = kg < N && slot * 8 < d ? att_load<T, 8, bf16x8>(kp, slot * 8, d, vec_ok) : bf16x8{};
+          *reinterpret_cast<bf16x8*>(ks + key * KROWB + att_swz<D>(key, slot) * 16) = kv;
+        } else {
+          f32x4 kv = kg < N && slot * 4 < d ? att_load<T, 4, f32x4>(kp, slot * 4, d, vec_ok) : f32x4{0, 0, 0, 0};
+          *reinterpret_cast<f32x4*>(ks + key * KROWB + slot * 16) = kv;
         }
-        *reinterpret_cast<f32x4*>(ks + key * KROWB + slot * 16) = kv;
+      }
+      for (int idx = tid; idx < KT * VSL; idx += 256) {
+        int key = idx / VSL, slot = idx - key * VSL;
+        int kg = kt * KT + key;
+        int seg = 0;
+        int64_t r = att_row(a, b, kg < N ? kg : 0, &seg);
+        const T* vp = (const T*)a.qkv[seg] + r * a.ld_qkv + a.v_off + h * a.hs_qkv;
+        int c0 = dv0 + slot * VN;
+        if constexpr (IS_BF16) {
+          bf16x8 vv = kg < N && c0 < d ? att_load<T, 8, bf16x8>(vp, c0, d, vec_ok) : bf16x8{};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(vs + (4 * slot + e) * VROWB + key * 4) = vv[e];
+          for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(vs + (8 * slot + e) * VROWB + key * 2) = vv[e];
+        } else {
+          f32x4 vv = kg < N && c0 < d ? att_load<T, 4, f32x4>(vp, c0, d, vec_ok) : f32x4{0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(vs + (4 * slot + e) * VROWB + key * 4) = vv[e];
+        }
       }
     }
     __syncthreads();
 
-    // ---- S^T = K . Q^T : 4 fragments of 16 keys ----------------------------------------------------
-    f32x4 sc[4];
+    // ---- S^T = K . Q^T : NF fragments of 16 keys ---------------------------------------------------
+    f32x4 sc[NF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NF; ++f) {
       sc[f] = f32x4{0, 0, 0, 0};
       int row = 16 * f + lr;
       if constexpr (IS_BF16) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * KROWB + att_swz(row, lg) * 16);
-        sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb, sc[f], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < D / 32; ++kk) {
+          bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * KROWB + att_swz<D>(row, 4 * kk + lg) * 16);
+          sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[kk], sc[f], 0, 0, 0);
+        }
       } else {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4 kf = *reinterpret_cast<const f32x4*>(ks + row * KROWB + (4 * hh + lg) * 16);
+        for (int kk = 0; kk < D / 16; ++kk) {
+          f32x4 kf = *reinterpret_cast<const f32x4*>(ks + row * KROWB + (4 * kk + lg) * 16);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[hh][e], sc[f], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[kk][e], sc[f], 0, 0, 0);
         }
       }
     }
     // ---- online softmax for this lane's query ------------------------------------------------------
     float tmax = -INFINITY;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int kg = kt * ATT_KT + 16 * f + 4 * lg + j;
-        float v = kg < T_len ? sc[f][j] * (IS_BF16 ? scale * 1.44269504088896341f : scale) : -INFINITY;
+        int kg = kt * KT + 16 * f + 4 * lg + j;
+        float v = kg < N ? sc[f][j] * sscale : -INFINITY;
         sc[f][j] = v;
         tmax = fmaxf(tmax, v);
       }
@@ -136,7 +189,7 @@ __global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restri
     float alpha = IS_BF16 ? __builtin_amdgcn_exp2f(m_run - m_new) : expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float p = IS_BF16 ? __builtin_amdgcn_exp2f(sc[f][j] - m_new) : expf(sc[f][j] - m_new);
@@ -147,13 +200,13 @@ __global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restri
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    o[0] *= alpha;
-    o[1] *= alpha;
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) o[df] *= alpha;
 
     // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
     if constexpr (IS_BF16) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {  // k-step u covers keys 32u .. 32u+31 (fragments 2u, 2u+1)
+      for (int u = 0; u < KT / 32; ++u) {  // k-step u covers keys 32u .. 32u+31 (fragments 2u, 2u+1)
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -161,7 +214,7 @@ __global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restri
           pf[4 + j] = (bf16_t)sc[2 * u + 1][j];
         }
 #pragma unroll
-        for (int df = 0; df < 2; ++df) {
+        for (int df = 0; df < NDF; ++df) {
           const unsigned char* vr = vs + (16 * df + lr) * VROWB;
           bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr + (32 * u + 4 * lg) * 2);
           bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + (32 * u + 16 + 4 * lg) * 2);
@@ -176,9 +229,9 @@ __global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restri
       }
     } else {
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int df = 0; df < 2; ++df) {
+        for (int df = 0; df < NDF; ++df) {
           f32x4 vf = *reinterpret_cast<const f32x4*>(vs + (16 * df + lr) * VROWB + (16 * f + 4 * lg) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j], sc[f][j], o[df], 0, 0, 0);
@@ -188,33 +241,87 @@ __global__ void __launch_bounds__(256) attention_legacy_kernel(const T* __restri
 
   if (q_ok) {
     float inv = 1.0f / l_run;
-    T* op = out + ((int64_t)b * T_len + q_idx) * (heads * ATT_D) + h * ATT_D;
+    int seg = 0;
+    int64_t r = att_row(a, b, q_idx, &seg);
+    T* op = (T*)a.out[seg] + r * a.ld_out + h * a.hs_out;
 #pragma unroll
-    for (int df = 0; df < 2; ++df) {
+    for (int df = 0; df < NDF; ++df) {
+      int c0 = dv0 + 16 * df + 4 * lg;
+      if (c0 >= d) continue;
       f32x4 v = o[df] * inv;
-      if constexpr (IS_BF16) {
-        bf16x4 t;
+      if (vec_ok && c0 + 4 <= d) {
+        if constexpr (IS_BF16) {
+          bf16x4 t;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (bf16_t)v[j];
-        *reinterpret_cast<bf16x4*>(op + 16 * df + 4 * lg) = t;
+          for (int j = 0; j < 4; ++j) t[j] = (bf16_t)v[j];
+          *reinterpret_cast<bf16x4*>(op + c0) = t;
+        } else {
+          *reinterpret_cast<f32x4*>(op + c0) = v;
+        }
       } else {
-        *reinterpret_cast<f32x4*>(op + 16 * df + 4 * lg) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < d) op[c0 + j] = (T)v[j];
       }
     }
   }
 }
 
-int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, hipStream_t s) {
-  DDMI_REQUIRE(B > 0 && T > 0 && heads > 0, "attention: bad shape");
-  dim3 grid(cdiv(T, ATT_QB), B * heads);
-  float scale = 1.0f / sqrtf((float)ATT_D);
-  PROF_SCOPE("attention_legacy", 4.0 * B * heads * (double)T * T * ATT_D, 4.0 * B * heads * T * ATT_D * dt_size(dt), s);
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(attention_legacy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, T, heads, scale);
-  else
-    hipLaunchKernelGGL(attention_legacy_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (float*)out, T, heads, scale);
+template <typename T, int D, int DV, int KT>
+static int launch_attention_t(const AttnArgs& a, hipStream_t s) {
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int lds = KT * (IS_BF16 ? D * 2 : D * 4 + 16) + DV * (KT + 4) * (int)sizeof(T);
+  static_assert(lds <= 160 * 1024, "attention tiles exceed the LDS");
+  auto kern = attention_mh_kernel<T, D, DV, KT>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  dim3 grid(cdiv(N, ATT_QB), a.B * a.heads, cdiv(a.d, DV));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
+}
+
+int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
+  AttnArgs a = a_in;
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  DDMI_REQUIRE(a.B > 0 && N > 0 && a.heads > 0 && a.d > 0 && a.d <= 512, "attention: bad shape (head dim must be <= 512)");
+  DDMI_REQUIRE(a.qkv[0] && a.out[0], "attention: null tensor");
+  const int vn = dt == DT_BF16 ? 8 : 4;
+  // 16-byte vector loads / 8-16-byte stores need every row, head and q/k/v block to start on a vector boundary
+  a.vec_ok = (a.d % vn == 0 && a.ld_qkv % vn == 0 && a.hs_qkv % vn == 0 && a.q_off % vn == 0 && a.k_off % vn == 0 &&
+              a.v_off % vn == 0 && a.ld_out % 4 == 0 && a.hs_out % 4 == 0) ? 1 : 0;
+  PROF_SCOPE(a.legacy_name ? "attention_legacy" : "attention_mh", 4.0 * a.B * a.heads * (double)N * N * a.d,
+             4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
+  if (dt == DT_BF16) {
+    if (a.d <= 32) return launch_attention_t<bf16_t, 32, 32, 64>(a, s);
+    if (a.d <= 64) return launch_attention_t<bf16_t, 64, 64, 64>(a, s);
+    if (a.d <= 128) return launch_attention_t<bf16_t, 128, 128, 64>(a, s);
+    if (a.d <= 256) return launch_attention_t<bf16_t, 256, 256, 64>(a, s);
+    return launch_attention_t<bf16_t, 512, 256, 64>(a, s);
+  }
+  if (a.d <= 32) return launch_attention_t<float, 32, 32, 64>(a, s);
+  if (a.d <= 64) return launch_attention_t<float, 64, 64, 64>(a, s);
+  if (a.d <= 128) return launch_attention_t<float, 128, 128, 64>(a, s);
+  if (a.d <= 256) return launch_attention_t<float, 256, 128, 32>(a, s);
+  return launch_attention_t<float, 512, 128, 32>(a, s);
+}
+
+// QKVAttentionLegacy layout: qkv [B, T, heads * 3d] with per-head [q | k | v] channel blocks; out [B, T, heads * d]
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s) {
+  AttnArgs a{};
+  a.qkv[0] = qkv; a.out[0] = out;
+  a.seg_len[0] = T;
+  a.ld_qkv = heads * 3 * d; a.ld_out = heads * d;
+  a.q_off = 0; a.k_off = d; a.v_off = 2 * d;
+  a.hs_qkv = 3 * d; a.hs_out = d;
+  a.d = d; a.heads = heads; a.B = B;
+  a.scale = 1.0f / sqrtf((float)d);  // (d^-1/4 q) . (d^-1/4 k), openaimodel.py:413-416
+  a.legacy_name = 1;
+  return launch_attention(a, dt, s);
 }
 
 // =====================================================================================================

@@ -80,7 +80,22 @@ int launch_transpose_2d(const void* src, void* dst, int dt, int batch, int R, in
 
 // ---- attention (QKVAttentionLegacy layout, head dim 32) -------------------------------------------------
 // qkv [B, T, heads*3*32] (token-major, per-head [q|k|v] channel interleave) -> out [B, T, heads*32]; out += nothing
-int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, hipStream_t s);
+// general form: per (sample, head) softmax(q k^T * scale) v over the concatenation of up to three row ranges
+struct AttnArgs {
+  const void* qkv[3];  // per segment: row 0 of sample 0 of a [B * seg_len][ld_qkv] matrix holding q, k and v
+  void* out[3];        // per segment: [B * seg_len][ld_out]
+  int seg_len[3];      // tokens per sample in each segment (unused segments 0)
+  int ld_qkv, ld_out;  // elements per token row
+  int q_off, k_off, v_off;  // element offset of head 0's q / k / v inside a row
+  int hs_qkv, hs_out;  // head stride inside a row
+  int d;               // head dim (1 .. 512)
+  int heads, B;
+  float scale;
+  int vec_ok;          // filled by launch_attention
+  int legacy_name;     // profiler label only
+};
+int launch_attention(const AttnArgs& a, int dt, hipStream_t s);
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s);
 
 // ---- fused plane sampling + coordinate MLP (image) ------------------------------------------------------
 struct Mlp2dLayer { const void* w; const float* bias; int K; };  // w [256][K] dtype dt (folded), bias [256] fp32

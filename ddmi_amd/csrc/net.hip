@@ -409,7 +409,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
       }
       case OP_ATTN_LEGACY: {
         const TensorDesc& t = tensors[o.out];
-        DDMI_TRY(launch_attention_legacy(tptr(o.in), tptr(o.out), dt, B, t.H * t.W, o.heads, s));
+        DDMI_TRY(launch_attention_legacy(tptr(o.in), tptr(o.out), dt, B, t.H * t.W, o.heads, t.C / o.heads, s));
         break;
       }
       case OP_ATTN_FULL: {

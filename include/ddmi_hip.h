@@ -187,6 +187,14 @@ int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, flo
                       int silu, int numerics);
 /* QKVAttentionLegacy (openaimodel.py:397-422): qkv [B, heads*3*32, T] -> out [B, heads*32, T] */
 int ddmi_op_attention_legacy(const float* qkv, float* out, int B, int heads, int T, int numerics);
+/* same with an explicit head dim (UNetModel_Triplane runs num_head_channels = 64): qkv [B, heads*3*d, T] */
+int ddmi_op_attention_legacy_hd(const float* qkv, float* out, int B, int heads, int d, int T, int numerics);
+/* multi-head attention of the video path's MemoryEfficientAttnBlock* modules (autoencoder_unet.py:273-335, 404-534;
+ * xformers.ops.memory_efficient_attention semantics): q, k, v, out [B, heads*d, N] with channel = head*d + j,
+ * out = softmax(q^T k / sqrt(d)) v per head.  seg0 / seg1 split the N tokens into up to three row ranges that are
+ * held in separate buffers internally (N - seg0 - seg1 is the third), the way the xy | xt | yt planes are. */
+int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
+                         int seg0, int seg1, int numerics);
 /* timestep_embedding (util.py:150-170): t [B] int64 -> [B, dim] */
 int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim);
 

@@ -172,6 +172,52 @@ def attn_op(qkv, heads, numerics):
     return out.cpu()
 
 
+def attn_mh_op(q, k, v, heads, seg0, seg1, numerics):
+    L = _lib.lib()
+    _lib.init_device(0)
+    B, C, N = q.shape
+    qd, kd, vd = _dev(q), _dev(k), _dev(v)
+    out = torch.empty((B, C, N), device=DEV, dtype=torch.float32)
+    _lib.check(L.ddmi_op_attention_mh(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), B, heads, C // heads, N,
+                                      seg0, seg1, _lib.numerics_code(numerics)))
+    return out.cpu()
+
+
+# (B, heads, d, N, seg0, seg1): every head-dim template of the kernel (32 / 64 / 128 / 256 / 512) incl. the padded
+# dims the video UNet produces (16, 96) and the toy dims that take the element-wise path (2, 4); token counts that are
+# not tile multiples; one, two and three row segments with boundaries inside a key tile
+ATTN_MH_CASES = [
+    (2, 16, 2, 128, 64, 32), (1, 16, 4, 48, 16, 16), (2, 4, 16, 200, 200, 0), (1, 3, 32, 130, 100, 30),
+    (1, 2, 64, 333, 111, 111), (1, 2, 96, 96, 64, 16), (1, 2, 128, 257, 257, 0), (1, 1, 256, 150, 50, 50),
+    (1, 2, 512, 192, 64, 64),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_MH_CASES)
+def test_attention_multihead_segments(case):
+    B, heads, d, N, seg0, seg1 = case
+    tag = "attmh%s" % (case,)
+    q = iw.normal(tag, "q", (B, heads * d, N), 0.0, 1.2)
+    k = iw.normal(tag, "k", (B, heads * d, N), 0.0, 1.2)
+    v = iw.normal(tag, "v", (B, heads * d, N))
+    q[0, 0:d, N // 3] *= 3.0  # running-max jump mid-sequence
+    ref = O.sdpa_heads(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), heads)
+    assert rel_err(attn_mh_op(q, k, v, heads, seg0, seg1, "fp32"), ref) < 2e-5
+    assert rel_err(attn_mh_op(q, k, v, heads, seg0, seg1, "bf16"), ref) < 8e-2
+
+
+@pytest.mark.parametrize("d", [16, 64])
+def test_attention_legacy_other_head_dims(d):
+    heads, T = 3, 150
+    qkv = iw.normal("attl%d" % d, "qkv", (2, heads * 3 * d, T), 0.0, 1.2)
+    ref = O.qkv_attention_legacy(torch.from_numpy(qkv), heads)
+    L = _lib.lib()
+    for numerics, tol in (("fp32", 2e-5), ("bf16", 8e-2)):
+        out = torch.empty((2, heads * d, T), device=DEV, dtype=torch.float32)
+        _lib.check(L.ddmi_op_attention_legacy_hd(_dev(qkv).data_ptr(), out.data_ptr(), 2, heads, d, T, _lib.numerics_code(numerics)))
+        assert rel_err(out.cpu(), ref) < tol
+
+
 def test_attention_golden(golden):
     u1 = golden.npz("U1_unet_ops.npz")
     assert rel_err(attn_op(u1["qkv"], 2, "fp32"), u1["attn_legacy"]) < 2e-5
