@@ -37,6 +37,14 @@ class Decoder2dCfg(C.Structure):
                 ("numerics", C.c_int)]
 
 
+class DecoderVCfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("z_channels", C.c_int), ("resolution", C.c_int), ("frames", C.c_int),
+                ("ch", C.c_int), ("num_res_blocks", C.c_int), ("n_mult", C.c_int), ("ch_mult", C.c_int * 8),
+                ("n_attn", C.c_int), ("attn_resolutions", C.c_int * 8), ("n_hdbf", C.c_int),
+                ("hdbf_resolutions", C.c_int * 8), ("n_inter", C.c_int), ("inter_attn_resolutions", C.c_int * 8),
+                ("attn_heads", C.c_int), ("max_batch", C.c_int), ("numerics", C.c_int)]
+
+
 class Mlp2dCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("ch", C.c_int), ("latent_dim", C.c_int),
                 ("numerics", C.c_int)]
@@ -86,6 +94,18 @@ SYMBOLS = {
     "ddmi_mlp3d_finalize": (_I, [_VP]),
     "ddmi_hdpe_mlp3d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _VP, _I, _I, _VP]),
     "ddmi_mlp3d_destroy": (_I, [_VP]),
+    "ddmi_unet3_create": (_I, [C.POINTER(UnetCfg), _I, _I, _I, C.POINTER(_VP)]),
+    "ddmi_decoderv_create": (_I, [C.POINTER(DecoderVCfg), C.POINTER(_VP)]),
+    "ddmi_decoderv_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_decoderv_finalize": (_I, [_VP]),
+    "ddmi_decoderv_num_scales": (_I, [_VP, C.POINTER(_I), C.POINTER(_I * 4), C.POINTER(_I)]),
+    "ddmi_decoderv_forward": (_I, [_VP, _VP, C.POINTER(_VP), _I, _I, _VP]),
+    "ddmi_decoderv_destroy": (_I, [_VP]),
+    "ddmi_mlpv_create": (_I, [C.POINTER(Mlp2dCfg), C.POINTER(_VP)]),
+    "ddmi_mlpv_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
+    "ddmi_mlpv_finalize": (_I, [_VP]),
+    "ddmi_hdpe_mlpv": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_mlpv_destroy": (_I, [_VP]),
     "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_debug_conv_config": (_I, [_I]),

@@ -12,6 +12,8 @@ struct ddmi_decoder2d { Decoder2d d; };
 struct ddmi_mlp2d { Mlp2d m; };
 struct ddmi_decoder3d { Decoder3d d; };
 struct ddmi_mlp3d { Mlp3d m; };
+struct ddmi_decoderv { DecoderV d; };
+struct ddmi_mlpv { MlpV m; };
 
 static int numerics_to_dt(int numerics, int* dt) {
   if (numerics == DDMI_PARITY_FP32) { *dt = DT_F32; return DDMI_OK; }
@@ -70,7 +72,13 @@ int ddmi_unet_load_weight(ddmi_unet* h, const char* key, const float* data, cons
 int ddmi_unet_finalize(ddmi_unet* h) {
   DDMI_REQUIRE(h, "null handle");
   if (h->u.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "already finalized");
-  return unet_finalize(h->u);
+  return h->u.size1 > 0 ? unet3_finalize(h->u) : unet_finalize(h->u);
+}
+int ddmi_unet3_create(const ddmi_unet_cfg* cfg, int size1, int size2, int size3, ddmi_unet** out) {
+  DDMI_REQUIRE(size1 > 0 && size2 > 0 && size3 > 0, "unet3_create: sizes must be positive");
+  DDMI_TRY(ddmi_unet_create(cfg, out));
+  (*out)->u.size1 = size1; (*out)->u.size2 = size2; (*out)->u.size3 = size3;
+  return DDMI_OK;
 }
 int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps_out, int B, void* stream) {
   DDMI_REQUIRE(h, "null handle");
@@ -227,6 +235,84 @@ int ddmi_decoder3d_destroy(ddmi_decoder3d* h) {
   return DDMI_OK;
 }
 
+// ---- video decoder / video MLP ---------------------------------------------------------------------------
+int ddmi_decoderv_create(const ddmi_decoderv_cfg* cfg, ddmi_decoderv** out) {
+  DDMI_REQUIRE(cfg && out, "decoderv_create: null argument");
+  DDMI_REQUIRE(cfg->max_batch >= 1, "decoderv_create: max_batch must be >= 1");
+  DDMI_REQUIRE(cfg->n_attn >= 0 && cfg->n_attn <= 8 && cfg->n_hdbf >= 0 && cfg->n_hdbf <= 8 && cfg->n_inter >= 0 &&
+                   cfg->n_inter <= 8 && cfg->frames >= 1 && cfg->resolution >= 8,
+               "decoderv_create: bad configuration");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_decoderv* h = new (std::nothrow) ddmi_decoderv();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->d.cfg = *cfg;
+  h->d.net.dt = dt;
+  h->d.net.max_batch = cfg->max_batch;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_decoderv_load_weight(ddmi_decoderv* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h, "null handle");
+  return h->d.net.add_host(key, data, shape, ndim);
+}
+int ddmi_decoderv_finalize(ddmi_decoderv* h) {
+  DDMI_REQUIRE(h, "null handle");
+  if (h->d.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "already finalized");
+  return decoderv_finalize(h->d);
+}
+int ddmi_decoderv_num_scales(ddmi_decoderv* h, int* n, int plane_hw[4], int* out_ch) {
+  DDMI_REQUIRE(h && n && plane_hw && out_ch, "null argument");
+  if (!h->d.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "decoder not finalized");
+  *n = h->d.n_scales;
+  *out_ch = h->d.out_ch;
+  for (int i = 0; i < h->d.n_scales; ++i) plane_hw[i] = h->d.plane_w[0][i];
+  return DDMI_OK;
+}
+int ddmi_decoderv_forward(ddmi_decoderv* h, const float* z, void* const* planes, int layout, int B, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return decoderv_forward(h->d, z, planes, layout, B, (hipStream_t)stream);
+}
+int ddmi_decoderv_destroy(ddmi_decoderv* h) {
+  delete h;
+  return DDMI_OK;
+}
+int ddmi_mlpv_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlpv** out) {
+  DDMI_REQUIRE(cfg && out, "mlpv_create: null argument");
+  int dt;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  ddmi_mlpv* h = new (std::nothrow) ddmi_mlpv();
+  if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
+  h->m.cfg = *cfg;
+  h->m.dt = dt;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_mlpv_load_weight(ddmi_mlpv* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DDMI_REQUIRE(h && key && data && ndim >= 0 && ndim <= 8, "mlpv_load_weight: bad arguments");
+  if (h->m.finalized) return ddmi_fail(DDMI_ERR_STATE, "load_weight after finalize");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  h->m.host[key] = std::move(t);
+  return DDMI_OK;
+}
+int ddmi_mlpv_finalize(ddmi_mlpv* h) {
+  DDMI_REQUIRE(h, "null handle");
+  return mlpv_finalize(h->m);
+}
+int ddmi_hdpe_mlpv(ddmi_mlpv* h, const void* const* planes, const int* plane_hw, int frames, int layout,
+                   const float* coords_xy, const float* coords_yt, const float* coords_xt, float* video_out, int B,
+                   int T, int H, int W, void* stream) {
+  DDMI_REQUIRE(h, "null handle");
+  return mlpv_forward(h->m, planes, plane_hw, frames, layout, coords_xy, coords_yt, coords_xt, video_out, B, T, H, W,
+                      (hipStream_t)stream);
+}
+int ddmi_mlpv_destroy(ddmi_mlpv* h) {
+  delete h;
+  return DDMI_OK;
+}
+
 int ddmi_mlp3d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp3d** out) {
   DDMI_REQUIRE(cfg && out, "mlp3d_create: null argument");
   int dt;
@@ -283,7 +369,7 @@ int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, 
   DDMI_REQUIRE(x && w && y, "op_conv2d: null tensor");
   Scratch sc;
   void *xn, *wp, *yn, *ws = nullptr;
-  int hin = upsample ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
+  int hin = upsample == 1 ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
   int Ho = (hin + 2 * pad - k) / stride + 1, Wo = (win + 2 * pad - k) / stride + 1;
   DDMI_TRY(sc.get((size_t)B * Cin * H * W * dt_size(dt), &xn));
   DDMI_TRY(sc.get((size_t)Cout * Cin * k * k * dt_size(dt), &wp));
@@ -327,7 +413,7 @@ int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, i
   DDMI_REQUIRE(ms_out && iters > 0, "bench_conv: bad arguments");
   Scratch sc;
   void *xn, *wp, *yn, *ws = nullptr;
-  int hin = upsample ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
+  int hin = upsample == 1 ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
   int Ho = (hin + 2 * pad - k) / stride + 1, Wo = (win + 2 * pad - k) / stride + 1;
   size_t xb = (size_t)B * Cin * H * W * dt_size(dt), wb = (size_t)Cout * Cin * k * k * dt_size(dt);
   DDMI_TRY(sc.get(xb, &xn));

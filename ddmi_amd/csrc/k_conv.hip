@@ -36,7 +36,7 @@ struct ConvK {
   float* ws;
   int B, Hin, Win, Cin, Hout, Wout, Cout;
   int KH, KW, stride, pad, ups;
-  int emb_stride;
+  int emb_stride, emb_mod;
   int M;        // rows per batch entry
   int CPT;      // chunks per tap = ceil(Cin / 32)
   int NK;       // total chunks
@@ -94,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
         continue;
       }
       if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)b * a.emb_stride + n);
+      if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)(a.emb_mod ? b % a.emb_mod : b) * a.emb_stride + n);
       if (rg) {
         const T* p = rg + (int64_t)m * a.Cout + n;
         if constexpr (IS_BF16) {
@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ktot = a.KH * a.KW * a.Cin;
-  const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
+  const int ush = a.ups == 1, usw = a.ups != 0;  // fused nearest upsample: 1 = x2 both axes, 2 = x2 along W only
+  const int Hlim = a.Hin << ush, Wlim = a.Win << usw;
   const int hw = a.Hout * a.Wout;
 
   // descriptors address at most 2 GiB: rebase the activation descriptor at the first sample this tile touches
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
         int ok = a_ok[i] & kvalid & (c0 + a_coff[i] < a.Cin) & ((unsigned)ih < (unsigned)Hlim) &
                  ((unsigned)iw < (unsigned)Wlim);
         int off = a_base[i] + a_delta;
-        if (a.ups) off = ((a_pix[i] + (ih >> 1) * a.Win + (iw >> 1)) * a.Cin + c0 + a_coff[i]) * SZ;
+        if (a.ups) off = ((a_pix[i] + (ih >> ush) * a.Win + (iw >> usw)) * a.Cin + c0 + a_coff[i]) * SZ;
         unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
         const int g = i * NW + wave;  // wave-uniform
         unsigned char* dst = g < GA ? sbase + c * (BM * ROWB) + g * 1024 : smem + SCRATCH + wave * 1024;
@@ -341,7 +342,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ktot = a.KH * a.KW * a.Cin;
-  const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
+  const int ush = a.ups == 1, usw = a.ups != 0;  // fused nearest upsample: 1 = x2 both axes, 2 = x2 along W only
+  const int Hlim = a.Hin << ush, Wlim = a.Win << usw;
   const int hw = a.Hout * a.Wout;
   const int taps = a.KH * a.KW;
   const int NCB = (a.Cin + 63) >> 6;  // 64-channel blocks per tap
@@ -403,7 +405,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     for (int i = 0; i < A_PER; ++i) {
       int ih = a_ih0[i] + q_kh, iw = a_iw0[i] + q_kw;
       int ok = cvalid & ((unsigned)ih < (unsigned)Hlim) & ((unsigned)iw < (unsigned)Wlim);
-      if (a.ups) { ih >>= 1; iw >>= 1; }
+      ih >>= ush; iw >>= usw;
       int off = a_pb[i] + (ih * a.Win + iw) * rowb + c0b;
       unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
       const int g = i * NW + wave;
@@ -686,7 +688,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
   const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ktot = a.KH * a.KW * a.Cin;
-  const int Hlim = a.ups ? 2 * a.Hin : a.Hin, Wlim = a.ups ? 2 * a.Win : a.Win;
+  const int ush = a.ups == 1, usw = a.ups != 0;  // fused nearest upsample: 1 = x2 both axes, 2 = x2 along W only
+  const int Hlim = a.Hin << ush, Wlim = a.Win << usw;
   const int hw = a.Hout * a.Wout;
 
   // descriptors address at most 2 GiB: rebase the activation descriptor at the first sample this tile touches
@@ -761,7 +764,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
         bool ok = a_ok[i] && kvalid && (c0 + a_coff[i] < a.Cin) && (unsigned)ih < (unsigned)Hlim &&
                   (unsigned)iw < (unsigned)Wlim;
         int off = a_base[i] + a_delta;
-        if (a.ups) off = ((a_pix[i] + (ih >> 1) * a.Win + (iw >> 1)) * a.Cin + c0 + a_coff[i]) * SZ;
+        if (a.ups) off = ((a_pix[i] + (ih >> ush) * a.Win + (iw >> usw)) * a.Cin + c0 + a_coff[i]) * SZ;
         unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
         if constexpr (IS_BF16) {
           if ((i * NW + wave) * 16 < BM) {  // wave-uniform: this row group exists
@@ -895,7 +898,7 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(ConvK a) {
     f32x4 v = *reinterpret_cast<const f32x4*>(a.ws + e0);
     for (int z = 1; z < a.SPS; ++z) v += *reinterpret_cast<const f32x4*>(a.ws + (int64_t)z * a.M * a.Cout + e0);
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-    if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)b * a.emb_stride + n);
+    if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)(a.emb_mod ? b % a.emb_mod : b) * a.emb_stride + n);
     if (a.res) {
       const T* p = (const T*)a.res + e0;
 #pragma unroll
@@ -944,7 +947,7 @@ static const RingCfg kRing[] = {
     {256, 128, -2},  // 20: halo<128,4,2> 8 waves, per-wave 64x64,  131 KB
 };
 static bool halo_ok(const ConvArgs& a) {
-  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hin == a.Win &&
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups &&
          (a.Win == 16 || a.Win == 32 || a.Win == 64) && (a.Hin * a.Win) % 256 == 0 && a.Hout == a.Hin && a.Wout == a.Win;
 }
 static const int kHaloFallback = 13;
@@ -987,7 +990,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.ws = splitk > 1 ? a.splitk_ws : nullptr;
   k.B = a.B; k.Hin = a.Hin; k.Win = a.Win; k.Cin = a.Cin; k.Hout = a.Hout; k.Wout = a.Wout; k.Cout = a.Cout;
   k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
-  k.emb_stride = a.emb_stride;
+  k.emb_stride = a.emb_stride; k.emb_mod = a.emb_mod;
   k.M = a.B * a.Hout * a.Wout;
   k.CPT = cdiv(a.Cin, 32);
   k.NK = k.CPT * a.KH * a.KW;
@@ -1165,7 +1168,7 @@ static int check_conv(const ConvArgs& a, int dt) {
   DDMI_REQUIRE((a.KH == 1 && a.KW == 1) || (a.KH == 3 && a.KW == 3), "conv: kernel must be 1x1 or 3x3");
   DDMI_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride must be 1 or 2");
   DDMI_REQUIRE(!(a.ups && a.stride != 1), "conv: fused upsample needs stride 1");
-  int hin = a.ups ? 2 * a.Hin : a.Hin, win = a.ups ? 2 * a.Win : a.Win;
+  int hin = a.ups == 1 ? 2 * a.Hin : a.Hin, win = a.ups ? 2 * a.Win : a.Win;
   DDMI_REQUIRE(a.Hout == (hin + 2 * a.pad - a.KH) / a.stride + 1 && a.Wout == (win + 2 * a.pad - a.KW) / a.stride + 1,
                "conv: output size mismatch");
   return DDMI_OK;

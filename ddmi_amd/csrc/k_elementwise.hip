@@ -95,16 +95,18 @@ int launch_ddpm_step(const float* x, const float* model_out, const float* noise,
 // =====================================================================================================
 template <typename T>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C,
-                                                           int HW) {
+                                                           int HW, int ld, int off) {
+  // source rows are `ld` long and the HW positions start at `off` (a token range of a [B, C, L] sequence); ld = HW,
+  // off = 0 for a whole tensor
   __shared__ float tile[32][33];
   int b = blockIdx.z;
   int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const float* s = src + (int64_t)b * C * HW;
+  const float* s = src + (int64_t)b * C * ld + off;
   T* d = dst + (int64_t)b * C * HW;
   for (int i = ty; i < 32; i += 8) {
     int c = c0 + i, p = p0 + tx;
-    tile[i][tx] = (c < C && p < HW) ? s[(int64_t)c * HW + p] : 0.f;
+    tile[i][tx] = (c < C && p < HW) ? s[(int64_t)c * ld + p] : 0.f;
   }
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
@@ -115,13 +117,13 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
 
 template <typename T>
 __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C,
-                                                           int HW) {
+                                                           int HW, int ld, int off) {
   __shared__ float tile[32][33];
   int b = blockIdx.z;
   int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const T* s = src + (int64_t)b * C * HW;
-  float* d = dst + (int64_t)b * C * HW;
+  float* d = dst + (int64_t)b * C * ld + off;
   for (int i = ty; i < 32; i += 8) {
     int p = p0 + i, c = c0 + tx;
     tile[i][tx] = (c < C && p < HW) ? to_f32(s[(int64_t)p * C + c]) : 0.f;
@@ -129,26 +131,28 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     int c = c0 + i, p = p0 + tx;
-    if (p < HW && c < C) d[(int64_t)c * HW + p] = tile[tx][i];
+    if (p < HW && c < C) d[(int64_t)c * ld + p] = tile[tx][i];
   }
 }
 
-int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int HW, hipStream_t s) {
+int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int HW, hipStream_t s, int ld, int off) {
+  if (ld <= 0) ld = HW;
   dim3 g(cdiv(HW, 32), cdiv(C, 32), B);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, dim3(256), 0, s, src, (float*)dst, C, HW);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, dim3(256), 0, s, src, (float*)dst, C, HW, ld, off);
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, dim3(256), 0, s, src, (bf16_t*)dst, C, HW);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, dim3(256), 0, s, src, (bf16_t*)dst, C, HW, ld, off);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
 
-int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s) {
+int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s, int ld, int off) {
+  if (ld <= 0) ld = HW;
   dim3 g(cdiv(HW, 32), cdiv(C, 32), B);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, dim3(256), 0, s, (const float*)src, dst, C, HW);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, dim3(256), 0, s, (const float*)src, dst, C, HW, ld, off);
   else
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, dst, C, HW);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, dst, C, HW, ld, off);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

@@ -39,7 +39,8 @@ template <> struct Vec16<bf16_t> {
 // fp64 -> part[b][split][group*2 + {sum, sumsq}].  No atomics, no zero-fill; bit-identical from run to run.
 #define GN_MAXSPLIT 64
 template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ part, int HW, int C, int NV, int R) {
+__global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ part, int HW, int C, int NV, int R, int seg,
+                                int nseg) {
   constexpr int VN = Vec16<T>::N;
   extern __shared__ float red[];  // s1[R][C] | s2[R][C]
   int b = blockIdx.y;
@@ -74,15 +75,16 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ pa
     double acc = 0.0;
     for (int rr = 0; rr < R; ++rr)
       for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += (double)red[(which * R + rr) * C + c];
-    part[((int64_t)b * GN_MAXSPLIT + blockIdx.x) * (GN_GROUPS * 2) + tid] = acc;
+    part[(((int64_t)b * nseg + seg) * GN_MAXSPLIT + blockIdx.x) * (GN_GROUPS * 2) + tid] = acc;
   }
 }
 
 // grid (nsplit, B); block = NV * R threads like the stats kernel: every thread owns ONE 16-byte channel vector for all
 // its pixels, so its scale/shift live in registers (no per-element index math, no LDS in the streaming loop).
+struct GnSegs { int nseg, nsplit[3], total_hw; };
 template <typename T>
 __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ part,
-                                int nsplit_stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                GnSegs sg, const float* __restrict__ gamma, const float* __restrict__ beta,
                                 float eps, int silu, int HW, int C, int NV, int R) {
   constexpr int VN = Vec16<T>::N;
   __shared__ float mr[GN_GROUPS * 2];  // mean, rstd per group
@@ -91,12 +93,15 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
   int cpg = C / GN_GROUPS;
   if (tid < GN_GROUPS) {
     double s1 = 0.0, s2 = 0.0;
-    const double* p = part + (int64_t)b * GN_MAXSPLIT * (GN_GROUPS * 2) + tid * 2;
-    for (int sidx = 0; sidx < nsplit_stats; ++sidx) {
-      s1 += p[(int64_t)sidx * (GN_GROUPS * 2)];
-      s2 += p[(int64_t)sidx * (GN_GROUPS * 2) + 1];
+    // statistics run over every segment of the sample (the video path normalises xy | xt | yt tokens jointly)
+    for (int sgi = 0; sgi < sg.nseg; ++sgi) {
+      const double* p = part + ((int64_t)b * sg.nseg + sgi) * GN_MAXSPLIT * (GN_GROUPS * 2) + tid * 2;
+      for (int sidx = 0; sidx < sg.nsplit[sgi]; ++sidx) {
+        s1 += p[(int64_t)sidx * (GN_GROUPS * 2)];
+        s2 += p[(int64_t)sidx * (GN_GROUPS * 2) + 1];
+      }
     }
-    double cnt = (double)HW * cpg;
+    double cnt = (double)sg.total_hw * cpg;
     double m = s1 / cnt;
     double var = s2 / cnt - m * m;
     if (var < 0) var = 0;
@@ -138,7 +143,8 @@ static int gn_splits(int B, int HW) {
   return std::max(1, std::min(std::min(want, HW / 16), GN_MAXSPLIT));
 }
 
-int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s) {
+int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg, int nseg) {
+  DDMI_REQUIRE(nseg >= 1 && nseg <= 3 && seg >= 0 && seg < nseg, "groupnorm: bad segment index");
   int vn = dt == DT_F32 ? 4 : 8;
   DDMI_REQUIRE(C % GN_GROUPS == 0, "groupnorm: C must be a multiple of 32");
   DDMI_REQUIRE(C % vn == 0, "groupnorm: C must be a multiple of the 16-byte vector");
@@ -150,27 +156,38 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
   size_t lds = (size_t)2 * R * C * sizeof(float);
   PROF_SCOPE("gn_stats", 0, (double)B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_stats_kernel<float>, g, dim3(threads), lds, s, (const float*)x, stats, HW, C, NV, R);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, g, dim3(threads), lds, s, (const float*)x, stats, HW, C, NV, R, seg, nseg);
   else
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, stats, HW, C, NV, R);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, stats, HW, C, NV, R, seg, nseg);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
 
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
-                    float eps, int silu, int B, int HW, int C, hipStream_t s) {
+                    float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw, int nseg) {
   int vn = dt == DT_F32 ? 4 : 8;
   int NV = C / vn;
   int R = std::max(1, 256 / NV);
   int threads = std::max(64, cdiv(NV * R, 64) * 64);
   int ns = gn_splits(B, HW);
   dim3 g(ns, B);
+  GnSegs sg{};
+  if (seg_hw == nullptr || nseg <= 1) {
+    sg.nseg = 1; sg.nsplit[0] = ns; sg.total_hw = HW;
+  } else {
+    DDMI_REQUIRE(nseg <= 3, "groupnorm: at most three segments");
+    sg.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+      sg.nsplit[i] = gn_splits(B, seg_hw[i]);  // what launch_gn_stats used for that segment (same B)
+      sg.total_hw += seg_hw[i];
+    }
+  }
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (float*)y, stats, ns, gamma,
+    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (float*)y, stats, sg, gamma,
                        beta, eps, silu, HW, C, NV, R);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, stats, ns, gamma,
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, stats, sg, gamma,
                        beta, eps, silu, HW, C, NV, R);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;

@@ -20,8 +20,10 @@ int launch_ddpm_step(const float* x, const float* model_out, const float* noise,
                      hipStream_t stream);
 
 // ---- layout / packing -----------------------------------------------------------------------------
-int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int HW, hipStream_t s);
-int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s);
+// fp32 [B, C, ld] (positions off .. off+HW of every channel row) <-> [B, HW, C] in the network dtype; ld = 0 means HW.
+// The video path keeps its three planes as token ranges of one [B, C, L] sequence (openaimodel.py:1141-1143).
+int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int HW, hipStream_t s, int ld = 0, int off = 0);
+int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s, int ld = 0, int off = 0);
 int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int dt, int64_t npix, hipStream_t s);
 int launch_pack_conv_weight(const float* w_oihw, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int launch_cast_f32(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
@@ -36,11 +38,14 @@ int launch_linear_small(const float* x, int x_stride, const float* W, const floa
                         int B, int K, int N, int silu_in, hipStream_t s);
 
 // ---- GroupNorm(32) ----------------------------------------------------------------------------------
-// stats: scratch of GN_STATS_DOUBLES(B) doubles ([B][64 splits][32 groups][sum, sumsq]); no zero-fill needed
-#define GN_STATS_DOUBLES(B) ((size_t)(B) * 64 * 64)
-int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s);
+// stats: scratch of GN_STATS_DOUBLES(B) doubles ([B][nseg <= 3][64 splits][32 groups][sum, sumsq]); no zero-fill needed.
+// A sample's statistics may span up to three tensors ("segments": the video path normalises the xy | xt | yt tokens
+// of a sample jointly, autoencoder_unet.py:1066-1071): run launch_gn_stats once per segment (same B, seg = 0..nseg-1),
+// then launch_gn_apply on each tensor with the HW of every segment in `seg_hw`.
+#define GN_STATS_DOUBLES(B) ((size_t)(B) * 3 * 64 * 64)
+int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg = 0, int nseg = 1);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
-                    float eps, int silu, int B, int HW, int C, hipStream_t s);
+                    float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1);
 
 // ---- implicit-GEMM convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 upsample) ------
 struct ConvArgs {
@@ -53,8 +58,9 @@ struct ConvArgs {
   float* y_nchw;      // optional fp32 NCHW output (model boundary)
   float* splitk_ws;   // fp32 [splitk][M][Cout] partial slabs when splitk > 1
   int B, Hin, Win, Cin, Hout, Wout, Cout;
-  int KH, KW, stride, pad, ups;
+  int KH, KW, stride, pad, ups;   // ups: fused nearest upsample of the input, 1 = x2 on both axes, 2 = x2 along W only
   int emb_stride;
+  int emb_mod;        // > 0: row of `emb` = sample % emb_mod (planes stacked along the batch axis share the embedding)
   int splitk;
   float out_scale;    // y = (acc + bias + emb + res) * out_scale
   int cfg;            // bf16 ring-kernel configuration id + 1 (0 = heuristic), see k_conv.hip kRing
@@ -127,3 +133,18 @@ struct Mlp3dArgs {
 int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s);
 size_t mlp3d_weight_elems();
 size_t mlp3d_fb_elems();
+
+// ---- fused tri-plane sampling + video MLP (MLPVideo) -------------------------------------------------------
+struct MlpVArgs {
+  const void* planes[9];   // index type*3 + scale, type order (xy, yt, xt), NHWC in the storage dtype
+  int plane_hw[3];         // P per scale: xy planes [P][P], yt / xt planes [frames][P]
+  int frames;
+  const float *cxy, *cyt, *cxt;  // coordinate grids [2][H][W], [2][T][H], [2][T][W]
+  const void* w;
+  const float* fb;
+  float* out;              // [B][3][T][H][W]
+  int B, T, H, W;
+};
+int launch_mlpv(const MlpVArgs& a, int dt, hipStream_t s);
+size_t mlpv_weight_elems();
+size_t mlpv_fb_elems();

@@ -4,6 +4,7 @@
 
 struct UNet {
   ddmi_unet_cfg cfg{};
+  int size1 = 0, size2 = 0, size3 = 0;   // tri-plane (video) variant: xy = [size1,size2], xt = [size3,size1], yt = [size3,size2]
   Net net;
   int emb_dim = 0;
   int emb_total = 0;             // sum of ResBlock out channels: width of the concatenated emb projection
@@ -14,6 +15,19 @@ struct UNet {
   float* tbuf = nullptr;         // [B][mc] temb | [B][E] | [B][E] | [B][emb_total]
 };
 int unet_finalize(UNet& u);
+// weight bundles of the blocks shared by the image and video networks (created once, emitted per tensor)
+struct ResW { int gn1 = -1, c1 = -1, gn2 = -1, c2 = -1, cs = -1, emb_off = -1; float eps = 1e-5f; };
+struct AttnW { int gn = -1, cqkv = -1, cp = -1, heads = 1, head_dim = 0, legacy = 0; float eps = 1e-5f, scale = 1.f; };
+int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w);
+int make_vae_resblock(Net& n, const std::string& pre, int cin, int cout, ResW* w);
+int emit_resblock(Net& n, const ResW& w, int x, int* out);
+int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w);
+int make_qkv_attn(Net& n, const std::string& pre, int ch, int heads, bool expand, AttnW* w);
+int emit_attn_single(Net& n, const AttnW& w, int x, int* out);
+int emit_attn_joint(Net& n, const AttnW& w, int xy, int tp, int* out_xy, int* out_tp);
+int unet_time_embed_setup(UNet& u);   // time_embed.* + sinusoid frequencies
+int unet_finish(UNet& u);             // concatenated emb projections, scratch, plan()
+int unet3_finalize(UNet& u);          // UNetModel_Triplane topology (models_video.hip)
 int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s);
 
 struct Decoder2d {
@@ -70,3 +84,27 @@ struct Mlp3d {
 int mlp3d_finalize(Mlp3d& m);
 int mlp3d_forward(Mlp3d& m, const void* const* planes, const int* plane_hw, int layout, const float* pts, float* logits,
                   int B, int N, hipStream_t s);
+
+struct DecoderV {            // video decoder (VITAutoencoder.decode + VideoDecoder_light), models_video.hip
+  ddmi_decoderv_cfg cfg{};
+  Net net;
+  int n_scales = 0, out_ch = 0, seq_len = 0;
+  int export_ops[3][4] = {{0}};
+  int plane_h[2][4] = {{0}}, plane_w[2][4] = {{0}};   // [0] xy planes, [1] yt / xt planes
+};
+int decoderv_finalize(DecoderV& d);
+int decoderv_forward(DecoderV& d, const float* z, void* const* planes, int layout, int B, hipStream_t s);
+
+struct MlpV {
+  ddmi_mlp2d_cfg cfg{};   // in_ch 2, out_ch 3, ch 256, latent_dim 64
+  int dt = DT_F32;
+  bool finalized = false;
+  std::map<std::string, HostTensor> host;
+  void* w_dev = nullptr;
+  float* fb_dev = nullptr;
+  std::vector<void*> dev_allocs;
+  ~MlpV();
+};
+int mlpv_finalize(MlpV& m);
+int mlpv_forward(MlpV& m, const void* const* planes, const int* plane_hw, int frames, int layout, const float* cxy,
+                 const float* cyt, const float* cxt, float* out, int B, int T, int H, int W, hipStream_t s);

@@ -17,67 +17,146 @@ static bool in_list(const int* v, int n, int x) {
 
 // one ResBlock (openaimodel.py:244-276, no up/down, use_scale_shift_norm=False):
 //   h = conv3(SiLU(GN(x))) + emb_proj ; h = conv3(SiLU(GN(h))) ; out = skip(x) + h
-static int build_resblock(UNet& u, const std::string& pre, int x, int cout, int* out) {
+// Weights are created once (make_*) and may be emitted on several tensors (the video UNet runs every block on the
+// xy plane and on the stacked xt / yt planes with the same weights).
+int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w) {
   Net& n = u.net;
-  int cin = n.tensors[x].C;
-  int gn1, gn2, c1, c2;
-  DDMI_TRY(n.make_gn(pre + "in_layers.0.", &gn1));
-  DDMI_TRY(n.make_conv(pre + "in_layers.2.weight", pre + "in_layers.2.bias", &c1));
-  DDMI_REQUIRE(n.convs[c1].Cin == cin && n.convs[c1].Cout == cout, "resblock conv shape mismatch at " + pre);
+  w->eps = 1e-5f;
+  DDMI_TRY(n.make_gn(pre + "in_layers.0.", &w->gn1));
+  DDMI_TRY(n.make_conv(pre + "in_layers.2.weight", pre + "in_layers.2.bias", &w->c1));
+  DDMI_REQUIRE(n.convs[w->c1].Cin == cin && n.convs[w->c1].Cout == cout, "resblock conv shape mismatch at " + pre);
   // time-embedding projection rows are appended to one big [Etot, emb_dim] matrix
   const HostTensor* ew = n.find(pre + "emb_layers.1.weight");
   const HostTensor* eb = n.find(pre + "emb_layers.1.bias");
   if (!ew || !eb) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + pre + "emb_layers.1.*'");
   DDMI_REQUIRE(ew->shape.size() == 2 && ew->shape[0] == cout && ew->shape[1] == u.emb_dim, "emb_layers shape mismatch at " + pre);
-  int emb_off = (int)u.emb_b_host.size();
+  w->emb_off = (int)u.emb_b_host.size();
   u.emb_w_host.insert(u.emb_w_host.end(), ew->data.begin(), ew->data.end());
   u.emb_b_host.insert(u.emb_b_host.end(), eb->data.begin(), eb->data.end());
-  DDMI_TRY(n.make_gn(pre + "out_layers.0.", &gn2));
-  DDMI_TRY(n.make_conv(pre + "out_layers.3.weight", pre + "out_layers.3.bias", &c2));
-  int skip = x;
+  DDMI_TRY(n.make_gn(pre + "out_layers.0.", &w->gn2));
+  DDMI_TRY(n.make_conv(pre + "out_layers.3.weight", pre + "out_layers.3.bias", &w->c2));
+  w->cs = -1;
   if (cin != cout) {
-    int cs;
-    DDMI_TRY(n.make_conv(pre + "skip_connection.weight", pre + "skip_connection.bias", &cs));
-    DDMI_REQUIRE(n.convs[cs].K == 1, "only 1x1 skip connections are supported (use_conv=False)");
-    skip = n.op_conv(x, cs, 1, 0, -1, -1);
+    DDMI_TRY(n.make_conv(pre + "skip_connection.weight", pre + "skip_connection.bias", &w->cs));
+    DDMI_REQUIRE(n.convs[w->cs].K == 1, "only 1x1 skip connections are supported (use_conv=False)");
   }
-  int a = n.op_gn(x, gn1, 1, 1e-5f);
-  int h = n.op_conv(a, c1, 1, 0, -1, emb_off);
-  int b = n.op_gn(h, gn2, 1, 1e-5f);
-  *out = n.op_conv(b, c2, 1, 0, skip, -1);
   return DDMI_OK;
 }
 
-// AttentionBlock (openaimodel.py:319-325) with QKVAttentionLegacy, head dim = num_head_channels (must be 32)
-static int build_attnblock(UNet& u, const std::string& pre, int x, int* out) {
+int emit_resblock(Net& n, const ResW& w, int x, int* out) {
+  DDMI_REQUIRE(n.tensors[x].C == n.convs[w.c1].Cin, "resblock input channel mismatch");
+  int skip = x;
+  if (w.cs >= 0) skip = n.op_conv(x, w.cs, 1, 0, -1, -1);
+  int a = n.op_gn(x, w.gn1, 1, w.eps);
+  int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off);
+  int b = n.op_gn(h, w.gn2, 1, w.eps);
+  *out = n.op_conv(b, w.c2, 1, 0, skip, -1);
+  return DDMI_OK;
+}
+
+static int build_resblock(UNet& u, const std::string& pre, int x, int cout, int* out) {
+  ResW w;
+  DDMI_TRY(make_unet_resblock(u, pre, u.net.tensors[x].C, cout, &w));
+  return emit_resblock(u.net, w, x, out);
+}
+
+// AttentionBlock (openaimodel.py:319-325) with QKVAttentionLegacy, head dim = num_head_channels
+int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w) {
   Net& n = u.net;
-  const TensorDesc t = n.tensors[x];
-  int gn, cq, cp;
-  DDMI_TRY(n.make_gn(pre + "norm.", &gn));
-  DDMI_TRY(n.make_conv(pre + "qkv.weight", pre + "qkv.bias", &cq));
-  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &cp));
-  DDMI_REQUIRE(n.convs[cq].Cout == 3 * t.C && n.convs[cq].Cin == t.C, "qkv shape mismatch at " + pre);
-  int a = n.op_gn(x, gn, 0, 1e-5f);
-  int qkv = n.op_conv(a, cq, 1, 0, -1, -1);
-  Op o;
-  o.kind = OP_ATTN_LEGACY;
-  o.in = qkv;
-  o.out = n.new_tensor(t.C, t.H, t.W);
-  o.heads = t.C / u.cfg.num_head_channels;
-  n.ops.push_back(o);
-  *out = n.op_conv(o.out, cp, 1, 0, x, -1);
+  DDMI_REQUIRE(u.cfg.num_head_channels > 0 && ch % u.cfg.num_head_channels == 0, "channels must be a multiple of num_head_channels");
+  w->eps = 1e-5f;
+  DDMI_TRY(n.make_gn(pre + "norm.", &w->gn));
+  DDMI_TRY(n.make_conv(pre + "qkv.weight", pre + "qkv.bias", &w->cqkv));
+  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
+  DDMI_REQUIRE(n.convs[w->cqkv].Cout == 3 * ch && n.convs[w->cqkv].Cin == ch, "qkv shape mismatch at " + pre);
+  w->head_dim = u.cfg.num_head_channels;
+  w->heads = ch / w->head_dim;
+  w->legacy = 1;
+  w->scale = 1.0f / std::sqrt((float)w->head_dim);  // (d^-1/4 q) . (d^-1/4 k), openaimodel.py:413-416
   return DDMI_OK;
 }
 
-int unet_finalize(UNet& u) {
+// attention over the tokens of ONE tensor (every batch entry - sample or stacked plane - on its own)
+int emit_attn_single(Net& n, const AttnW& w, int x, int* out) {
+  const TensorDesc t = n.tensors[x];
+  int a = n.op_gn(x, w.gn, 0, w.eps);
+  int qkv = n.op_conv(a, w.cqkv, 1, 0, -1, -1);
+  Op o;
+  o.kind = OP_ATTN_MH;
+  o.in = qkv;
+  o.out = n.new_tensor(w.heads * w.head_dim, t.H, t.W, -1, t.bmul);
+  o.bmul = t.bmul;
+  o.heads = w.heads; o.head_dim = w.head_dim; o.legacy_layout = w.legacy; o.scale = w.scale;
+  n.ops.push_back(o);
+  *out = n.op_conv(o.out, w.cp, 1, 0, x, -1);
+  return DDMI_OK;
+}
+
+// attention over the concatenated tokens xy | xt | yt of every sample (openaimodel.py:1148-1157, ae:1066-1075)
+int emit_attn_joint(Net& n, const AttnW& w, int xy, int tp, int* out_xy, int* out_tp) {
+  const TensorDesc txy = n.tensors[xy], tt = n.tensors[tp];
+  DDMI_REQUIRE(txy.bmul == 1 && tt.bmul == 2 && txy.C == tt.C, "joint attention expects an xy tensor and a stacked xt|yt tensor");
+  Op g;
+  g.kind = OP_GN_JOINT;
+  g.in = xy; g.in2 = tp;
+  g.out = n.new_tensor(txy.C, txy.H, txy.W, -1, 1);
+  g.out2 = n.new_tensor(tt.C, tt.H, tt.W, -1, 2);
+  g.gn = w.gn; g.eps = w.eps; g.silu = 0;
+  g.gn_slot = n.n_gn_slots++;
+  n.ops.push_back(g);
+  int q_xy = n.op_conv(g.out, w.cqkv, 1, 0, -1, -1);
+  int q_tp = n.op_conv(g.out2, w.cqkv, 1, 0, -1, -1);
+  Op o;
+  o.kind = OP_ATTN_MH;
+  o.in = q_xy; o.in2 = q_tp;
+  o.out = n.new_tensor(w.heads * w.head_dim, txy.H, txy.W, -1, 1);
+  o.out2 = n.new_tensor(w.heads * w.head_dim, tt.H, tt.W, -1, 2);
+  o.heads = w.heads; o.head_dim = w.head_dim; o.legacy_layout = w.legacy; o.scale = w.scale;
+  n.ops.push_back(o);
+  *out_xy = n.op_conv(o.out, w.cp, 1, 0, xy, -1);
+  *out_tp = n.op_conv(o.out2, w.cp, 1, 0, tp, -1);
+  return DDMI_OK;
+}
+
+// q / k / v stored as three Conv1d/Conv2d(C -> Cq) modules (autoencoder_unet.py:223-242, 279-298, 410-430, 476-496):
+// fused into one [3 Cq, C] projection so the normalised activations are read once
+int make_qkv_attn(Net& n, const std::string& pre, int ch, int heads, bool expand, AttnW* w) {
+  w->eps = 1e-6f;
+  DDMI_TRY(n.make_gn(pre + "norm.", &w->gn));
+  const int cq = expand ? ch * heads : ch;
+  std::vector<float> wcat, bcat;
+  for (const char* nm : {"q.", "k.", "v."}) {
+    const HostTensor* wt = n.find(pre + nm + "weight");
+    const HostTensor* bt = n.find(pre + nm + "bias");
+    if (!wt || !bt) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + pre + nm + "*'");
+    DDMI_REQUIRE(wt->numel() == (int64_t)cq * ch && bt->numel() == cq, "q/k/v projection shape mismatch at " + pre);
+    wcat.insert(wcat.end(), wt->data.begin(), wt->data.end());
+    bcat.insert(bcat.end(), bt->data.begin(), bt->data.end());
+  }
+  DDMI_TRY(n.make_conv_host(wcat, 3 * cq, ch, 1, &bcat, &w->cqkv));
+  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
+  DDMI_REQUIRE(n.convs[w->cp].Cin == cq && n.convs[w->cp].Cout == ch, "proj_out shape mismatch at " + pre);
+  w->heads = heads;
+  w->head_dim = cq / heads;
+  w->legacy = 0;
+  w->scale = 1.0f / std::sqrt((float)w->head_dim);  // xformers.ops.memory_efficient_attention default scale
+  return DDMI_OK;
+}
+
+static int build_attnblock(UNet& u, const std::string& pre, int x, int* out) {
+  AttnW w;
+  DDMI_TRY(make_unet_attnblock(u, pre, u.net.tensors[x].C, &w));
+  return emit_attn_single(u.net, w, x, out);
+}
+
+int unet_time_embed_setup(UNet& u) {
   Net& n = u.net;
   const ddmi_unet_cfg& c = u.cfg;
-  DDMI_REQUIRE(c.num_head_channels == 32, "only num_head_channels == 32 is supported by the fused attention kernel");
+  DDMI_REQUIRE(c.num_head_channels >= 1 && c.num_head_channels <= 512, "num_head_channels must be in 1..512");
   DDMI_REQUIRE(c.n_mult >= 1 && c.n_mult <= 8 && c.n_attn >= 0 && c.n_attn <= 8, "bad channel_mult / attention_resolutions");
   DDMI_REQUIRE(c.model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm32)");
   const int mc = c.model_channels;
   u.emb_dim = 4 * mc;
-
   // ---- time embedding MLP (openaimodel.py:557-562) -------------------------------------------------
   {
     int half = mc / 2;
@@ -98,7 +177,14 @@ int unet_finalize(UNet& u) {
     }
     DDMI_REQUIRE(n.find(keys[0])->shape[0] == u.emb_dim && n.find(keys[0])->shape[1] == mc, "time_embed.0 shape mismatch");
   }
+  return DDMI_OK;
+}
 
+int unet_finalize(UNet& u) {
+  Net& n = u.net;
+  const ddmi_unet_cfg& c = u.cfg;
+  DDMI_TRY(unet_time_embed_setup(u));
+  const int mc = c.model_channels;
   // ---- topology (openaimodel.py:567-743) -------------------------------------------------------------
   const int S = c.image_size;
   Op in;
@@ -171,7 +257,13 @@ int unet_finalize(UNet& u) {
   n.ops.back().out_nchw = 1;
   n.ops.back().ext = 1;
   (void)y;
+  return unet_finish(u);
+}
 
+int unet_finish(UNet& u) {
+  Net& n = u.net;
+  const ddmi_unet_cfg& c = u.cfg;
+  const int mc = c.model_channels;
   // ---- concatenated emb projections ------------------------------------------------------------------
   u.emb_total = (int)u.emb_b_host.size();
   DDMI_TRY(n.dev_upload(u.emb_w_host.data(), (int64_t)u.emb_w_host.size(), &u.emb_w));
@@ -210,25 +302,23 @@ int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int 
 // D2C-VAE image decoder
 // =====================================================================================================
 // ResnetBlock (autoencoder_unet.py:129-149) with temb=None
-static int build_vae_resblock(Net& n, const std::string& pre, int x, int cout, int* out) {
-  int cin = n.tensors[x].C;
-  int gn1, gn2, c1, c2;
-  DDMI_TRY(n.make_gn(pre + "norm1.", &gn1));
-  DDMI_TRY(n.make_conv(pre + "conv1.weight", pre + "conv1.bias", &c1));
-  DDMI_TRY(n.make_gn(pre + "norm2.", &gn2));
-  DDMI_TRY(n.make_conv(pre + "conv2.weight", pre + "conv2.bias", &c2));
-  DDMI_REQUIRE(n.convs[c1].Cin == cin && n.convs[c1].Cout == cout, "decoder resblock shape mismatch at " + pre);
-  int skip = x;
-  if (cin != cout) {
-    int cs;
-    DDMI_TRY(n.make_conv(pre + "nin_shortcut.weight", pre + "nin_shortcut.bias", &cs));
-    skip = n.op_conv(x, cs, 1, 0, -1, -1);
-  }
-  int a = n.op_gn(x, gn1, 1, 1e-6f);
-  int h = n.op_conv(a, c1, 1, 0, -1, -1);
-  int b = n.op_gn(h, gn2, 1, 1e-6f);
-  *out = n.op_conv(b, c2, 1, 0, skip, -1);
+int make_vae_resblock(Net& n, const std::string& pre, int cin, int cout, ResW* w) {
+  w->eps = 1e-6f;
+  w->emb_off = -1;
+  DDMI_TRY(n.make_gn(pre + "norm1.", &w->gn1));
+  DDMI_TRY(n.make_conv(pre + "conv1.weight", pre + "conv1.bias", &w->c1));
+  DDMI_TRY(n.make_gn(pre + "norm2.", &w->gn2));
+  DDMI_TRY(n.make_conv(pre + "conv2.weight", pre + "conv2.bias", &w->c2));
+  DDMI_REQUIRE(n.convs[w->c1].Cin == cin && n.convs[w->c1].Cout == cout, "decoder resblock shape mismatch at " + pre);
+  w->cs = -1;
+  if (cin != cout) DDMI_TRY(n.make_conv(pre + "nin_shortcut.weight", pre + "nin_shortcut.bias", &w->cs));
   return DDMI_OK;
+}
+
+static int build_vae_resblock(Net& n, const std::string& pre, int x, int cout, int* out) {
+  ResW w;
+  DDMI_TRY(make_vae_resblock(n, pre, n.tensors[x].C, cout, &w));
+  return emit_resblock(n, w, x, out);
 }
 
 // AttnBlock with num_heads=1 (autoencoder_unet.py:187-215; make_attn 'vanilla' :561-567)

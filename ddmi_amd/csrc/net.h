@@ -33,17 +33,26 @@ struct GNW {
 };
 
 enum OpKind { OP_NCHW_IN = 0, OP_GN, OP_CONV, OP_ATTN_LEGACY, OP_ATTN_FULL, OP_CONCAT, OP_EXPORT, OP_PLANES_TO_CHANNELS,
-              OP_CHANNELS_TO_PLANES };
+              OP_CHANNELS_TO_PLANES,
+              // video path: a sample's tokens are xy | xt | yt; the xy plane is one tensor (`out` / `in`), the two
+              // t-planes are stacked along the batch axis of a second one (`out2` / `in2`: xt samples, then yt samples)
+              OP_SEG_IN,      // ext [B, C, L] fp32 -> out (xy), out2 (xt, yt)
+              OP_SEG_OUT,     // in, in2 -> ext [B, C, L] fp32
+              OP_GN_JOINT,    // GroupNorm whose statistics run over all tokens of the sample: in, in2 -> out, out2
+              OP_ATTN_MH };   // multi-head attention over in (+ in2 when >= 0) -> out (+ out2)
 
 struct Op {
   int kind = 0;
-  int in = -1, in2 = -1, out = -1, res = -1;
+  int in = -1, in2 = -1, out = -1, out2 = -1, res = -1;
   int conv = -1, gn = -1;
   int silu = 0;
   float eps = 1e-5f;
   int stride = 1, pad = 0, ups = 0;
   int emb_off = -1;
   int heads = 0;
+  int head_dim = 0;    // OP_ATTN_MH
+  int legacy_layout = 0;  // OP_ATTN_MH: per-head [q|k|v] channel interleave (QKVAttentionLegacy) instead of [q heads|k heads|v heads]
+  int seq_len = 0;     // OP_SEG_IN / OP_SEG_OUT: L of the external [B, C, L] tensor
   int out_nchw = 0;   // OP_CONV: write fp32 NCHW to external output slot `ext`
   int ext = -1;       // external pointer slot (inputs / outputs of the network)
   int gn_slot = -1;   // index into the GN statistics arena

@@ -144,7 +144,7 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
   const TensorDesc& t = tensors[in];
   const ConvW& c = convs[conv];
   int pad = c.K / 2;
-  int hin = ups ? 2 * t.H : t.H, win = ups ? 2 * t.W : t.W;
+  int hin = ups == 1 ? 2 * t.H : t.H, win = ups ? 2 * t.W : t.W;
   int ho = (hin + 2 * pad - c.K) / stride + 1, wo = (win + 2 * pad - c.K) / stride + 1;
   Op o;
   o.kind = OP_CONV;
@@ -173,7 +173,7 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   a->B = B; a->Hin = ti.H; a->Win = ti.W; a->Cin = c.Cin;
   a->Cout = c.Cout;
   a->KH = a->KW = c.K; a->stride = o.stride; a->pad = o.pad; a->ups = o.ups;
-  int hin = o.ups ? 2 * ti.H : ti.H, win = o.ups ? 2 * ti.W : ti.W;
+  int hin = o.ups == 1 ? 2 * ti.H : ti.H, win = o.ups ? 2 * ti.W : ti.W;
   a->Hout = (hin + 2 * o.pad - c.K) / o.stride + 1;
   a->Wout = (win + 2 * o.pad - c.K) / o.stride + 1;
   a->out_scale = o.scale;
@@ -192,7 +192,7 @@ int Net::plan() {
   for (int i = 0; i < nops; ++i) {
     const Op& o = ops[i];
     touch(o.in, i, false); touch(o.in2, i, false); touch(o.res, i, false);
-    touch(o.out, i, true); touch(o.tmp0, i, true); touch(o.tmp1, i, true); touch(o.tmp2, i, true);
+    touch(o.out, i, true); touch(o.out2, i, true); touch(o.tmp0, i, true); touch(o.tmp1, i, true); touch(o.tmp2, i, true);
   }
   // first-fit allocator over op order
   struct Blk { size_t off, size; };
@@ -387,6 +387,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         ConvArgs a;
         fill_conv_args(*this, o, B, &a);
         DDMI_REQUIRE(tensors[o.in].C == a.Cin, "conv input channel mismatch");
+        a.x = plane_ptr(o.in, o.in_boff);
         if (o.out_nchw) a.y_nchw = (float*)ext[o.ext];
         else a.y = plane_ptr(o.out, o.out_boff);
         if (o.res >= 0) a.res = tptr(o.res);
@@ -394,6 +395,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           DDMI_REQUIRE(emb != nullptr, "conv needs the time embedding");
           a.emb = emb + o.emb_off;
           a.emb_stride = emb_stride;
+          a.emb_mod = o.bmul > 1 ? Bnet : 0;
         }
         if (Bnet == max_batch && o.tuned.cfg > 0) {
           a.cfg = o.tuned.cfg; a.order = o.tuned.order; a.splitk = o.tuned.splitk;
@@ -405,6 +407,63 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         if (a.splitk > 1)
           DDMI_REQUIRE((size_t)a.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
         DDMI_TRY(launch_conv(a, dt, s));
+        break;
+      }
+      case OP_SEG_IN: {
+        const TensorDesc &txy = tensors[o.out], &tt = tensors[o.out2];
+        const int nxy = txy.H * txy.W, nt = tt.H * tt.W;
+        const float* src = (const float*)ext[o.ext];
+        DDMI_TRY(launch_nchw_to_nhwc(src, tptr(o.out), dt, Bnet, txy.C, nxy, s, o.seq_len, 0));
+        DDMI_TRY(launch_nchw_to_nhwc(src, plane_ptr(o.out2, 0), dt, Bnet, tt.C, nt, s, o.seq_len, nxy));
+        DDMI_TRY(launch_nchw_to_nhwc(src, plane_ptr(o.out2, 1), dt, Bnet, tt.C, nt, s, o.seq_len, nxy + nt));
+        break;
+      }
+      case OP_SEG_OUT: {
+        const TensorDesc &txy = tensors[o.in], &tt = tensors[o.in2];
+        const int nxy = txy.H * txy.W, nt = tt.H * tt.W;
+        float* dst = (float*)ext[o.ext];
+        DDMI_TRY(launch_nhwc_to_nchw(tptr(o.in), dt, dst, Bnet, txy.C, nxy, s, o.seq_len, 0));
+        DDMI_TRY(launch_nhwc_to_nchw(plane_ptr(o.in2, 0), dt, dst, Bnet, tt.C, nt, s, o.seq_len, nxy));
+        DDMI_TRY(launch_nhwc_to_nchw(plane_ptr(o.in2, 1), dt, dst, Bnet, tt.C, nt, s, o.seq_len, nxy + nt));
+        break;
+      }
+      case OP_GN_JOINT: {
+        const TensorDesc &txy = tensors[o.in], &tt = tensors[o.in2];
+        const GNW& g = gns[o.gn];
+        DDMI_REQUIRE(g.C == txy.C && g.C == tt.C, "groupnorm channel mismatch");
+        const int hw[3] = {txy.H * txy.W, tt.H * tt.W, tt.H * tt.W};
+        const void* src[3] = {tptr(o.in), plane_ptr(o.in2, 0), plane_ptr(o.in2, 1)};
+        void* dst[3] = {tptr(o.out), plane_ptr(o.out2, 0), plane_ptr(o.out2, 1)};
+        for (int i = 0; i < 3; ++i) DDMI_TRY(launch_gn_stats(src[i], dt, gn_stats, Bnet, hw[i], g.C, s, i, 3));
+        for (int i = 0; i < 3; ++i)
+          DDMI_TRY(launch_gn_apply(src[i], dst[i], dt, gn_stats, g.gamma, g.beta, o.eps, o.silu, Bnet, hw[i], g.C, s, hw, 3));
+        break;
+      }
+      case OP_ATTN_MH: {
+        const TensorDesc &ti = tensors[o.in], &to = tensors[o.out];
+        AttnArgs a{};
+        a.heads = o.heads; a.d = o.head_dim; a.scale = o.scale;
+        a.legacy_name = o.legacy_layout;
+        a.ld_qkv = ti.C; a.ld_out = to.C;
+        if (o.legacy_layout) {
+          a.q_off = 0; a.k_off = o.head_dim; a.v_off = 2 * o.head_dim; a.hs_qkv = 3 * o.head_dim;
+        } else {
+          a.q_off = 0; a.k_off = o.heads * o.head_dim; a.v_off = 2 * o.heads * o.head_dim; a.hs_qkv = o.head_dim;
+        }
+        a.hs_out = o.head_dim;
+        a.qkv[0] = tptr(o.in); a.out[0] = tptr(o.out);
+        a.seg_len[0] = ti.H * ti.W;
+        if (o.in2 >= 0) {  // tokens of a sample: xy | xt | yt
+          const TensorDesc& tt = tensors[o.in2];
+          DDMI_REQUIRE(tt.C == ti.C && tensors[o.out2].C == to.C, "attention: plane channel mismatch");
+          a.qkv[1] = plane_ptr(o.in2, 0); a.qkv[2] = plane_ptr(o.in2, 1);
+          a.out[1] = plane_ptr(o.out2, 0); a.out[2] = plane_ptr(o.out2, 1);
+          a.seg_len[1] = a.seg_len[2] = tt.H * tt.W;
+          a.B = Bnet;
+        } else {
+          a.B = B;
+        }
+        DDMI_TRY(launch_attention(a, dt, s));
         break;
       }
       case OP_ATTN_LEGACY: {

@@ -65,8 +65,6 @@ class DDPM:
                  v_posterior=0.0, parameterization="eps", sampling_timesteps=1000, ddim_sampling_eta=1.0, w=1.0,
                  mixed_prediction=True, mixed_init=-6, domain="image", **ignorekwargs):
         assert parameterization in ("eps", "x0", "v")
-        if domain == "video":
-            raise NotImplementedError("video latents ([B,C,L]) are a later row of the scope table")
         self.model = model
         self.parameterization = parameterization
         self.clip_denoised = bool(clip_denoised)
@@ -80,7 +78,9 @@ class DDPM:
         self.ddim_sampling_eta = float(ddim_sampling_eta)
         self.w = w
         self.mixed_prediction = bool(mixed_prediction)
-        self.mixing_logit = (np.full((1, self.channels, 1, 1), mixed_init, dtype=np.float32)
+        # [1,C,1,1] for image latents, [1,C,1] for the video token sequence [B,C,L] (ddpm.py:152-159)
+        self._logit_shape = (1, self.channels, 1) if domain == "video" else (1, self.channels, 1, 1)
+        self.mixing_logit = (np.full(self._logit_shape, mixed_init, dtype=np.float32)
                              if self.mixed_prediction else None)
         self._logit_dev = None
 
@@ -116,7 +116,7 @@ class DDPM:
         if "mixing_logit" in state and self.mixed_prediction:
             v = state["mixing_logit"]
             v = v.detach().float().cpu().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
-            self.mixing_logit = v.reshape(1, self.channels, 1, 1).astype(np.float32)
+            self.mixing_logit = v.reshape(self._logit_shape).astype(np.float32)
             self._logit_dev = None
         for name in SCHEDULE_BUFFERS:  # buffers are derived, a checkpoint's copy must agree with ours
             if name in state:

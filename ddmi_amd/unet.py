@@ -171,7 +171,7 @@ class UNetModel:
             cfg.attention_resolutions[i] = a
         cfg.num_head_channels, cfg.max_batch, cfg.numerics = self.num_head_channels, self.max_batch, self.numerics
         h = C.c_void_p()
-        _lib.check(L.ddmi_unet_create(C.byref(cfg), C.byref(h)))
+        _lib.check(self._create(L, cfg, h))
         try:
             _lib.load_weights(L.ddmi_unet_load_weight, h, self._state)
             _lib.check(L.ddmi_unet_finalize(h))
@@ -183,6 +183,9 @@ class UNetModel:
         if getattr(self, "_uniform_t", False):
             _lib.check(L.ddmi_unet_set_uniform_t(h, 1))
         return self
+
+    def _create(self, L, cfg, h):
+        return L.ddmi_unet_create(C.byref(cfg), C.byref(h))
 
     def memory(self):
         out = (C.c_uint64 * 3)()

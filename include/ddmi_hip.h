@@ -168,6 +168,61 @@ int ddmi_hdpe_mlp3d(ddmi_mlp3d* h, const void* const* planes, const int* plane_h
 int ddmi_mlp3d_destroy(ddmi_mlp3d* h);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Video (SkyTimelapse) path.  A latent is a token sequence [B, C, L], L = s1*s2 + s1*s3 + s2*s3, holding the planes
+ * xy = [s1,s2] | xt = [s3,s1] | yt = [s3,s2] back to back (models/ldm/modules/diffusionmodules/openaimodel.py:1141-1143).
+ *
+ * Tri-plane UNet: replaces UNetModel_Triplane.forward (openaimodel.py:1113-1221): the UNetModel blocks on each plane
+ * with shared weights + a 16-head 1-D attention over the concatenated tokens after every block
+ * (make_attn('vanilla-1d-multihead') -> MemoryEfficientAttnBlock1D, models/d2c_vae/autoencoder_unet.py:404-468, with
+ * xformers.ops.memory_efficient_attention = softmax(q k^T / sqrt(head_dim)) v).  Keys: the UNetModel_Triplane state
+ * dict ("input_blocks.*", "input_attns.N.{norm,q,k,v,proj_out}.*", "mid_attn.*", "output_attns.N.*", ...).
+ * The handle type and every other call (load_weight, finalize, forward, set_uniform_t, memory, destroy) are the
+ * ddmi_unet_* ones; forward takes x / eps_out as [B, C, L].  cfg->image_size is ignored; size1 must equal size2.
+ * --------------------------------------------------------------------------------------------------------- */
+int ddmi_unet3_create(const ddmi_unet_cfg* cfg, int size1, int size2, int size3, ddmi_unet** out);
+
+/* Video decoder: replaces VITAutoencoder.decode (models/d2c_vae/autoencoder_vit.py:188-202) = post_xy / post_yt /
+ * post_xt 1x1 convs + VideoDecoder_light.forward (autoencoder_unet.py:1040-1144).  Keys: "post_{xy,yt,xt}.*",
+ * "decoder.*".  z [B, embed_dim, L] fp32 with s1 = s2 = resolution/8, s3 = frames.
+ * planes[plane*n_scales + scale], plane order (xy, yt, xt) = the tuple decode() returns, scales coarse -> fine;
+ * xy planes are [B,out_ch,P,P], yt / xt planes [B,out_ch,frames,P], in `layout`. */
+typedef struct ddmi_decoderv ddmi_decoderv;
+typedef struct {
+  int embed_dim, z_channels, resolution, frames, ch, num_res_blocks;
+  int n_mult;   int ch_mult[8];
+  int n_attn;   int attn_resolutions[8];
+  int n_hdbf;   int hdbf_resolutions[8];
+  int n_inter;  int inter_attn_resolutions[8];
+  int attn_heads;              /* per-plane attention: 1 = attn_type 'vanilla', 16 = 'vanilla-multihead' */
+  int max_batch;
+  int numerics;
+} ddmi_decoderv_cfg;
+int ddmi_decoderv_create(const ddmi_decoderv_cfg* cfg, ddmi_decoderv** out);
+int ddmi_decoderv_load_weight(ddmi_decoderv* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_decoderv_finalize(ddmi_decoderv* h);
+/* n scales; plane_hw[0..3] = P of each scale; out_ch of the planes */
+int ddmi_decoderv_num_scales(ddmi_decoderv* h, int* n, int plane_hw[4], int* out_ch);
+int ddmi_decoderv_forward(ddmi_decoderv* h, const float* z, void* const* planes, int layout, int B, void* stream);
+int ddmi_decoderv_destroy(ddmi_decoderv* h);
+
+/* Fused tri-plane sampling + video MLP: replaces MLPVideo.forward (models/d2c_vae/mlp.py:128-157):
+ * triplane_positional_encoding(mode='concat') (utils/general_utils.py:134-145: three bilinear grid_samples,
+ * align_corners=True, border, broadcast over (t,h,w) and channel-concatenated) at 3 scales + 4 ResnetBlockFC
+ * (blocks.py:673-716) + Linear(leaky_relu(x, 0.2)).
+ * planes[9] as ddmi_decoderv_forward returns them, plane_hw[3] = P per scale, frames = height of the yt / xt planes;
+ * coords_xy [2,H,W], coords_yt [2,T,H], coords_xt [2,T,W] fp32: the grids of convert_to_coord_format_3d (channel 0
+ * is handed to grid_sample as the plane's width coordinate, exactly as the reference does);
+ * video_out [B, out_ch, T, H, W] fp32. */
+typedef struct ddmi_mlpv ddmi_mlpv;
+int ddmi_mlpv_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlpv** out);   /* in_ch 2, out_ch 3, ch 256, latent_dim 64 */
+int ddmi_mlpv_load_weight(ddmi_mlpv* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int ddmi_mlpv_finalize(ddmi_mlpv* h);
+int ddmi_hdpe_mlpv(ddmi_mlpv* h, const void* const* planes, const int* plane_hw, int frames, int layout,
+                   const float* coords_xy, const float* coords_yt, const float* coords_xt, float* video_out, int B,
+                   int T, int H, int W, void* stream);
+int ddmi_mlpv_destroy(ddmi_mlpv* h);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Diagnostic single-op entry points (used by the parity tests; reference-layout tensors in, reference-layout
  * tensors out; they allocate temporaries and synchronise - not for the hot path).
  * --------------------------------------------------------------------------------------------------------- */

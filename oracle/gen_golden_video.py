@@ -26,12 +26,12 @@ from ddmi_amd import initweights as iw  # noqa: E402
 
 OUT = G.OUT
 
-TOY_UNET_V = dict(in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[2],
+TOY_UNET_V = dict(in_channels=8, model_channels=32, out_channels=8, num_res_blocks=1, attention_resolutions=[2],
                   channel_mult=[1, 2], num_head_channels=16, size1=8, size2=8, size3=4)
-TOY_DDV = dict(double_z=True, timesformer_channels=32, splits=1, patch_size=8, resolution=64, z_channels=4, in_channels=3,
+TOY_DDV = dict(double_z=True, timesformer_channels=32, splits=1, patch_size=8, resolution=64, z_channels=8, in_channels=3,
                out_ch=64, ch=32, ch_mult=[1, 1, 2, 2], num_res_blocks=1, attn_resolutions=[], hdbf_resolutions=[32, 16],
                inter_attn_resolutions=[8, 16, 32, 64], dropout=0.0, attn_type="vanilla-multihead")
-TOY_EMBED_V, TOY_FRAMES = 4, 4
+TOY_EMBED_V, TOY_FRAMES = 8, 4
 MLPV_CFG = dict(in_ch=2, out_ch=3, ch=256, latent_dim=64)
 
 
@@ -79,7 +79,7 @@ def main():
     unet = UNetModel_Triplane(**TOY_UNET_V)
     manifests["V1.unet3"] = G.load_named(unet, "V1.unet3")
     L = TOY_UNET_V["size1"] * TOY_UNET_V["size2"] + 2 * TOY_UNET_V["size1"] * TOY_UNET_V["size3"]
-    x = iw.normal("V1", "x", (2, 4, L))
+    x = iw.normal("V1", "x", (2, 8, L))
     v1 = {"x": x}
     for name, ts in (("t7", [7, 7]), ("t3_11", [3, 11])):
         v1[name] = np32(unet(torch.from_numpy(x), torch.tensor(ts, dtype=torch.long)))
@@ -109,14 +109,14 @@ def main():
 
     # ---------------- V4: whole video chain (tools/ldm/video.py:214-230) --------------------------------
     v4 = {}
-    shape = [1, 4, L]
+    shape = [1, 8, L]
     xT = iw.normal("V4", "x_T", shape)
     v4["x_T"] = xT
     for name, T, S, eta in (("ddim_eta0", 20, 4, 0.0), ("anc", 5, 5, 1.0)):
-        d = DDPM(model=unet, timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta, channels=4, domain="video")
-        assert tuple(d.mixing_logit.shape) == (1, 4, 1)
-        manifests.setdefault("V4.ddpm_extra", {"mixing_logit": [1, 4, 1]})
-        d.mixing_logit.data.copy_(torch.from_numpy(iw.fill_state("V4.ddpm", [("mixing_logit", (1, 4, 1))])["mixing_logit"]))
+        d = DDPM(model=unet, timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta, channels=8, domain="video")
+        assert tuple(d.mixing_logit.shape) == (1, 8, 1)
+        manifests.setdefault("V4.ddpm_extra", {"mixing_logit": [1, 8, 1]})
+        d.mixing_logit.data.copy_(torch.from_numpy(iw.fill_state("V4.ddpm", [("mixing_logit", (1, 8, 1))])["mixing_logit"]))
         ndraw = S - 1 if S < T else T
         draws = [iw.normal("V4", f"{name}.n{i}", shape) for i in range(ndraw)]
         with G.DrawQueue(draws).patched():

@@ -64,7 +64,7 @@ def test_generate_video_chain(golden, name, T, S, eta):
     shape = v4["x_T"].shape
     ndraw = S - 1 if S < T else T
     draws = [iw.normal("V4", f"{name}.n{i}", shape) for i in range(ndraw)]
-    logit = torch.from_numpy(iw.fill_state("V4.ddpm", [("mixing_logit", (1, 4, 1))])["mixing_logit"])
+    logit = torch.from_numpy(iw.fill_state("V4.ddpm", [("mixing_logit", (1, 8, 1))])["mixing_logit"])
     out = O.generate_video(vstate(golden, "V1.unet3"), cfgs["TOY_UNET_V"], vstate(golden, "V2.vit"), cfgs["TOY_DDV"],
                            cfgs["TOY_FRAMES"], vstate(golden, "V3.mlpv"), O.make_schedule(T), logit,
                            torch.from_numpy(v4["x_T"]), draws, T, S, eta, toy_coords(golden))
