@@ -81,3 +81,104 @@ def test_generate_video_chain_golden(golden, name, T, S, eta):
     mlp = make(MLPVideo, "V3.mlpv", "fp32", **cfgs["MLPV_CFG"])
     vid = mlp(toy_coords(cfgs), vit.decode(z)).clamp(-1.0, 1.0)
     assert rel_err(vid, v4[f"{name}.video"]) < TOL_FP32
+
+
+# ---------------- SkyTimelapse shapes against the CPU oracle (same named-seed weights) -----------------------------
+def test_sky_unet_full_size_vs_oracle():
+    from helpers import SKY_UNET
+    from oracle import ddmi_oracle as O
+    unet32 = UNetModel_Triplane(numerics="fp32", max_batch=1, **SKY_UNET)
+    st = named_state("sky.unet3", unet32.manifest())
+    unet32.load_state_dict(st)
+    x = iw.normal("sky", "x", (1, 64, 2048))
+    t = torch.tensor([437], dtype=torch.int64)
+    ref = O.unet_triplane_forward(O.to_state(st), SKY_UNET, torch.from_numpy(x), t)
+    eps32 = unet32(torch.from_numpy(x).to(DEV), t.to(DEV))
+    assert rel_err(eps32, ref) < TOL_FP32
+    del unet32
+    torch.cuda.empty_cache()
+    unet16 = UNetModel_Triplane(numerics="bf16", max_batch=1, **SKY_UNET)
+    unet16.load_state_dict(st)
+    eps16 = unet16(torch.from_numpy(x).to(DEV), t.to(DEV))
+    assert rel_err(eps16, ref) < TOL_BF16
+
+
+def test_sky_decoder_quarter_resolution_vs_oracle():
+    """VideoDecoder_light with the real widths / heads / 16 frames at resolution 64 (latent 8x8 + 2 x 16x8): the largest
+    size whose 8-head attention matrices (6144^2 at the top level) the CPU oracle can hold."""
+    from helpers import SKY_DD, SKY_EMBED, SKY_FRAMES
+    from oracle import ddmi_oracle as O
+    dd = dict(SKY_DD, resolution=64, hdbf_resolutions=[32, 16], inter_attn_resolutions=[8, 16, 32, 64])
+    vit = VITAutoencoder(dd, SKY_EMBED, SKY_FRAMES, numerics="fp32", max_batch=1)
+    st = named_state("sky.vit", vit.manifest())
+    vit.load_state_dict(st)
+    z = iw.normal("sky", "z64", (1, SKY_EMBED, vit.seq_len))
+    ref = O.vit_decode(O.to_state(st), dd, SKY_FRAMES, torch.from_numpy(z))
+    got = vit.decode(torch.from_numpy(z).to(DEV), reference_layout=True)
+    for lst_g, lst_r in zip(got, ref):
+        for g, r in zip(lst_g, lst_r):
+            assert tuple(g.shape) == tuple(r.shape)
+            assert rel_err(g, r) < TOL_FP32
+    vit16 = VITAutoencoder(dd, SKY_EMBED, SKY_FRAMES, numerics="bf16", max_batch=1)
+    vit16.load_state_dict(st)
+    got16 = vit16.decode(torch.from_numpy(z).to(DEV), reference_layout=True)
+    for lst_g, lst_r in zip(got16, ref):
+        for g, r in zip(lst_g, lst_r):
+            assert rel_err(g, r) < TOL_BF16
+
+
+def test_attention_at_the_full_video_length_sampled_queries():
+    """The decoder's last inter-plane attention: 73 728 tokens (256^2 + 2 x 16 x 256), 8 heads of 64 channels.  The
+    full score matrix is 174 GB in fp32, so the oracle side is evaluated for a sample of query rows only."""
+    import ctypes as C
+    from ddmi_amd import _lib
+    heads, d, N = 8, 64, 256 * 256 + 2 * 16 * 256
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn((1, heads * d, N), generator=g) * 0.7
+    k = torch.randn((1, heads * d, N), generator=g) * 0.7
+    v = torch.randn((1, heads * d, N), generator=g)
+    out = torch.empty((1, heads * d, N), device=DEV, dtype=torch.float32)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    _lib.init_device(0)
+    _lib.check(_lib.lib().ddmi_op_attention_mh(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), 1, heads, d, N,
+                                              256 * 256, 16 * 256, _lib.numerics_code("bf16")))
+    out = out.cpu()
+    rows = torch.tensor([0, 1, 63, 64, 4097, 65535, 65536, 65537, 69631, 69632, 73727, 31337, 12345, 50000, 70000, 255])
+    qh = q[0].reshape(heads, d, N)[:, :, rows].permute(0, 2, 1)        # [H, R, d]
+    kh = k[0].reshape(heads, d, N)
+    vh = v[0].reshape(heads, d, N).permute(0, 2, 1)                    # [H, N, d]
+    w = torch.softmax(torch.matmul(qh, kh) * d ** -0.5, dim=-1)        # [H, R, N]
+    ref = torch.matmul(w, vh)                                          # [H, R, d]
+    got = out[0].reshape(heads, d, N)[:, :, rows].permute(0, 2, 1)
+    assert rel_err(got, ref) < 4e-2
+
+
+def test_sky_full_size_decode_and_mlp_run():
+    """Full-size VITAutoencoder.decode + MLPVideo in perf mode (B = 1): shapes, finiteness and the value range; the
+    arithmetic itself is pinned by the tests above (no CPU oracle can hold this size)."""
+    import time
+    from helpers import SKY_DD, SKY_EMBED, SKY_FRAMES
+    from ddmi_amd.video import video_generation_coords
+    vit = VITAutoencoder(SKY_DD, SKY_EMBED, SKY_FRAMES, numerics="bf16", max_batch=1)
+    vit.load_state_dict(named_state("sky.vit", vit.manifest()))
+    mlp = MLPVideo(numerics="bf16")
+    mlp.load_state_dict(named_state("sky.mlpv", mlp.manifest()))
+    z = torch.from_numpy(iw.normal("sky", "z", (1, SKY_EMBED, vit.seq_len))).to(DEV)
+    coords = video_generation_coords(256, 16)
+    hdbf = vit.decode(z)  # warm-up (autotune, lazy module load)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    hdbf = vit.decode(z)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    vid = mlp(coords, hdbf)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    print("sky decode %.1f ms, mlpvideo %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    assert [tuple(p.shape) for p in hdbf[0]] == [(1, 64, 64, 64), (1, 64, 128, 128), (1, 64, 256, 256)]
+    assert [tuple(p.shape) for p in hdbf[1]] == [(1, 64, 16, 64), (1, 64, 16, 128), (1, 64, 16, 256)]
+    assert tuple(vid.shape) == (1, 3, 16, 256, 256)
+    assert bool(torch.isfinite(vid).all())
+    for lst in hdbf:
+        for p in lst:
+            assert bool(torch.isfinite(p.float()).all())
