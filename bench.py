@@ -75,8 +75,10 @@ def pmc_traffic(live_name):
     if m:
         bm, bn, kk, nst = (int(v) for v in m.groups())
         pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}>")
+    elif m2 and m2.group(1) == "halo":  # conv_halo_kernel<BN, WM, WN>: BM is fixed at 256
+        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, ")
     elif m2:
-        pat = re.compile(rf"conv_{m2.group(1)}_kernel<{m2.group(2)}, {m2.group(3)}, ")
+        pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
         return None
     with open(files[-1]) as f:
