@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include <math.h>
+#include <cstdlib>
 
 #define ATT_QB 64   // queries per workgroup
 
@@ -267,6 +268,222 @@ __global__ void __launch_bounds__(256) attention_mh_kernel(AttnArgs a) {
   }
 }
 
+// =====================================================================================================
+// bf16 production variant for head dims <= 128 (every attention of the image UNet and of the video UNet, and the
+// decoder's 64- and 128-channel levels).  Same query-on-lane formulation as above, plus:
+//   * QF fragments of 16 queries per wave (QF = 2: 128 queries per workgroup) - every K fragment read from LDS feeds
+//     QF MFMAs, halving LDS traffic per FLOP;
+//   * V stays ROW-major in LDS ([key][channel], written with one 16-byte store per thread like K) and the V^T
+//     A-operand is fetched with ds_read_b64_tr_b16 (hardware 4 x 16 transpose per 16-lane group) - the generic
+//     kernel's eight 2-byte transposed stores per vector are gone;
+//   * the next K/V tile is prefetched global -> registers while the current one is consumed, and written to the other
+//     LDS buffer afterwards: one barrier per tile, HBM/L2 latency off the critical path;
+//   * the softmax scale is folded into the exp2 argument (one FMA per score).
+// V swizzle (16-byte chunk index ^ 2*f(key)) keeps the tr reads of a 32-lane half (8 keys x 32 bytes) on distinct banks.
+// =====================================================================================================
+template <int D> __device__ __forceinline__ int att_vswz(int key) {
+  if constexpr (D == 32) return 2 * ((key >> 2) & 1);
+  else if constexpr (D == 64) return 2 * ((key >> 1) & 3);
+  else return 2 * (key & 7);
+}
+
+template <int D, int QF>
+__global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
+  using T = bf16_t;
+  constexpr int KT = 64, RB = D * 2, TILE = KT * RB;
+  constexpr int SL = D / 8;                 // 16-byte slots per row
+  constexpr int NV = KT * SL / 256;         // staging vectors per thread per operand
+  constexpr int NKK = D / 32, NDF = D / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  unsigned char* const ks = att_smem;               // [2][KT][RB]
+  unsigned char* const vs = att_smem + 2 * TILE;    // [2][KT][RB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+  const int d = a.d;
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  const float sscale = a.scale * 1.44269504088896341f;
+
+  // ---- Q fragments ------------------------------------------------------------------------------------
+  bf16x8 qb[QF][NKK];
+  bool q_ok[QF];
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    const int q_idx = blockIdx.x * (64 * QF) + (wave * QF + qf) * 16 + lr;
+    q_ok[qf] = q_idx < N;
+    int seg = 0;
+    int64_t r = att_row(a, b, q_ok[qf] ? q_idx : 0, &seg);
+    const T* qp = (const T*)a.qkv[seg] + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+      qb[qf][kk] = q_ok[qf] && kk * 32 + 8 * lg < d ? *reinterpret_cast<const bf16x8*>(qp + kk * 32 + 8 * lg) : bf16x8{};
+  }
+
+  // ---- staging: thread owns NV (key, slot) vectors of every tile ------------------------------------------
+  bf16x8 kreg[NV], vreg[NV];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int idx = tid + it * 256;
+      const int key = idx / SL, slot = idx - key * SL;
+      int kg = kt * KT + key;
+      kg = kg < N ? kg : N - 1;  // rows past the end repeat the last key: finite data, scores masked below
+      int seg = 0;
+      int64_t r = att_row(a, b, kg, &seg);
+      const T* base = (const T*)a.qkv[seg] + r * a.ld_qkv + h * a.hs_qkv + slot * 8;
+      const bool cok = slot * 8 < d;
+      kreg[it] = cok ? *reinterpret_cast<const bf16x8*>(base + a.k_off) : bf16x8{};
+      vreg[it] = cok ? *reinterpret_cast<const bf16x8*>(base + a.v_off) : bf16x8{};
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int idx = tid + it * 256;
+      const int key = idx / SL, slot = idx - key * SL;
+      *reinterpret_cast<bf16x8*>(ks + buf * TILE + key * RB + att_swz<D>(key, slot) * 16) = kreg[it];
+      *reinterpret_cast<bf16x8*>(vs + buf * TILE + key * RB + ((slot ^ att_vswz<D>(key)) << 4)) = vreg[it];
+    }
+  };
+
+  float m_run[QF], l_run[QF];
+  f32x4 o[QF][NDF];
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    m_run[qf] = -INFINITY;
+    l_run[qf] = 0.f;
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+  }
+  // transposed-read lane constants: lane 4q+p of a 16-lane group addresses key row q, 4 channels at 4p
+  const int tq = lr >> 2, tp = lr & 3;
+  const int vkey = 4 * lg + tq;                       // key inside an aligned 16-key block
+  const int vsw = att_vswz<D>(vkey);                  // (the swizzle depends on key & 7 / (key>>1)&3 / (key>>2)&1 only)
+  const int vbase = vkey * RB + (tp & 1) * 8;
+
+  const int ntiles = (N + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  if (ntiles > 1) load_tile(1);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    const unsigned char* kb = ks + buf * TILE;
+    const unsigned char* vb = vs + buf * TILE;
+    // ---- S^T = K . Q^T -----------------------------------------------------------------------------
+    f32x4 sc[QF][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int row = 16 * f + lr;
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) sc[qf][f] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * RB + att_swz<D>(row, 4 * kk + lg) * 16);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[qf][kk], sc[qf][f], 0, 0, 0);
+      }
+    }
+    // ---- the other buffer is free (everyone passed the barrier that ended tile kt-1): park tile kt+1 there and
+    //      start fetching tile kt+2 ----------------------------------------------------------------------
+    if (kt + 1 < ntiles) {
+      store_tile(buf ^ 1);
+      if (kt + 2 < ntiles) load_tile(kt + 2);
+    }
+    // ---- online softmax (base 2, scale folded into the exponent) -----------------------------------------
+    const bool tail = (kt + 1) * KT > N;
+    bf16x8 pf[QF][2];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (tail && kt * KT + 16 * f + 4 * lg + j >= N) sc[qf][f][j] = -INFINITY;
+          tmax = fmaxf(tmax, sc[qf][f][j]);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run[qf], tmax * sscale);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qf] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qf][f][j], sscale, -m_new));
+          psum += p;
+          pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)p;
+        }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      l_run[qf] = l_run[qf] * alpha + psum;
+      m_run[qf] = m_new;
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+    }
+    // ---- O^T += V^T . P^T, V^T fragments by transposed LDS reads -------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) {
+        const int coff = ((2 * df + (tp >> 1)) ^ vsw) << 4;
+        // whole-vector reinterpretation: an element-wise bit_cast short -> bf16 is folded by hipcc 7.2 into a splat
+        // of element 0 (seen in the ISA as v_perm + v_mov of the low dword), which silently drops three of four keys
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + vbase + (32 * u) * RB + coff));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + vbase + (32 * u + 16) * RB + coff));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) o[qf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][df], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // tile kt consumed by everyone; tile kt+1 visible
+  }
+
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    const int q_idx = blockIdx.x * (64 * QF) + (wave * QF + qf) * 16 + lr;
+    if (!q_ok[qf]) continue;
+    const float inv = 1.0f / l_run[qf];
+    int seg = 0;
+    int64_t r = att_row(a, b, q_idx, &seg);
+    T* op = (T*)a.out[seg] + r * a.ld_out + h * a.hs_out;
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) {
+      const int c0 = 16 * df + 4 * lg;
+      if (c0 >= d) continue;
+      f32x4 v = o[qf][df] * inv;
+      bf16x4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x4*>(op + c0) = t;
+    }
+  }
+}
+
+template <int D, int QF>
+static int launch_attention_v2(const AttnArgs& a, hipStream_t s) {
+  constexpr int lds = 4 * 64 * D * 2;
+  auto kern = attention_v2_kernel<D, QF>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  dim3 grid(cdiv(N, 64 * QF), a.B * a.heads);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <typename T, int D, int DV, int KT>
 static int launch_attention_t(const AttnArgs& a, hipStream_t s) {
   constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -296,6 +513,13 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
               a.v_off % vn == 0 && a.ld_out % 4 == 0 && a.hs_out % 4 == 0) ? 1 : 0;
   PROF_SCOPE(a.legacy_name ? "attention_legacy" : "attention_mh", 4.0 * a.B * a.heads * (double)N * N * a.d,
              4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
+  static const int use_v2 = getenv("DDMI_ATTN_V1") ? 0 : 1;  // diagnostics: DDMI_ATTN_V1=1 pins the generic kernel
+  if (dt == DT_BF16 && a.vec_ok && a.d % 4 == 0 && a.d <= 128 && use_v2) {
+    const bool big = N >= 128;
+    if (a.d <= 32) return big ? launch_attention_v2<32, 2>(a, s) : launch_attention_v2<32, 1>(a, s);
+    if (a.d <= 64) return big ? launch_attention_v2<64, 2>(a, s) : launch_attention_v2<64, 1>(a, s);
+    return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);
+  }
   if (dt == DT_BF16) {
     if (a.d <= 32) return launch_attention_t<bf16_t, 32, 32, 64>(a, s);
     if (a.d <= 64) return launch_attention_t<bf16_t, 64, 64, 64>(a, s);
