@@ -102,3 +102,91 @@ class ImagePipeline:
         img = self.mlp(self.coords(), hdbf=planes, si=get_scale_injection(self.test_resolution))
         img = img.clamp_(-1.0, 1.0)
         return (img, z) if return_latent else img
+
+
+class VideoPipeline:
+    """tools/ldm/video.py:214-236 (`LDMTrainer.generate`, video domain): sample([B, C, L]) -> VITAutoencoder.decode ->
+    MLPVideo(coords, planes) -> clamp -> [B, 3, frames, R, R].  Construction mirrors exp/stage.py:245-262."""
+
+    def __init__(self, unetconfig: Mapping, ddconfig: Mapping, mlpconfig: Mapping, ddpmconfig: Mapping, embed_dim: int,
+                 frames: int = 16, test_resolution: int = 256, numerics: str = "bf16", max_batch: int = 2,
+                 device: str = "cuda:0"):
+        from .video import MLPVideo, UNetModel_Triplane, VITAutoencoder
+        self.device = device
+        self.numerics = numerics
+        self.max_batch = int(max_batch)
+        self.unet = UNetModel_Triplane(**dict(unetconfig), numerics=numerics, max_batch=max_batch)
+        self.vae = VITAutoencoder(ddconfig, embed_dim, frames, numerics=numerics, max_batch=max_batch)
+        self.mlp = MLPVideo(**dict(mlpconfig), numerics=numerics)
+        cfg = dict(ddpmconfig)
+        cfg["domain"] = "video"
+        self.ddpm = DDPM(model=self.unet, **cfg)
+        self.embed_dim = int(embed_dim)
+        self.frames = int(frames)
+        self.test_resolution = int(test_resolution)
+        assert self.unet.seq_len == self.vae.seq_len, "unetconfig sizes and ddconfig resolution / frames disagree"
+        self._coords = None
+
+    def load_named_seed(self, tag: str = "sky"):
+        self.unet.load_state_dict(initweights.fill_state(tag + ".unet3", self.unet.manifest()))
+        self.vae.load_state_dict(initweights.fill_state(tag + ".vit", self.vae.manifest()))
+        self.mlp.load_state_dict(initweights.fill_state(tag + ".mlpv", self.mlp.manifest()))
+        self.ddpm.load_state_dict({"mixing_logit": initweights.fill_state(tag + ".ddpm", [("mixing_logit", (1, self.ddpm.channels, 1))])["mixing_logit"]},
+                                  strict=False)
+        return self
+
+    def load_checkpoint(self, path: str, use_ema: bool = True):
+        """`ldm-last.pt` as written by tools/ldm/video.py:93-109 (same keys as the image trainer)."""
+        import torch
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.vae.load_state_dict(ck["vaemodel"], strict=False)   # encoder / TimeSformer entries are not on this path
+        self.mlp.load_state_dict(ck["mlp"], strict=True)
+        diff = ck["diffusion"]
+        if use_ema and "ema" in ck:
+            ema = {k[len("ema_model."):]: v for k, v in ck["ema"].items() if k.startswith("ema_model.")}
+            if ema:
+                diff = ema
+        diff = {k: v for k, v in diff.items() if k != "lvlb_weights" and k != "logvar"}
+        self.ddpm.load_state_dict(diff, strict=True)
+        return self
+
+    def finalize(self):
+        idx = int(str(self.device).split(":")[1]) if ":" in str(self.device) else 0
+        self.unet.finalize(idx)
+        self.unet.set_uniform_t(True)
+        self.vae.finalize(idx)
+        self.mlp.finalize(idx)
+        return self
+
+    def coords(self):
+        if self._coords is None:
+            from .video import video_generation_coords
+            self._coords = video_generation_coords(self.test_resolution, self.frames)
+        return self._coords
+
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False):
+        """Finished clips for the given GLOBAL sample indices; per-sample generators as in ImagePipeline.generate."""
+        import torch
+        B = len(indices)
+        dev = torch.device(self.device)
+        shape = (B, self.embed_dim, self.unet.seq_len)
+        gens = []
+        for i in indices:
+            g = torch.Generator(device=dev)
+            g.manual_seed(sample_seed(base_seed, i))
+            gens.append(g)
+        buf = torch.empty(shape, device=dev, dtype=torch.float32)
+
+        def draw(_step):
+            for j, g in enumerate(gens):
+                torch.randn(shape[1:], generator=g, out=buf[j])
+            return buf
+
+        x_T = draw(-1).clone()
+        z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
+        outs = []
+        for b0 in range(0, B, self.vae.max_batch):  # decode in slices: the 73k-token attention buffers are per sample
+            zz = z[b0:b0 + self.vae.max_batch].contiguous()
+            outs.append(self.mlp(self.coords(), self.vae.decode(zz)).clamp_(-1.0, 1.0))
+        vid = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        return (vid, z) if return_latent else vid

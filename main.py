@@ -2,7 +2,7 @@
 """Entry point with the reference's surface: `python main.py --exp ldm --configs configs/ldm/afhq.yaml [--seed 777]`
 (reference main.py:54-65), also under `accelerate launch` / `torch.distributed.run` (one process per GPU).
 
-Only the generation path is implemented (`data.mode: gen | eval` of the `ldm` experiment, image domain): gen writes a
+Only the generation path is implemented (`data.mode: gen | eval` of the `ldm` experiment, image and video domains): gen writes a
 grid of `test_batch_size` samples like tools/ldm/image.py:225-249; eval runs the sample-parallel 10k-image loop of
 evals/eval.py:215-234 (images written as PNG shards; Inception scoring needs downloaded weights and is out of scope).
 """
@@ -24,30 +24,40 @@ def main(args):
     from ddmi_amd.pipeline import ImagePipeline
 
     args = load_ldm_args(args.configs, args)
-    if args.domain != "image" or args.DiT:
-        raise SystemExit(f"domain '{args.domain}' / DiT are later rows of the scope table")
+    if args.domain not in ("image", "video") or args.DiT:
+        raise SystemExit(f"domain '{args.domain}' / DiT: use ddmi_amd.occupancy for occupancy; DiT is out of scope")
     random_seed(args.seed)
     rank, local_rank, world = D.init_process_group()
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     dc = args.data_config
     B = int(dc.test_batch_size)
-    pipe = ImagePipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
-                         test_resolution=int(dc.test_resolution), numerics=args.numerics, max_batch=B, device=dev)
+    if args.domain == "video":  # exp/stage.py:245-262, tools/ldm/video.py:214-236
+        from ddmi_amd.pipeline import VideoPipeline
+        pipe = VideoPipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
+                             frames=int(dc.get("frames", 16)), test_resolution=int(dc.test_resolution),
+                             numerics=args.numerics, max_batch=B, device=dev)
+    else:
+        pipe = ImagePipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
+                             test_resolution=int(dc.test_resolution), numerics=args.numerics, max_batch=B, device=dev)
     ckpt = os.path.join(dc.save_pth, "ldm-last.pt")
     if os.path.exists(ckpt):
         print("Loading Pretrained Models!")
         pipe.load_checkpoint(ckpt)
     else:
         print(f"{ckpt} not found: using named-seed synthetic weights")
-        pipe.load_named_seed("afhq")
+        pipe.load_named_seed("sky" if args.domain == "video" else "afhq")
     pipe.finalize()
     out_dir = os.path.join(dc.save_pth, "results")
     os.makedirs(out_dir, exist_ok=True)
     if args.mode == "gen":
         print("Random image generation!")
         img = D.generate_sharded(lambda idx: pipe.generate(idx, base_seed=args.seed), world * B, B, rank, world)
-        if rank == 0:
+        if rank == 0 and args.domain == "video":  # [N, 3, T, H, W] -> uint8 [N, T, H, W, 3] (tools/ldm/video.py:231-236 writes frames)
+            u8 = ((img + 1) / 2 * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 4, 1).cpu().numpy()
+            np.save(os.path.join(out_dir, "generation_video.npy"), u8)
+            print("Finished generating videos!")
+        elif rank == 0:
             u8 = ((img + 1) / 2 * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
             np.save(os.path.join(out_dir, "generation.npy"), u8)
             try:

@@ -182,3 +182,39 @@ def test_sky_full_size_decode_and_mlp_run():
     for lst in hdbf:
         for p in lst:
             assert bool(torch.isfinite(p.float()).all())
+
+
+def test_video_pipeline_matches_oracle_and_is_batch_invariant(golden):
+    """ddmi_amd.pipeline.VideoPipeline (tools/ldm/video.py:214-236) on the toy configuration, parity mode: the chain it
+    runs equals the oracle's chain fed with the same per-sample generator draws, and a sample does not depend on which
+    other samples share its batch."""
+    from ddmi_amd.dist import sample_seed
+    from ddmi_amd.pipeline import VideoPipeline
+    from oracle import ddmi_oracle as O
+    cfgs = golden.json("configs_video.json")
+    R, Tn = cfgs["TOY_DDV"]["resolution"], cfgs["TOY_FRAMES"]
+    T, S = 20, 4
+    ddpmconfig = dict(timesteps=T, sampling_timesteps=S, ddim_sampling_eta=0.5, channels=cfgs["TOY_EMBED_V"], domain="video")
+    pipe = VideoPipeline(cfgs["TOY_UNET_V"], cfgs["TOY_DDV"], cfgs["MLPV_CFG"], ddpmconfig, cfgs["TOY_EMBED_V"], frames=Tn,
+                         test_resolution=R, numerics="fp32", max_batch=2, device=DEV)
+    pipe.load_named_seed("toyv").finalize()
+    idx = [5, 9]
+    vid, z = pipe.generate(idx, base_seed=3, return_latent=True)
+    assert tuple(vid.shape) == (2, 3, Tn, R, R)
+    # replay the draws: x_T, then one draw per non-final DDIM step, per-sample device generators
+    shape1 = (cfgs["TOY_EMBED_V"], pipe.unet.seq_len)
+    gens = []
+    for i in idx:
+        g = torch.Generator(device=DEV)
+        g.manual_seed(sample_seed(3, i))
+        gens.append(g)
+    draws = [torch.stack([torch.randn(shape1, generator=g, device=DEV) for g in gens]).cpu() for _ in range(S)]
+    st = lambda tag, man: O.to_state(named_state(tag, man))
+    logit = torch.from_numpy(iw.fill_state("toyv.ddpm", [("mixing_logit", (1, cfgs["TOY_EMBED_V"], 1))])["mixing_logit"])
+    ref = O.generate_video(st("toyv.unet3", pipe.unet.manifest()), cfgs["TOY_UNET_V"], st("toyv.vit", pipe.vae.manifest()),
+                           cfgs["TOY_DDV"], Tn, st("toyv.mlpv", pipe.mlp.manifest()), O.make_schedule(T), logit, draws[0],
+                           draws[1:], T, S, 0.5, O.video_coords(R, Tn))
+    assert rel_err(z, ref["z"]) < TOL_FP32
+    assert rel_err(vid, ref["video"]) < TOL_FP32
+    solo = pipe.generate([9], base_seed=3)
+    assert rel_err(solo[0], vid[1]) < 1e-5
