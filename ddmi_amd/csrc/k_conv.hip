@@ -43,6 +43,7 @@ struct ConvK {
   int NS;       // total stages
   int SPS;      // stages per split
   int tiles_n;
+  int tile_map;                             // 0 row-major, 1 XCD-contiguous m-major, 2 XCD-contiguous n-major
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
   int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier
   float out_scale;
@@ -72,6 +73,30 @@ __device__ __forceinline__ int swz(int row, int slot) {
 
 #define OOB_OFFSET 0x80000000u
 
+// ---- blockIdx.x -> (tile_m, tile_n), XCD-aware ---------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MiB L2.  `tile_map` 1/2 gives the
+// workgroups of one XCD a CONTIGUOUS range of logical tile ids, walked m-major (1: neighbours share activation rows,
+// each XCD streams all weights) or n-major (2: neighbours share weights - the 8x8 / 16x16 levels whose weights
+// outweigh their activations), so an operand is pulled into one L2 instead of several.  0 = plain row-major.
+struct TileMN { int m, n; };
+__device__ __forceinline__ TileMN conv_tile_of_block(int tile_map, int tiles_n) {
+  int id = blockIdx.x;
+  if (tile_map) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = id & 7;
+    id = x * q + min(x, r) + (id >> 3);
+  }
+  TileMN t;
+  if (tile_map == 2) {
+    const int tiles_m = gridDim.x / tiles_n;
+    t.n = id / tiles_m;
+    t.m = id - t.n * tiles_m;
+  } else {
+    t.m = id / tiles_n;
+    t.n = id - t.m * tiles_n;
+  }
+  return t;
+}
+
 // ---- epilogue shared by both kernels: lane holds channels n..n+3 of pixel m for every (i, j) fragment ----------
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
@@ -84,6 +109,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
     int m = m_base + i * 16 + lr;
     if (m >= a.M) continue;
     int b = m / hw;
+    int be = b;  // embedding row: sample index modulo emb_mod (planes stacked <= 3x along the batch axis), no division
+    if (a.emb_mod) {
+      be -= be >= a.emb_mod ? a.emb_mod : 0;
+      be -= be >= a.emb_mod ? a.emb_mod : 0;
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       int n = n_base + j * 16 + lg * 4;
@@ -94,7 +124,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
         continue;
       }
       if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)(a.emb_mod ? b % a.emb_mod : b) * a.emb_stride + n);
+      if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)be * a.emb_stride + n);
       if (rg) {
         const T* p = rg + (int64_t)m * a.Cout + n;
         if constexpr (IS_BF16) {
@@ -158,7 +188,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const TileMN tmn = conv_tile_of_block(a.tile_map, a.tiles_n);
+  const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ktot = a.KH * a.KW * a.Cin;
   const int ush = a.ups == 1, usw = a.ups != 0;  // fused nearest upsample: 1 = x2 both axes, 2 = x2 along W only
@@ -339,7 +370,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const TileMN tmn = conv_tile_of_block(a.tile_map, a.tiles_n);
+  const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ktot = a.KH * a.KW * a.Cin;
   const int ush = a.ups == 1, usw = a.ups != 0;  // fused nearest upsample: 1 = x2 both axes, 2 = x2 along W only
@@ -363,7 +395,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   // slot - hence the channel offset - is ONE per-lane constant for every load of both operands.
   static_assert(NW % 2 == 0, "slot constant needs an even wave count");
   const int coff = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 8;
-  int a_ih0[A_PER], a_iw0[A_PER], a_pb[A_PER];  // invalid rows get ih0 = -2^20 so the bounds test rejects them
+  // one register per A row group (the kernel sits at the 256-VGPR limit): sample index relative to the tile's first
+  // sample << 24 | (ih0 + 0x400) << 12 | (iw0 + 0x400); invalid rows get an ih0 field of 0 = -0x400 -> bounds test fails
+  int a_row[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     int row = (i * NW + wave) * 8 + (lane >> 3);
@@ -372,17 +406,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     int b = ok ? m / hw : 0;
     int r = ok ? m - b * hw : 0;
     int oh = r / a.Wout, ow = r - oh * a.Wout;
-    a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
-    a_iw0[i] = ow * a.stride - a.pad;
-    a_pb[i] = ((ok ? b - b_first : 0) * a.Hin * a.Win * a.Cin + coff) * SZ;
+    int ih0 = ok ? oh * a.stride - a.pad + 0x400 : 0;
+    a_row[i] = ((ok ? b - b_first : 0) << 24) | (ih0 << 12) | (ow * a.stride - a.pad + 0x400);
   }
-  int b_base[B_PER];  // invalid rows: negative
-#pragma unroll
-  for (int i = 0; i < B_PER; ++i) {
-    int row = (i * NW + wave) * 8 + (lane >> 3);
-    int n = n0 + row;
-    b_base[i] = ((row < BN) && (n < a.Cout)) ? (n * Ktot + coff) * SZ : -1;
-  }
+  const int sample_bytes = a.Hin * a.Win * a.Cin * SZ, coff_b = coff * SZ;
+  // weight rows: group i of a wave sits 8*NW rows after group 0 - a scalar step, so one base register serves all
+  const int b_row0 = wave * 8 + (lane >> 3);
+  const int b_base0 = ((n0 + b_row0) * Ktot + coff) * SZ;
 
   // ---- wave-uniform walk over stages: (tap, 64-channel block) in tap-major or channel-major order ----------------
   const int s_begin = blockIdx.z * a.SPS;
@@ -403,10 +433,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     const int rowb = a.Cin * SZ, c0b = c0 * SZ;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      int ih = a_ih0[i] + q_kh, iw = a_iw0[i] + q_kw;
+      int ih = ((a_row[i] >> 12) & 0xFFF) + (q_kh - 0x400), iw = (a_row[i] & 0xFFF) + (q_kw - 0x400);
       int ok = cvalid & ((unsigned)ih < (unsigned)Hlim) & ((unsigned)iw < (unsigned)Wlim);
       ih >>= ush; iw >>= usw;
-      int off = a_pb[i] + (ih * a.Win + iw) * rowb + c0b;
+      int off = (int)((unsigned)a_row[i] >> 24) * sample_bytes + coff_b + (ih * a.Win + iw) * rowb + c0b;
       unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
       const int g = i * NW + wave;
       unsigned char* dst = g < GA ? sbase + g * 1024 : smem + SCRATCH + wave * 1024;
@@ -414,8 +444,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-      int ok = cvalid & (b_base[i] >= 0);
-      unsigned voff = ok ? (unsigned)(b_base[i] + b_delta) : OOB_OFFSET;
+      int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + b_row0 + i * 8 * NW < a.Cout);
+      unsigned voff = ok ? (unsigned)(b_base0 + i * 8 * NW * Ktot * SZ + b_delta) : OOB_OFFSET;
       const int g = i * NW + wave;
       unsigned char* dst = g < GB ? sbase + A_BYTES + g * 1024 : smem + SCRATCH + wave * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
@@ -505,7 +535,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
 }
 
 // =====================================================================================================
-// bf16 production kernel v3 ("halo") for 3x3 / stride 1 / pad 1 convolutions on W in {16, 32, 64}.
+// bf16 production kernel v3 ("halo") for 3x3 / stride 1 / pad 1 convolutions on W in {8, 16, 32, 64}.
 //
 // PMC counters of the pipe kernel: 456 MB fetched per launch against 70 MB of algorithmic reads - the nine taps re-read
 // every activation row and L2 does not absorb it.  Here a 256-pixel tile = TR whole rows of one sample, and for each
@@ -535,14 +565,19 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const TileMN tmn = conv_tile_of_block(a.tile_map, a.tiles_n);
+  const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int W = a.Win, H = a.Hin, hw = H * W;
   const int Ktot = 9 * a.Cin;
   const int NCB = (a.Cin + 63) >> 6;
-  const int TR = BM / W, HWd = W + 2, NH = (TR + 2) * HWd, GH = (NH + 7) >> 3;
+  // a tile is TR whole rows of ONE sample (hw >= 256), or SPT whole samples of RS = H rows each (hw = 64 / 128: the
+  // 8x8 level); every sample block carries its own one-pixel border, so the halo has SPT * (RS + 2) rows of W + 2
+  const int HWd = W + 2;
+  const int SPT = hw >= BM ? 1 : BM / hw, RS = hw >= BM ? BM / W : H;
+  const int HRS = (RS + 2) * HWd, NH = SPT * HRS, GH = (NH + 7) >> 3;
   const int b_first = m0 / hw;
-  const int ty0 = (m0 - b_first * hw) / W;
+  const int ty0 = hw >= BM ? (m0 - b_first * hw) / W : 0;
 
   const T* xg = (const T*)a.x + (int64_t)b_first * hw * a.Cin;
   const T* wg = (const T*)a.w;
@@ -558,11 +593,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   // halo group g: 8 halo rows hr = 8g + (lane>>3); the slot swizzle depends on hr, so the channel offset does too
   auto load_halo_group = [&](int g, int cb, int hbuf) {
     const int hr = g * 8 + (lane >> 3);
-    const int hy = hr / HWd, hx = hr - hy * HWd;
+    int sb = 0, rem = hr;                           // sample block of the tile, halo row inside it
+    if (SPT > 1) { sb = hr / HRS; rem = hr - sb * HRS; }
+    const int hy = rem / HWd, hx = rem - hy * HWd;
     const int iy = ty0 - 1 + hy, ix = hx - 1;
     const int ch = cb * 64 + (((lane & 7) ^ ((hr >> 1) & 7)) << 3);
     const int ok = (hr < NH) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W) & (ch < a.Cin);
-    const unsigned voff = ok ? (unsigned)(((iy * W + ix) * a.Cin + ch) * SZ) : OOB_OFFSET;
+    // samples past the batch end fall outside the descriptor's extent and read as zeros
+    const unsigned voff = ok ? (unsigned)(((sb * hw + iy * W + ix) * a.Cin + ch) * SZ) : OOB_OFFSET;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
   };
   auto load_b_stage = [&](int cb, int tap, int bbuf, bool valid) {
@@ -587,7 +625,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   {
     int m = wm * TM + lr;
     int ty = m / W, tx = m - ty * W;
-    hr00 = ty * HWd + tx;
+    int sb = SPT > 1 ? ty / RS : 0;  // a wave's TM = 64 pixels never straddle two samples (hw is a multiple of 64)
+    hr00 = sb * HRS + (ty - sb * RS) * HWd + tx;
   }
   const int woff0 = (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
   // `shift` = kh*(W+2) + kw moves every A fragment to the tap's halo row; it stays a loop-carried scalar so the
@@ -685,7 +724,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const TileMN tmn = conv_tile_of_block(a.tile_map, a.tiles_n);
+  const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ktot = a.KH * a.KW * a.Cin;
   const int ush = a.ups == 1, usw = a.ups != 0;  // fused nearest upsample: 1 = x2 both axes, 2 = x2 along W only
@@ -947,8 +987,12 @@ static const RingCfg kRing[] = {
     {256, 128, -2},  // 20: halo<128,4,2> 8 waves, per-wave 64x64,  131 KB
 };
 static bool halo_ok(const ConvArgs& a) {
-  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups &&
-         (a.Win == 16 || a.Win == 32 || a.Win == 64) && (a.Hin * a.Win) % 256 == 0 && a.Hout == a.Hin && a.Wout == a.Win;
+  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hout == a.Hin && a.Wout == a.Win)) return false;
+  if (!(a.Win == 8 || a.Win == 16 || a.Win == 32 || a.Win == 64)) return false;
+  const int hw = a.Hin * a.Win;
+  if (hw % 256 == 0) return true;                       // TR whole rows of one sample
+  if (hw != 64 && hw != 128) return false;              // whole samples per tile, 64 pixels per wave inside one sample
+  return (256 / hw) * (a.Hin + 2) * (a.Win + 2) <= HALO_MAX_ROWS;
 }
 static const int kHaloFallback = 13;
 static const int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
@@ -1184,6 +1228,15 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
   k.chan_major = a.order == 2 || (a.order == 0 && a.KH * a.KW > 1 && splitk == 1);
+  {
+    static const int env_map = getenv("DDMI_CONV_TILEMAP") ? atoi(getenv("DDMI_CONV_TILEMAP")) : 0;  // diagnostics
+    int tm = env_map ? env_map : a.tile_map;
+    if (tm == 0) {  // heuristic: keep the LARGER operand's reuse inside one XCD
+      const double act = (double)a.B * a.Hin * a.Win * a.Cin, wgt = (double)a.Cout * a.KH * a.KW * a.Cin;
+      tm = wgt > act ? 2 : 1;
+    }
+    k.tile_map = tm < 0 ? 0 : tm;
+  }
   DDMI_TRY(dispatch(k, t, dt, splitk, 1, s));
   if (splitk > 1) DDMI_TRY(launch_splitk_finish(a, dt, s));
   return DDMI_OK;

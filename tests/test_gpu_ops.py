@@ -99,6 +99,8 @@ VARIANT_CASES = [
     (1, 96, 32, 32, 160, 3, 1, 0),
     (1, 192, 64, 64, 224, 3, 1, 0),
     (2, 448, 8, 8, 224, 1, 1, 0),
+    (5, 128, 8, 8, 224, 3, 1, 0),     # 8x8 level: halo tiles of four whole samples, last tile runs past the batch
+    (3, 64, 8, 16, 96, 3, 1, 0),      # non-square plane (video xt / yt), two samples per tile
 ]
 _variant_cache = {}
 
