@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=777)
+    ap.add_argument("--rng", default="philox", choices=["philox", "torch"],
+                    help="per-chain noise: in-kernel Philox streams (default) or one torch generator per chain")
     args = ap.parse_args()
 
     import torch
@@ -132,7 +134,7 @@ def main():
         idx = [(step_idx * world + rank) * B + j for j in range(B)]  # disjoint global sample indices
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        img = pipe.generate(idx, base_seed=args.seed, events=ev[1:3])
+        img = pipe.generate(idx, base_seed=args.seed, events=ev[1:3], rng=args.rng)
         out = D.all_gather_samples(img, world)
         ev[3].record()
         phase["_ev"] = ev

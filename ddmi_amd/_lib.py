@@ -72,6 +72,8 @@ SYMBOLS = {
     "ddmi_unet_destroy": (_I, [_VP]),
     "ddmi_unet_memory": (_I, [_VP, C.POINTER(C.c_uint64 * 3)]),
     "ddmi_ddpm_step": (_I, [_VP, _VP, _VP, _VP, C.POINTER(StepCoefs), _I, _I, _VP, _VP, _I, _I, _I, _VP]),
+    "ddmi_ddpm_step_rng": (_I, [_VP, _VP, _VP, C.c_uint32, _VP, C.POINTER(StepCoefs), _I, _I, _VP, _VP, _I, _I, _I, _VP]),
+    "ddmi_randn_fill": (_I, [_VP, _VP, _I, C.c_int64, C.c_uint32, _VP]),
     "ddmi_decoder2d_create": (_I, [C.POINTER(Decoder2dCfg), C.POINTER(_VP)]),
     "ddmi_decoder2d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
     "ddmi_decoder2d_finalize": (_I, [_VP]),

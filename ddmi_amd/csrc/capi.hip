@@ -102,10 +102,11 @@ int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]) {
 }
 
 // ---- sampler step ---------------------------------------------------------------------------------------
-int ddmi_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
-                   const ddmi_step_coefs* c, int mode, int clip_denoised, float* x_out, float* x0_out, int B, int C,
-                   int HW, void* stream) {
+static int ddpm_step_impl(const float* x, const float* model_out, const float* noise, const uint64_t* seeds, unsigned tag,
+                          const float* mixing_logit, const ddmi_step_coefs* c, int mode, int clip_denoised, float* x_out,
+                          float* x0_out, int B, int C, int HW, void* stream) {
   DDMI_REQUIRE(c, "ddpm_step: null coefs");
+  DDMI_REQUIRE(seeds == nullptr || ((int64_t)C * HW) % 4 == 0, "ddpm_step_rng: C*HW must be a multiple of 4");
   StepCoefs k;
   k.sqrt_one_minus_ac = c->sqrt_one_minus_ac;
   k.sqrt_recip_ac = c->sqrt_recip_ac;
@@ -117,7 +118,21 @@ int ddmi_ddpm_step(const float* x, const float* model_out, const float* noise, c
   k.c_dir = c->c_dir;
   k.sigma = c->sigma;
   return launch_ddpm_step(x, model_out, noise, mixing_logit, k, mode, clip_denoised, x_out, x0_out, B, C, HW,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, seeds, tag);
+}
+int ddmi_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
+                   const ddmi_step_coefs* c, int mode, int clip_denoised, float* x_out, float* x0_out, int B, int C,
+                   int HW, void* stream) {
+  return ddpm_step_impl(x, model_out, noise, nullptr, 0, mixing_logit, c, mode, clip_denoised, x_out, x0_out, B, C, HW, stream);
+}
+int ddmi_ddpm_step_rng(const float* x, const float* model_out, const uint64_t* seeds, uint32_t tag,
+                       const float* mixing_logit, const ddmi_step_coefs* c, int mode, int clip_denoised, float* x_out,
+                       float* x0_out, int B, int C, int HW, void* stream) {
+  DDMI_REQUIRE(seeds, "ddpm_step_rng: null seeds");
+  return ddpm_step_impl(x, model_out, nullptr, seeds, tag, mixing_logit, c, mode, clip_denoised, x_out, x0_out, B, C, HW, stream);
+}
+int ddmi_randn_fill(float* out, const uint64_t* seeds, int B, int64_t n_per_sample, uint32_t tag, void* stream) {
+  return launch_randn_fill(out, seeds, B, n_per_sample, tag, (hipStream_t)stream);
 }
 
 // ---- decoder ----------------------------------------------------------------------------------------------

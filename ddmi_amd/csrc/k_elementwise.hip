@@ -9,13 +9,68 @@
 // algorithmic traffic with the write), keeps everything in registers.
 // Layout NCHW fp32 (the sampler state keeps the reference's layout); mixing_logit is [C].
 // =====================================================================================================
+// ---- counter-based noise: Philox4x32-10 (Salmon et al., SC'11) keyed by the SAMPLE's 64-bit seed ----------------------
+// normal(seed, tag, e) for element e of a sample depends on nothing else, so a chain's noise is the same whatever batch
+// or GPU it runs in (the sharding invariant of ddmi_amd/dist.py), and the sampler step can draw it in registers instead
+// of reading a [B, C, HW] tensor that 256 per-sample generator launches filled.  Counter = (e / 4, tag, 0x44444d49, 0);
+// `tag` = step index (0xFFFFFFFF for x_T).  Four uniforms -> four normals by Box-Muller.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void normal4(uint64_t seed, unsigned tag, unsigned quad, float (&z)[4]) {
+  unsigned r[4];
+  philox4x32_10(quad, tag, 0x44444d49u, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+  // u in (0, 1]: 24-bit mantissas, never 0 so the logarithm is finite
+  const float u0 = ((r[0] >> 8) + 1) * (1.0f / 16777216.0f), u1 = (r[1] >> 8) * (1.0f / 16777216.0f);
+  const float u2 = ((r[2] >> 8) + 1) * (1.0f / 16777216.0f), u3 = (r[3] >> 8) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincospif(2.0f * u1, &s0, &c0);
+  sincospif(2.0f * u3, &s1, &c1);
+  z[0] = ra * c0; z[1] = ra * s0; z[2] = rb * c1; z[3] = rb * s1;
+}
+
+// out[b][e] = normal(seeds[b], tag, e), e < n (n a multiple of 4)
+__global__ void __launch_bounds__(256) randn_fill_kernel(float* __restrict__ out, const uint64_t* __restrict__ seeds,
+                                                         int64_t nquad_per_sample, int64_t total_quads, unsigned tag) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_quads; i += stride) {
+    int64_t b = i / nquad_per_sample;
+    unsigned q = (unsigned)(i - b * nquad_per_sample);
+    float z[4];
+    normal4(seeds[b], tag, q, z);
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(z[0], z[1], z[2], z[3]);
+  }
+}
+
+int launch_randn_fill(float* out, const uint64_t* seeds, int B, int64_t n_per_sample, unsigned tag, hipStream_t stream) {
+  DDMI_REQUIRE(out && seeds && B > 0 && n_per_sample > 0, "randn_fill: bad arguments");
+  DDMI_REQUIRE(n_per_sample % 4 == 0 && n_per_sample / 4 <= 0xFFFFFFFFll, "randn_fill: elements per sample must be a multiple of 4");
+  int64_t nq = n_per_sample / 4, total = nq * B;
+  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 8);
+  hipLaunchKernelGGL(randn_fill_kernel, dim3(blocks), dim3(256), 0, stream, out, seeds, nq, total, tag);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(256) ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ mo,
                                                         const float* __restrict__ noise,
+                                                        const uint64_t* __restrict__ seeds, unsigned tag,
                                                         const float* __restrict__ logit, StepCoefs k, int mode, int clip,
                                                         float* __restrict__ out, float* __restrict__ x0_out, int C, int HW,
                                                         int64_t nvec) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t quads_per_sample = (int64_t)C * HW / 4;  // only used on the VEC == 4 path
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     int64_t e0 = i * VEC;
     float xv[VEC], mv[VEC], nv[VEC], ov[VEC], zv[VEC];
@@ -24,7 +79,14 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const float* __restrict_
       float4 b = *reinterpret_cast<const float4*>(mo + e0);
       xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
       mv[0] = b.x; mv[1] = b.y; mv[2] = b.z; mv[3] = b.w;
-      if (noise != nullptr && mode != STEP_DDIM_LAST) {
+      if (mode == STEP_DDIM_LAST) {
+        nv[0] = nv[1] = nv[2] = nv[3] = 0.f;
+      } else if (seeds != nullptr) {  // drawn in registers: same values as randn_fill(seeds, tag)
+        int64_t bs = i / quads_per_sample;
+        float z[4];
+        normal4(seeds[bs], tag, (unsigned)(i - bs * quads_per_sample), z);
+        nv[0] = z[0]; nv[1] = z[1]; nv[2] = z[2]; nv[3] = z[3];
+      } else if (noise != nullptr) {
         float4 c = *reinterpret_cast<const float4*>(noise + e0);
         nv[0] = c.x; nv[1] = c.y; nv[2] = c.z; nv[3] = c.w;
       } else {
@@ -70,22 +132,23 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const float* __restrict_
 
 int launch_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
                      StepCoefs k, int mode, int clip, float* x_out, float* x0_out, int B, int C, int HW,
-                     hipStream_t stream) {
+                     hipStream_t stream, const uint64_t* seeds, unsigned tag) {
   DDMI_REQUIRE(x && model_out && x_out, "ddpm_step: null tensor");
   DDMI_REQUIRE(mode >= 0 && mode <= 2, "ddpm_step: bad mode");
   DDMI_REQUIRE(B > 0 && C > 0 && HW > 0, "ddpm_step: bad shape");
   int64_t n = (int64_t)B * C * HW;
   bool vec4 = (HW % 4 == 0) && (((uintptr_t)x | (uintptr_t)model_out | (uintptr_t)noise | (uintptr_t)x_out |
                                  (uintptr_t)x0_out) % 16 == 0);
+  DDMI_REQUIRE(seeds == nullptr || vec4, "ddpm_step: in-kernel noise needs HW % 4 == 0 and 16-byte aligned tensors");
   int64_t nvec = vec4 ? n / 4 : n;
   int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 8);
   PROF_SCOPE("ddpm_step", 0, (noise && mode != STEP_DDIM_LAST ? 16.0 : 12.0) * (double)n, stream);
   if (vec4)
-    hipLaunchKernelGGL(ddpm_step_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, mixing_logit, k,
-                       mode, clip, x_out, x0_out, C, HW, nvec);
+    hipLaunchKernelGGL(ddpm_step_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, seeds, tag,
+                       mixing_logit, k, mode, clip, x_out, x0_out, C, HW, nvec);
   else
-    hipLaunchKernelGGL(ddpm_step_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, mixing_logit, k,
-                       mode, clip, x_out, x0_out, C, HW, nvec);
+    hipLaunchKernelGGL(ddpm_step_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, seeds, tag,
+                       mixing_logit, k, mode, clip, x_out, x0_out, C, HW, nvec);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

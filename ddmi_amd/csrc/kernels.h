@@ -15,9 +15,13 @@ struct StepCoefs {
 };
 enum { STEP_ANCESTRAL = 0, STEP_DDIM = 1, STEP_DDIM_LAST = 2 };
 
+// noise source: `seeds` != null -> drawn in registers (Philox keyed per sample, stream `tag`; needs C*HW % 4 == 0),
+// else `noise` != null -> read, else zero
 int launch_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
                      StepCoefs k, int mode, int clip, float* x_out, float* x0_out, int B, int C, int HW,
-                     hipStream_t stream);
+                     hipStream_t stream, const uint64_t* seeds = nullptr, unsigned tag = 0);
+// out[b][e] = the same normal(seeds[b], tag, e) the step kernel draws
+int launch_randn_fill(float* out, const uint64_t* seeds, int B, int64_t n_per_sample, unsigned tag, hipStream_t stream);
 
 // ---- layout / packing -----------------------------------------------------------------------------
 // fp32 [B, C, ld] (positions off .. off+HW of every channel row) <-> [B, HW, C] in the network dtype; ld = 0 means HW.

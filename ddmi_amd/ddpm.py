@@ -171,13 +171,30 @@ class DDPM:
             self._logit_dev = torch.from_numpy(self.mixing_logit.reshape(-1).copy()).to(device)
         return self._logit_dev.data_ptr()
 
-    def _step(self, x, model_out, noise, coefs, mode, out, clip):
+    def _step(self, x, model_out, noise, coefs, mode, out, clip, seeds=None, tag=0):
         B, Cc = x.shape[0], x.shape[1]
         hw = int(np.prod(x.shape[2:]))
+        if seeds is not None:  # noise drawn inside the kernel from the per-chain Philox streams
+            _lib.check(_lib.lib().ddmi_ddpm_step_rng(x.data_ptr(), model_out.data_ptr(), seeds.data_ptr(), int(tag),
+                                                     self._logit_ptr(x.device), C.byref(coefs), mode, int(clip),
+                                                     out.data_ptr(), None, B, Cc, hw, _lib.stream_ptr()))
+            return out
         _lib.check(_lib.lib().ddmi_ddpm_step(x.data_ptr(), model_out.data_ptr(),
                                              noise.data_ptr() if noise is not None else None,
                                              self._logit_ptr(x.device), C.byref(coefs), mode, int(clip),
                                              out.data_ptr(), None, B, Cc, hw, _lib.stream_ptr()))
+        return out
+
+    X_T_TAG = 0xFFFFFFFF  # Philox stream of a chain's initial noise; step n of the loop uses stream n
+
+    @staticmethod
+    def randn_from_seeds(shape, seeds, tag):
+        """[B, ...] standard normals from the per-chain streams: row b = normal(seeds[b], tag, .) - what
+        `ddmi_ddpm_step_rng` draws in registers for that tag."""
+        import torch
+        out = torch.empty(tuple(shape), device=seeds.device, dtype=torch.float32)
+        n = int(np.prod(shape[1:]))
+        _lib.check(_lib.lib().ddmi_randn_fill(out.data_ptr(), seeds.data_ptr(), int(shape[0]), n, int(tag), _lib.stream_ptr()))
         return out
 
     @staticmethod
@@ -191,13 +208,22 @@ class DDPM:
 
     # ---- samplers ---------------------------------------------------------------------------------------------------
     def p_sample_loop(self, shape, cond=None, return_intermediates=False, noise=None, enable_mask=False,
-                      step_noise=None, device=None, generator=None):
-        """ddpm.py:283-300.  One `randn` per step including t=0 (ddpm.py:278), multiplied by 0 there."""
+                      step_noise=None, device=None, generator=None, seeds=None):
+        """ddpm.py:283-300.  One `randn` per step including t=0 (ddpm.py:278), multiplied by 0 there.
+        `seeds` ([B] int64 on the device): per-chain Philox streams - x_T and every step's noise are drawn in the
+        library (no noise tensors, no per-sample generator launches) and do not depend on the batch composition."""
         import torch
         assert cond is None
         device = torch.device(device or "cuda")
-        img = (torch.randn(tuple(shape), device=device, generator=generator) if noise is None
-               else torch.as_tensor(noise).to(device=device, dtype=torch.float32).contiguous().clone())
+        if seeds is not None:
+            assert step_noise is None and generator is None
+            seeds = seeds.to(device=device, dtype=torch.int64).contiguous()
+        if noise is not None:
+            img = torch.as_tensor(noise).to(device=device, dtype=torch.float32).contiguous().clone()
+        elif seeds is not None:
+            img = self.randn_from_seeds(shape, seeds, self.X_T_TAG)
+        else:
+            img = torch.randn(tuple(shape), device=device, generator=generator)
         draw = self._noise_source(step_noise, tuple(shape), device, generator)
         B = shape[0]
         nxt = torch.empty_like(img)
@@ -209,8 +235,8 @@ class DDPM:
         for n, i in enumerate(reversed(range(self.num_timesteps))):
             tt.fill_(i)
             self.model(img, tt, cond, out=eps, enable_mask=False)
-            nz = draw(n)
-            self._step(img, eps, nz, self.ancestral_coefs(i), _lib.STEP_ANCESTRAL, nxt, self.clip_denoised)
+            nz = draw(n) if seeds is None else None
+            self._step(img, eps, nz, self.ancestral_coefs(i), _lib.STEP_ANCESTRAL, nxt, self.clip_denoised, seeds, n)
             img, nxt = nxt, img
             if return_intermediates:
                 intermediates.append(img.clone())
@@ -219,13 +245,21 @@ class DDPM:
         return (img, intermediates) if return_intermediates else img
 
     def ddim_sample(self, shape, cond=None, clip_denoised=False, noise=None, enable_mask=False, step_noise=None,
-                    device=None, generator=None):
-        """ddpm.py:334-369.  A `randn_like` is drawn on every non-final step even when eta == 0 (ddpm.py:363)."""
+                    device=None, generator=None, seeds=None):
+        """ddpm.py:334-369.  A `randn_like` is drawn on every non-final step even when eta == 0 (ddpm.py:363).
+        `seeds`: as in p_sample_loop."""
         import torch
         assert cond is None
         device = torch.device(device or "cuda")
-        img = (torch.randn(tuple(shape), device=device, generator=generator) if noise is None
-               else torch.as_tensor(noise).to(device=device, dtype=torch.float32).contiguous().clone())
+        if seeds is not None:
+            assert step_noise is None and generator is None
+            seeds = seeds.to(device=device, dtype=torch.int64).contiguous()
+        if noise is not None:
+            img = torch.as_tensor(noise).to(device=device, dtype=torch.float32).contiguous().clone()
+        elif seeds is not None:
+            img = self.randn_from_seeds(shape, seeds, self.X_T_TAG)
+        else:
+            img = torch.randn(tuple(shape), device=device, generator=generator)
         draw = self._noise_source(step_noise, tuple(shape), device, generator)
         B = shape[0]
         nxt = torch.empty_like(img)
@@ -240,8 +274,9 @@ class DDPM:
                 self._step(img, eps, None, self._base_coefs(t), _lib.STEP_DDIM_LAST, nxt, clip_denoised)
             else:
                 k = self.ddim_coefs(t, t_next)
-                nz = draw(n) if (k.sigma != 0.0 or step_noise is not None) else None
-                self._step(img, eps, nz, k, _lib.STEP_DDIM, nxt, clip_denoised)
+                use_seeds = seeds if (seeds is not None and k.sigma != 0.0) else None
+                nz = draw(n) if (seeds is None and (k.sigma != 0.0 or step_noise is not None)) else None
+                self._step(img, eps, nz, k, _lib.STEP_DDIM, nxt, clip_denoised, use_seeds, n)
             img, nxt = nxt, img
         if hasattr(self.model, "set_uniform_t"):
             self.model.set_uniform_t(False)

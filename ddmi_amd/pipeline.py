@@ -72,28 +72,32 @@ class ImagePipeline:
             self._coords = generation_coords(self.test_resolution)
         return self._coords
 
-    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, events=None):
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, events=None,
+                 rng: str = "philox"):
         """One batch of finished samples for the given GLOBAL sample indices.  Every chain draws x_T and its per-step
-        noise from its own device generator seeded by (base_seed, index), so results do not depend on how indices are
-        sharded over GPUs or batched."""
+        noise from its own counter-based stream keyed by sample_seed(base_seed, index) (inside the sampler-step
+        kernel), so results do not depend on how indices are sharded over GPUs or batched."""
         import torch
         B = len(indices)
         dev = torch.device(self.device)
         shape = (B, self.embed_dim, self.latent_size, self.latent_size)
-        gens = []
-        for i in indices:
-            g = torch.Generator(device=dev)
-            g.manual_seed(sample_seed(base_seed, i))
-            gens.append(g)
-        buf = torch.empty(shape, device=dev, dtype=torch.float32)
+        if rng == "philox":
+            seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
+            z = self.ddpm.sample(list(shape), seeds=seeds, device=dev)
+        else:  # rng == "torch": one torch device generator per chain (B small launches per step; kept for comparison)
+            gens = []
+            for i in indices:
+                g = torch.Generator(device=dev)
+                g.manual_seed(sample_seed(base_seed, i))
+                gens.append(g)
+            buf = torch.empty(shape, device=dev, dtype=torch.float32)
 
-        def draw(_step):
-            for j, g in enumerate(gens):
-                torch.randn(shape[1:], generator=g, out=buf[j])
-            return buf
+            def draw(_step):
+                for j, g in enumerate(gens):
+                    torch.randn(shape[1:], generator=g, out=buf[j])
+                return buf
 
-        x_T = draw(-1).clone()
-        z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
+            z = self.ddpm.sample(list(shape), noise=draw(-1).clone(), step_noise=draw, device=dev)
         if events:
             events[0].record()
         planes = self.vae.decode(z)
@@ -170,20 +174,8 @@ class VideoPipeline:
         B = len(indices)
         dev = torch.device(self.device)
         shape = (B, self.embed_dim, self.unet.seq_len)
-        gens = []
-        for i in indices:
-            g = torch.Generator(device=dev)
-            g.manual_seed(sample_seed(base_seed, i))
-            gens.append(g)
-        buf = torch.empty(shape, device=dev, dtype=torch.float32)
-
-        def draw(_step):
-            for j, g in enumerate(gens):
-                torch.randn(shape[1:], generator=g, out=buf[j])
-            return buf
-
-        x_T = draw(-1).clone()
-        z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
+        seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
+        z = self.ddpm.sample(list(shape), seeds=seeds, device=dev)
         outs = []
         for b0 in range(0, B, self.vae.max_batch):  # decode in slices: the 73k-token attention buffers are per sample
             zz = z[b0:b0 + self.vae.max_batch].contiguous()

@@ -95,6 +95,17 @@ int ddmi_ddpm_step(const float* x, const float* model_out, const float* noise, c
                    const ddmi_step_coefs* coefs, int mode, int clip_denoised, float* x_out, float* x0_out, int B,
                    int C, int HW, void* stream);
 
+/* Same step with the noise drawn INSIDE the kernel: the reference draws `noise_like(x.shape)` / `randn_like(img)` from
+ * the global torch generator (ddpm.py:278, 363); here every chain has its own counter-based stream
+ * normal(seeds[b], tag, element) (Philox4x32-10 + Box-Muller), so a sample's noise does not depend on the batch or GPU
+ * it runs in, and no [B,C,HW] noise tensor is written or read.  `tag`: the step index.  C*HW % 4 == 0. */
+int ddmi_ddpm_step_rng(const float* x, const float* model_out, const uint64_t* seeds, uint32_t tag,
+                       const float* mixing_logit, const ddmi_step_coefs* coefs, int mode, int clip_denoised, float* x_out,
+                       float* x0_out, int B, int C, int HW, void* stream);
+/* out[b][e] = normal(seeds[b], tag, e), e < n_per_sample (multiple of 4): the very values ddmi_ddpm_step_rng draws for
+ * that tag - x_T of a chain (tag 0xFFFFFFFF by convention), or a replay of a step's noise for parity checks */
+int ddmi_randn_fill(float* out, const uint64_t* seeds, int B, int64_t n_per_sample, uint32_t tag, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * D2C-VAE image decoder: replaces Autoencoder.decode (models/d2c_vae/autoencoder_unet.py:855-858) =
  * post_quant_conv + Decoder.forward (:790-829).  Keys: "post_quant_conv.*", "decoder.*".

@@ -164,3 +164,31 @@ def test_afhq_decoder_and_mlp_full_size_vs_oracle():
     mlp16 = make_mlp("afhq.mlp", "bf16")
     rgb16 = mlp16(generation_coords(256), hdbf=planes16, si=1.0)
     assert rel_err(rgb16, ref_rgb) < TOL_BF16
+
+
+def test_image_pipeline_matches_oracle_and_is_batch_invariant(golden):
+    """ddmi_amd.pipeline.ImagePipeline (tools/ldm/image.py:225-249) on the toy configuration, parity mode: the whole
+    chain - x_T and per-step noise drawn inside the library from per-sample Philox streams - equals the oracle's chain
+    fed with the replayed draws, and a sample does not depend on which other samples share its batch."""
+    from ddmi_amd.dist import sample_seed
+    from ddmi_amd.pipeline import ImagePipeline
+    cfgs = golden.json("configs.json")
+    T = 6
+    ddpmconfig = dict(timesteps=T, sampling_timesteps=T, channels=64, image_size=8)   # S == T -> ancestral loop
+    pipe = ImagePipeline(cfgs["TOY_UNET"], cfgs["TOY_DD"], cfgs["MLP_CFG"], ddpmconfig, cfgs["TOY_EMBED"], test_resolution=32,
+                         numerics="fp32", max_batch=3, device=DEV)
+    pipe.load_named_seed("toyi").finalize()
+    idx = [4, 0, 11]
+    img, z = pipe.generate(idx, base_seed=5, return_latent=True)
+    shape = (3, 64, 8, 8)
+    seeds = torch.tensor([sample_seed(5, i) for i in idx], dtype=torch.int64, device=DEV)
+    x_T = DDPM.randn_from_seeds(shape, seeds, DDPM.X_T_TAG).cpu()
+    draws = [DDPM.randn_from_seeds(shape, seeds, n).cpu() for n in range(T)]
+    st = lambda tag, man: O.to_state(named_state(tag, man))
+    logit = torch.from_numpy(iw.fill_state("toyi.ddpm", [("mixing_logit", (1, 64, 1, 1))])["mixing_logit"])
+    ref = O.generate(st("toyi.unet", pipe.unet.manifest()), cfgs["TOY_UNET"], st("toyi.vae", pipe.vae.manifest()), cfgs["TOY_DD"],
+                     st("toyi.mlp", pipe.mlp.manifest()), O.make_schedule(T), logit, x_T, draws, T, T, 1.0, 32)
+    assert rel_err(z, ref["z"]) < TOL_FP32
+    assert rel_err(img, ref["img"]) < TOL_FP32
+    solo = pipe.generate([11], base_seed=5)
+    assert rel_err(solo[0], img[2]) < 1e-5

@@ -134,6 +134,37 @@ def test_conv2d_every_bf16_variant(cfg):
         L.ddmi_debug_conv_config(-1)
 
 
+def test_philox_noise_streams():
+    """ddmi_randn_fill / ddmi_ddpm_step_rng: per-chain counter-based normals.  Moments, independence across chains and
+    steps, determinism, independence of the batch composition, and the step kernel drawing exactly the fill's values."""
+    L = _lib.lib()
+    _lib.init_device(0)
+    B, Cc, HW = 6, 64, 64 * 64
+    seeds = torch.tensor([(777 << 32) + i for i in (0, 1, 2, 3, 4, 12345)], dtype=torch.int64, device=DEV)
+    a = DDPM.randn_from_seeds((B, Cc, HW), seeds, 7)
+    z = a.double().cpu()
+    n = z[0].numel()
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.var()) - 1.0) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 5e-2 and float(z.abs().max()) < 6.5 and bool(torch.isfinite(a).all())
+    flat = z.reshape(B, -1)
+    corr = (flat @ flat.T) / n
+    assert float((corr - torch.eye(B, dtype=torch.float64)).abs().max()) < 1e-2          # chains are independent
+    b = DDPM.randn_from_seeds((B, Cc, HW), seeds, 8).double().cpu()
+    assert abs(float((z * b).mean())) < 3e-3 and not torch.equal(z, b)                   # steps are independent
+    assert abs(float((flat[:, :-1] * flat[:, 1:]).mean())) < 3e-3                        # neighbours are independent
+    assert torch.equal(a, DDPM.randn_from_seeds((B, Cc, HW), seeds, 7))                  # deterministic
+    solo = DDPM.randn_from_seeds((1, Cc, HW), seeds[5:6].contiguous(), 7)
+    assert torch.equal(solo[0], a[5])                                                    # batch composition is irrelevant
+    # the fused step draws the same numbers in registers
+    x = torch.randn((B, Cc, 64, 64), device=DEV)
+    mo = torch.randn((B, Cc, 64, 64), device=DEV)
+    d = DDPM(model=None, timesteps=250, sampling_timesteps=250, channels=Cc)
+    out_rng, out_ref = torch.empty_like(x), torch.empty_like(x)
+    d._step(x, mo, None, d.ancestral_coefs(100), _lib.STEP_ANCESTRAL, out_rng, False, seeds, 7)
+    d._step(x, mo, a.reshape(x.shape).contiguous(), d.ancestral_coefs(100), _lib.STEP_ANCESTRAL, out_ref, False)
+    assert torch.equal(out_rng, out_ref)
+
+
 def gn_op(x, g, b, eps, silu, numerics):
     L = _lib.lib()
     _lib.init_device(0)

@@ -201,14 +201,10 @@ def test_video_pipeline_matches_oracle_and_is_batch_invariant(golden):
     idx = [5, 9]
     vid, z = pipe.generate(idx, base_seed=3, return_latent=True)
     assert tuple(vid.shape) == (2, 3, Tn, R, R)
-    # replay the draws: x_T, then one draw per non-final DDIM step, per-sample device generators
-    shape1 = (cfgs["TOY_EMBED_V"], pipe.unet.seq_len)
-    gens = []
-    for i in idx:
-        g = torch.Generator(device=DEV)
-        g.manual_seed(sample_seed(3, i))
-        gens.append(g)
-    draws = [torch.stack([torch.randn(shape1, generator=g, device=DEV) for g in gens]).cpu() for _ in range(S)]
+    # replay the draws: x_T (stream 0xFFFFFFFF), then stream n for the n-th step, from the per-chain Philox seeds
+    shape = (2, cfgs["TOY_EMBED_V"], pipe.unet.seq_len)
+    seeds = torch.tensor([sample_seed(3, i) for i in idx], dtype=torch.int64, device=DEV)
+    draws = [DDPM.randn_from_seeds(shape, seeds, DDPM.X_T_TAG).cpu()] + [DDPM.randn_from_seeds(shape, seeds, n).cpu() for n in range(S - 1)]
     st = lambda tag, man: O.to_state(named_state(tag, man))
     logit = torch.from_numpy(iw.fill_state("toyv.ddpm", [("mixing_logit", (1, cfgs["TOY_EMBED_V"], 1))])["mixing_logit"])
     ref = O.generate_video(st("toyv.unet3", pipe.unet.manifest()), cfgs["TOY_UNET_V"], st("toyv.vit", pipe.vae.manifest()),
