@@ -130,6 +130,9 @@ def lib() -> C.CDLL:
     """The loaded library; raises (loudly) when it has not been built - there is no CPU/torch fallback."""
     global _lib
     if _lib is None:
+        path = os.environ.get("DDMI_LIB_PATH", LIB_PATH)  # diagnostics: A/B two builds of the library on one GPU box
+        if path != LIB_PATH:
+            globals()["LIB_PATH"] = path
         if not os.path.exists(LIB_PATH):
             raise DdmiError(f"{LIB_PATH} is missing: build it with `python -m ddmi_amd.build` "
                             "(hipcc --offload-arch=gfx950); ddmi_amd has no fallback path")

@@ -44,6 +44,7 @@ struct ConvK {
   int SPS;      // stages per split
   int tiles_n;
   int tile_map;                             // 0 row-major, 1 XCD-contiguous m-major, 2 XCD-contiguous n-major
+  int paired;                               // pipe kernel: paired-fragment instantiation (order 3 / 4)
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
   int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier
   float out_scale;
@@ -97,13 +98,110 @@ __device__ __forceinline__ TileMN conv_tile_of_block(int tile_map, int tiles_n) 
   return t;
 }
 
-// ---- epilogue shared by both kernels: lane holds channels n..n+3 of pixel m for every (i, j) fragment ----------
-template <typename T, int FM, int FN>
+// ---- fragment pairing ---------------------------------------------------------------------------------------------
+// An MFMA 16x16 result leaves lane (lr, lg) with rows 4lg..4lg+3 = four output channels.  With PAIRED the weight rows
+// fed to fragments 2p and 2p+1 are interleaved in groups of four, so those two fragments hand the lane EIGHT consecutive
+// channels: every epilogue access (bias, embedding, residual, store) becomes 16 bytes wide and there are half as many
+// of them - the store tail of a tile is issue-bound (MI355X_MICROARCH.md, attention epilogue row).
+//   weight row of (fragment j, MFMA row r): 32 (j>>1) + 8 (r>>2) + 4 (j&1) + (r&3);  an unpaired last fragment keeps 16 j + r
+template <int FN, bool PAIRED> __device__ __forceinline__ int frag_row(int j, int r) {
+  if (!PAIRED || ((FN & 1) && j == FN - 1)) return 16 * j + r;
+  return 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
+}
+// The pairing is realised where the weight tile is LOADED: LDS row R of the tile holds weight row lds_row_chan(R), so
+// the fragment reads (16 consecutive LDS rows, conflict-free swizzle) stay exactly as they are.  R = wn*TN + l with l
+// inside the wave's slab: rows of the paired part are permuted inside 32-row blocks, 32p + 16h + 4q + t -> 32p + 8q + 4h + t.
+template <int TN> __device__ __forceinline__ int lds_row_chan(int R) {
+  constexpr int FN = TN / 16;
+  const int wn = R / TN, l = R - wn * TN;
+  if (l >= 32 * (FN / 2)) return R;
+  const int r32 = l & 31;
+  return R - r32 + 8 * ((r32 >> 2) & 3) + 4 * (r32 >> 4) + (r32 & 3);
+}
+// first channel (relative to the wave's slab) of the lane's four values in fragment j
+template <int FN, bool PAIRED> __device__ __forceinline__ int frag_chan(int j, int lg) {
+  if (!PAIRED || ((FN & 1) && j == FN - 1)) return 16 * j + 4 * lg;
+  return 32 * (j >> 1) + 8 * lg + 4 * (j & 1);
+}
+
+// ---- epilogue shared by all kernels --------------------------------------------------------------------------------
+template <typename T, int NV>
+__device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV], int m, int n, int b, int be, int hw,
+                                                  T* __restrict__ yg, const T* __restrict__ rg) {
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  if (a.ws != nullptr) {  // split-K partial slab [z][M][Cout], summed by splitk_finish_kernel
+    float* p = a.ws + ((int64_t)blockIdx.z * a.M + m) * a.Cout + n;
+#pragma unroll
+    for (int q = 0; q < NV; q += 4) *reinterpret_cast<f32x4*>(p + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    return;
+  }
+  if (a.bias) {
+#pragma unroll
+    for (int q = 0; q < NV; q += 4) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n + q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q + e] += t[e];
+    }
+  }
+  if (a.emb) {
+    const float* pe = a.emb + (int64_t)be * a.emb_stride + n;
+#pragma unroll
+    for (int q = 0; q < NV; q += 4) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(pe + q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q + e] += t[e];
+    }
+  }
+  if (rg) {
+    const T* p = rg + (int64_t)m * a.Cout + n;
+    if constexpr (IS_BF16 && NV == 8) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+    } else if constexpr (IS_BF16) {
+      bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV; q += 4) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q + e] += t[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] *= a.out_scale;
+  if (a.y_nchw) {
+    int r = m - b * hw;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) a.y_nchw[((int64_t)b * a.Cout + n + e) * hw + r] = v[e];
+    return;
+  }
+  T* p = yg + (int64_t)m * a.Cout + n;
+  if constexpr (IS_BF16 && NV == 8) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  } else if constexpr (IS_BF16) {
+    bf16x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x4*>(p) = t;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NV; q += 4) *reinterpret_cast<f32x4*>(p + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+  }
+}
+
+template <typename T, int FM, int FN, bool PAIRED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
                                               int lg, int hw) {
-  constexpr bool IS_BF16 = sizeof(T) == 2;
   T* __restrict__ yg = a.y ? (T*)a.y + (int64_t)blockIdx.y * a.y_bstride : nullptr;
   const T* __restrict__ rg = (const T*)a.res;
+  constexpr int NPAIR = PAIRED ? FN / 2 : 0;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     int m = m_base + i * 16 + lr;
@@ -115,42 +213,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
       be -= be >= a.emb_mod ? a.emb_mod : 0;
     }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      int n = n_base + j * 16 + lg * 4;
+    for (int p = 0; p < NPAIR; ++p) {  // fragments 2p, 2p+1: eight consecutive channels
+      int n = n_base + 32 * p + 8 * lg;
+      if (n + 8 <= a.Cout) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * p][e]; v[4 + e] = acc[i][2 * p + 1][e]; }
+        conv_epilogue_vec<T, 8>(a, v, m, n, b, be, hw, yg, rg);
+      } else if (n < a.Cout) {  // Cout is a multiple of 4: the first half exists, the second does not
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][2 * p][e];
+        conv_epilogue_vec<T, 4>(a, v, m, n, b, be, hw, yg, rg);
+      }
+    }
+#pragma unroll
+    for (int j = 2 * NPAIR; j < FN; ++j) {
+      int n = n_base + frag_chan<FN, PAIRED>(j, lg);
       if (n >= a.Cout) continue;
-      f32x4 v = acc[i][j];
-      if (a.ws != nullptr) {  // split-K partial slab [z][M][Cout], summed by splitk_finish_kernel
-        *reinterpret_cast<f32x4*>(a.ws + ((int64_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
-        continue;
-      }
-      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (a.emb) v += *reinterpret_cast<const f32x4*>(a.emb + (int64_t)be * a.emb_stride + n);
-      if (rg) {
-        const T* p = rg + (int64_t)m * a.Cout + n;
-        if constexpr (IS_BF16) {
-          bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+      float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
-        } else {
-          v += *reinterpret_cast<const f32x4*>(p);
-        }
-      }
-      v *= a.out_scale;
-      if (a.y_nchw) {
-        int r = m - b * hw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a.y_nchw[((int64_t)b * a.Cout + n + e) * hw + r] = v[e];
-      } else {
-        T* p = yg + (int64_t)m * a.Cout + n;
-        if constexpr (IS_BF16) {
-          bf16x4 t;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(p) = t;
-        } else {
-          *reinterpret_cast<f32x4*>(p) = v;
-        }
-      }
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+      conv_epilogue_vec<T, 4>(a, v, m, n, b, be, hw, yg, rg);
     }
   }
 }
@@ -230,7 +314,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   for (int i = 0; i < B_PER; ++i) {
     int row = (i * NW + wave) * 16 + (lane >> 2);
     int slot = swz(row, lane & 3);
-    int n = n0 + row;
+    int n = n0 + lds_row_chan<TN>(row);  // paired fragments: LDS row -> weight row (see frag_row)
     b_ok[i] = (row < BN) & (n < a.Cout);
     b_coff[i] = slot * EPS;
     b_base[i] = (n * Ktot + b_coff[i]) * SZ;
@@ -334,7 +418,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
   }
-  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+  conv_epilogue<T, FM, FN, true>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
 }
 
 // =====================================================================================================
@@ -353,7 +437,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
 //         [B] read frags(2s+2) || MFMA(2s+1)
 //     Two LDS buffers; the DMA of stage s+2 has one full stage of MFMA time to land.
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PAIRED>
 __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   using T = bf16_t;
   constexpr int NW = WM * WN;
@@ -412,7 +496,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
   const int sample_bytes = a.Hin * a.Win * a.Cin * SZ, coff_b = coff * SZ;
   // weight rows: group i of a wave sits 8*NW rows after group 0 - a scalar step, so one base register serves all
   const int b_row0 = wave * 8 + (lane >> 3);
-  const int b_base0 = ((n0 + b_row0) * Ktot + coff) * SZ;
+  const int b_base0 = (n0 * Ktot + coff) * SZ;   // + weight row * Ktot * SZ per load
+  // paired fragments: LDS row R holds weight row lds_row_chan(R); the B_PER row shifts (|d| <= 12) packed 8 bits each
+  int b_perm[(B_PER + 3) / 4];
+#pragma unroll
+  for (int i = 0; i < (B_PER + 3) / 4; ++i) b_perm[i] = 0;
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int R = b_row0 + i * 8 * NW;
+    b_perm[i >> 2] |= (((PAIRED ? lds_row_chan<TN>(R) : R) - R + 16) & 0xFF) << (8 * (i & 3));
+  }
 
   // ---- wave-uniform walk over stages: (tap, 64-channel block) in tap-major or channel-major order ----------------
   const int s_begin = blockIdx.z * a.SPS;
@@ -444,8 +537,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-      int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + b_row0 + i * 8 * NW < a.Cout);
-      unsigned voff = ok ? (unsigned)(b_base0 + i * 8 * NW * Ktot * SZ + b_delta) : OOB_OFFSET;
+      int brow = b_row0 + i * 8 * NW;
+      if constexpr (PAIRED) {  // LDS row -> weight row of the paired layout
+        int pk = b_perm[i >> 2];
+        asm volatile("" : "+v"(pk));  // keep the unpack (2 VALU) in the loop: hoisted it would cost B_PER registers
+        brow += (int)((pk >> (8 * (i & 3))) & 0xFF) - 16;
+      }
+      int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + brow < a.Cout);
+      unsigned voff = ok ? (unsigned)(b_base0 + brow * Ktot * SZ + b_delta) : OOB_OFFSET;
       const int g = i * NW + wave;
       unsigned char* dst = g < GB ? sbase + A_BYTES + g * 1024 : smem + SCRATCH + wave * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
@@ -531,7 +630,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     if (c1) mma(xb, wb);
     buf ^= 1;
   }
-  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+  conv_epilogue<T, FM, FN, PAIRED>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
 }
 
 // =====================================================================================================
@@ -589,7 +688,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   // weight rows: lane owns physical slot lane&7 of row (lane>>3) of its 8-row group; one channel offset per lane
   const int coff = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 8;
   const int b_row0 = wave * 8 + (lane >> 3);             // group i adds 8*NW rows (a scalar step)
-  const int b_base0 = ((n0 + b_row0) * Ktot + coff) * SZ;
+  const int b_base0 = (n0 * Ktot + coff) * SZ;   // + weight row * Ktot * SZ per load
   // halo group g: 8 halo rows hr = 8g + (lane>>3); the slot swizzle depends on hr, so the channel offset does too
   auto load_halo_group = [&](int g, int cb, int hbuf) {
     const int hr = g * 8 + (lane >> 3);
@@ -611,8 +710,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     for (int i = 0; i < B_PER; ++i) {
       const int g = i * NW + wave;
       if (g < GB) {
-        int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + b_row0 + i * 8 * NW < a.Cout);
-        unsigned voff = ok ? (unsigned)(b_base0 + i * 8 * NW * Ktot * SZ + delta) : OOB_OFFSET;
+        const int brow = lds_row_chan<TN>(b_row0 + i * 8 * NW);  // LDS row -> weight row of the paired layout
+        int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + brow < a.Cout);
+        unsigned voff = ok ? (unsigned)(b_base0 + brow * Ktot * SZ + delta) : OOB_OFFSET;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(BB + bbuf * B_BYTES + g * 1024), 16, voff, 0, 0, 0);
       }
     }
@@ -698,7 +798,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, 0, xa, wa);
     if (c1) mma(xb, wb);
   }
-  conv_epilogue<T, FM, FN>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+  conv_epilogue<T, FM, FN, true>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KPS>
@@ -1127,10 +1227,14 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "pipe tile does not fit the 160 KiB LDS");
   k.tiles_n = cdiv(k.Cout, BN);
   dim3 grid(cdiv(k.M, BM) * k.tiles_n, batch, splitk);
-  auto kern = conv_pipe_kernel<BM, BN, WM, WN>;
+  // two instantiations: plain, and PAIRED fragments (16-byte epilogue accesses: +7 % on the 1x1 convs whose tiles are
+  // mostly prologue / epilogue, -4 % on long-K 3x3 tiles from two more VALU per weight load); the autotuner picks
+  auto kern_plain = conv_pipe_kernel<BM, BN, WM, WN, false>;
+  auto kern_paired = conv_pipe_kernel<BM, BN, WM, WN, true>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_plain), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_paired), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   {
@@ -1138,7 +1242,8 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
     conv_work(k, batch, 2, &flops, &bytes);
     static const std::string name = "conv_pipe<bf16," + std::to_string(BM) + "x" + std::to_string(BN) + ">";
     PROF_SCOPE(name.c_str(), flops, bytes, s);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+    if (k.paired) hipLaunchKernelGGL(kern_paired, grid, dim3(WM * WN * 64), lds, s, k);
+    else hipLaunchKernelGGL(kern_plain, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
@@ -1227,7 +1332,10 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
-  k.chan_major = a.order == 2 || (a.order == 0 && a.KH * a.KW > 1 && splitk == 1);
+  // order: 1 tap-major, 2 channel-major, +2 = paired-fragment instantiation of the pipe kernel; 0 = heuristic
+  const int walk = a.order > 2 ? a.order - 2 : a.order;
+  k.chan_major = walk == 2 || (a.order == 0 && a.KH * a.KW > 1 && splitk == 1);
+  k.paired = a.order > 2 || (a.order == 0 && a.KH * a.KW == 1);
   {
     static const int env_map = getenv("DDMI_CONV_TILEMAP") ? atoi(getenv("DDMI_CONV_TILEMAP")) : 0;  // diagnostics
     int tm = env_map ? env_map : a.tile_map;
@@ -1298,7 +1406,9 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
       if (sk > 1 && (tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
       if (rc.kps == -2 && sk > cdiv(a0.Cin, 64)) continue;
       if ((size_t)sk * M * a0.Cout * sizeof(float) > ws_bytes && sk > 1) continue;
-      for (int order = 1; order <= ((a0.KH * a0.KW > 1 && rc.kps != -2) ? 2 : 1); ++order) {
+      const int n_walk = (a0.KH * a0.KW > 1 && rc.kps != -2) ? 2 : 1;
+      for (int order = 1; order <= (rc.kps == -1 ? n_walk + 2 : n_walk); ++order) {  // pipe: + the paired instantiation
+        if (order > n_walk && order <= 2) continue;
         ConvArgs a = a0;
         a.cfg = id + 1; a.order = order; a.splitk = sk; a.splitk_ws = ws;
         int rc2 = DDMI_OK;

@@ -68,7 +68,8 @@ struct ConvArgs {
   int splitk;
   float out_scale;    // y = (acc + bias + emb + res) * out_scale
   int cfg;            // bf16 ring-kernel configuration id + 1 (0 = heuristic), see k_conv.hip kRing
-  int order;          // K walk: 0 = heuristic, 1 = tap-major, 2 = channel-major (taps innermost)
+  int order;          // K walk: 0 = heuristic, 1 = tap-major, 2 = channel-major (taps innermost); 3 / 4 = the same walks
+                      // on the pipe kernel's paired-fragment instantiation (16-byte epilogue accesses)
   int tile_map;       // blockIdx -> tile: 0 = heuristic, -1 = row-major, 1 / 2 = XCD-contiguous m-major / n-major (k_conv.hip)
 };
 struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // result of conv_autotune (0 = heuristic)
