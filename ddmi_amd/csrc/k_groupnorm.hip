@@ -53,7 +53,22 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ pa
 #pragma unroll
     for (int i = 0; i < VN; ++i) s1[i] = s2[i] = 0.f;
     const T* base = x + (int64_t)b * HW * C + (int64_t)v * VN;
-    for (int p = p0 + r; p < p1; p += R) {
+    int p = p0 + r;
+    // four independent 16-byte loads in flight per thread: the pass is a pure HBM stream and one load per thread per
+    // iteration leaves the memory pipes half empty
+    for (; p + 3 * R < p1; p += 4 * R) {
+      float t[4][VN];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Vec16<T>::load(base + (int64_t)(p + u * R) * C, t[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+          s1[i] += t[u][i];
+          s2[i] += t[u][i] * t[u][i];
+        }
+    }
+    for (; p < p1; p += R) {
       float t[VN];
       Vec16<T>::load(base + (int64_t)p * C, t);
 #pragma unroll
@@ -124,7 +139,23 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
   int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
   const T* xb = x + (int64_t)b * HW * C + (int64_t)v * VN;
   T* yb = y + (int64_t)b * HW * C + (int64_t)v * VN;
-  for (int p = p0 + r; p < p1; p += R) {
+  int p = p0 + r;
+  for (; p + 3 * R < p1; p += 4 * R) {  // four loads in flight per thread (see gn_stats_kernel)
+    float t[4][VN];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Vec16<T>::load(xb + (int64_t)(p + u * R) * C, t[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        float q = t[u][j] * sc[j] + sh[j];
+        if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
+        t[u][j] = q;
+      }
+      Vec16<T>::store(yb + (int64_t)(p + u * R) * C, t[u]);
+    }
+  }
+  for (; p < p1; p += R) {
     float t[VN];
     Vec16<T>::load(xb + (int64_t)p * C, t);
 #pragma unroll
