@@ -39,8 +39,8 @@ template <> struct Vec16<bf16_t> {
 // fp64 -> part[b][split][group*2 + {sum, sumsq}].  No atomics, no zero-fill; bit-identical from run to run.
 #define GN_MAXSPLIT 64
 template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ part, int HW, int C, int NV, int R, int seg,
-                                int nseg) {
+__global__ void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, double* __restrict__ part,
+                                int HW, int C, int NV, int R, int seg, int nseg) {
   constexpr int VN = Vec16<T>::N;
   extern __shared__ float red[];  // s1[R][C] | s2[R][C]
   int b = blockIdx.y;
@@ -52,14 +52,18 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ pa
     float s1[VN], s2[VN];
 #pragma unroll
     for (int i = 0; i < VN; ++i) s1[i] = s2[i] = 0.f;
-    const T* base = x + (int64_t)b * HW * C + (int64_t)v * VN;
+    // the tensor may be the channel concatenation [x | x2] of two tensors read in place (th.cat([h, hs.pop()], 1),
+    // openaimodel.py:787): a thread's 16-byte channel vector lies wholly in one of them (C1 is a vector multiple)
+    const bool second = x2 != nullptr && v * VN >= C1;
+    const int ldc = x2 == nullptr ? C : (second ? C - C1 : C1);
+    const T* base = (second ? x2 + (int64_t)v * VN - C1 : x + (int64_t)v * VN) + (int64_t)b * HW * ldc;
     int p = p0 + r;
     // four independent 16-byte loads in flight per thread: the pass is a pure HBM stream and one load per thread per
     // iteration leaves the memory pipes half empty
     for (; p + 3 * R < p1; p += 4 * R) {
       float t[4][VN];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) Vec16<T>::load(base + (int64_t)(p + u * R) * C, t[u]);
+      for (int u = 0; u < 4; ++u) Vec16<T>::load(base + (int64_t)(p + u * R) * ldc, t[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -70,7 +74,7 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ pa
     }
     for (; p < p1; p += R) {
       float t[VN];
-      Vec16<T>::load(base + (int64_t)p * C, t);
+      Vec16<T>::load(base + (int64_t)p * ldc, t);
 #pragma unroll
       for (int i = 0; i < VN; ++i) {
         s1[i] += t[i];
@@ -98,7 +102,8 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ pa
 // its pixels, so its scale/shift live in registers (no per-element index math, no LDS in the streaming loop).
 struct GnSegs { int nseg, nsplit[3], total_hw; };
 template <typename T>
-__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ part,
+__global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, T* __restrict__ y,
+                                const double* __restrict__ part,
                                 GnSegs sg, const float* __restrict__ gamma, const float* __restrict__ beta,
                                 float eps, int silu, int HW, int C, int NV, int R) {
   constexpr int VN = Vec16<T>::N;
@@ -137,13 +142,15 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
   }
   int per = cdiv(HW, gridDim.x);
   int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
-  const T* xb = x + (int64_t)b * HW * C + (int64_t)v * VN;
+  const bool second = x2 != nullptr && v * VN >= C1;  // dual-source input, see gn_stats_kernel
+  const int ldc = x2 == nullptr ? C : (second ? C - C1 : C1);
+  const T* xb = (second ? x2 + (int64_t)v * VN - C1 : x + (int64_t)v * VN) + (int64_t)b * HW * ldc;
   T* yb = y + (int64_t)b * HW * C + (int64_t)v * VN;
   int p = p0 + r;
   for (; p + 3 * R < p1; p += 4 * R) {  // four loads in flight per thread (see gn_stats_kernel)
     float t[4][VN];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Vec16<T>::load(xb + (int64_t)(p + u * R) * C, t[u]);
+    for (int u = 0; u < 4; ++u) Vec16<T>::load(xb + (int64_t)(p + u * R) * ldc, t[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -157,7 +164,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
   }
   for (; p < p1; p += R) {
     float t[VN];
-    Vec16<T>::load(xb + (int64_t)p * C, t);
+    Vec16<T>::load(xb + (int64_t)p * ldc, t);
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
       float q = t[j] * sc[j] + sh[j];
@@ -174,11 +181,13 @@ static int gn_splits(int B, int HW) {
   return std::max(1, std::min(std::min(want, HW / 16), GN_MAXSPLIT));
 }
 
-int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg, int nseg) {
+int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg, int nseg,
+                    const void* x2, int C1) {
   DDMI_REQUIRE(nseg >= 1 && nseg <= 3 && seg >= 0 && seg < nseg, "groupnorm: bad segment index");
   int vn = dt == DT_F32 ? 4 : 8;
   DDMI_REQUIRE(C % GN_GROUPS == 0, "groupnorm: C must be a multiple of 32");
   DDMI_REQUIRE(C % vn == 0, "groupnorm: C must be a multiple of the 16-byte vector");
+  DDMI_REQUIRE(x2 == nullptr || (C1 > 0 && C1 < C && C1 % vn == 0), "groupnorm: the concat boundary must fall on a 16-byte vector");
   int NV = C / vn;
   DDMI_REQUIRE(NV <= 1024, "groupnorm: too many channels");
   int R = std::max(1, 256 / NV);
@@ -187,15 +196,18 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
   size_t lds = (size_t)2 * R * C * sizeof(float);
   PROF_SCOPE("gn_stats", 0, (double)B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_stats_kernel<float>, g, dim3(threads), lds, s, (const float*)x, stats, HW, C, NV, R, seg, nseg);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, g, dim3(threads), lds, s, (const float*)x, (const float*)x2, C1, stats, HW, C,
+                       NV, R, seg, nseg);
   else
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, stats, HW, C, NV, R, seg, nseg);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, (const bf16_t*)x2, C1, stats, HW,
+                       C, NV, R, seg, nseg);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
 
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
-                    float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw, int nseg) {
+                    float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw, int nseg, const void* x2,
+                    int C1) {
   int vn = dt == DT_F32 ? 4 : 8;
   int NV = C / vn;
   int R = std::max(1, 256 / NV);
@@ -215,10 +227,10 @@ int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const f
   }
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * dt_size(dt), s);
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (float*)y, stats, sg, gamma,
+    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (const float*)x2, C1, (float*)y, stats, sg, gamma,
                        beta, eps, silu, HW, C, NV, R);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, stats, sg, gamma,
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma,
                        beta, eps, silu, HW, C, NV, R);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;

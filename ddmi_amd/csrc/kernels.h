@@ -47,9 +47,13 @@ int launch_linear_small(const float* x, int x_stride, const float* W, const floa
 // of a sample jointly, autoencoder_unet.py:1066-1071): run launch_gn_stats once per segment (same B, seg = 0..nseg-1),
 // then launch_gn_apply on each tensor with the HW of every segment in `seg_hw`.
 #define GN_STATS_DOUBLES(B) ((size_t)(B) * 3 * 64 * 64)
-int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg = 0, int nseg = 1);
+// x2 != null: the input is the channel concatenation [x (C1 channels) | x2 (C - C1)] of two tensors, read in place
+// (replaces th.cat before a ResBlock's in_layers, openaimodel.py:787); the output is one C-channel tensor.
+int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg = 0, int nseg = 1,
+                    const void* x2 = nullptr, int C1 = 0);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
-                    float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1);
+                    float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1,
+                    const void* x2 = nullptr, int C1 = 0);
 
 // ---- implicit-GEMM convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 upsample) ------
 struct ConvArgs {

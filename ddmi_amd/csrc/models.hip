@@ -5,6 +5,8 @@
 #include "models.h"
 #include "prof.h"
 #include <cmath>
+#include <cstdlib>
+#include <algorithm>
 
 // =====================================================================================================
 // UNet
@@ -19,7 +21,7 @@ static bool in_list(const int* v, int n, int x) {
 //   h = conv3(SiLU(GN(x))) + emb_proj ; h = conv3(SiLU(GN(h))) ; out = skip(x) + h
 // Weights are created once (make_*) and may be emitted on several tensors (the video UNet runs every block on the
 // xy plane and on the stacked xt / yt planes with the same weights).
-int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w) {
+int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split) {
   Net& n = u.net;
   w->eps = 1e-5f;
   DDMI_TRY(n.make_gn(pre + "in_layers.0.", &w->gn1));
@@ -35,11 +37,40 @@ int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW*
   u.emb_b_host.insert(u.emb_b_host.end(), eb->data.begin(), eb->data.end());
   DDMI_TRY(n.make_gn(pre + "out_layers.0.", &w->gn2));
   DDMI_TRY(n.make_conv(pre + "out_layers.3.weight", pre + "out_layers.3.bias", &w->c2));
-  w->cs = -1;
-  if (cin != cout) {
+  w->cs = w->cs2 = -1;
+  if (cin != cout && split > 0) {
+    // the block's input is th.cat([h, skip], 1) (openaimodel.py:787) and is never materialised: the 1x1 skip_connection
+    // becomes two accumulating 1x1 convolutions over the column blocks [0, split) and [split, cin) of its weight
+    const HostTensor* wt = n.find(pre + "skip_connection.weight");
+    const HostTensor* bt = n.find(pre + "skip_connection.bias");
+    if (!wt || !bt) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + pre + "skip_connection.*'");
+    DDMI_REQUIRE(wt->numel() == (int64_t)cout * cin && bt->numel() == cout, "skip_connection shape mismatch at " + pre);
+    std::vector<float> wa((size_t)cout * split), wb((size_t)cout * (cin - split));
+    for (int o = 0; o < cout; ++o) {
+      std::copy(wt->data.begin() + (size_t)o * cin, wt->data.begin() + (size_t)o * cin + split, wa.begin() + (size_t)o * split);
+      std::copy(wt->data.begin() + (size_t)o * cin + split, wt->data.begin() + (size_t)(o + 1) * cin,
+                wb.begin() + (size_t)o * (cin - split));
+    }
+    DDMI_TRY(n.make_conv_host(wa, cout, split, 1, &bt->data, &w->cs));
+    DDMI_TRY(n.make_conv_host(wb, cout, cin - split, 1, nullptr, &w->cs2));
+  } else if (cin != cout) {
     DDMI_TRY(n.make_conv(pre + "skip_connection.weight", pre + "skip_connection.bias", &w->cs));
     DDMI_REQUIRE(n.convs[w->cs].K == 1, "only 1x1 skip connections are supported (use_conv=False)");
   }
+  return DDMI_OK;
+}
+
+// ResBlock on the channel concatenation [x1 | x2] without materialising it: dual-source GroupNorm for in_layers, the
+// skip connection as conv(x1) + conv(x2)
+int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out) {
+  DDMI_REQUIRE(w.cs >= 0 && w.cs2 >= 0, "concat-free ResBlock needs a split skip connection");
+  DDMI_REQUIRE(n.tensors[x1].C + n.tensors[x2].C == n.convs[w.c1].Cin, "resblock input channel mismatch");
+  int sk = n.op_conv(x1, w.cs, 1, 0, -1, -1);
+  sk = n.op_conv(x2, w.cs2, 1, 0, sk, -1);
+  int a = n.op_gn(x1, w.gn1, 1, w.eps, x2);
+  int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off);
+  int b = n.op_gn(h, w.gn2, 1, w.eps);
+  *out = n.op_conv(b, w.c2, 1, 0, sk, -1);
   return DDMI_OK;
 }
 
@@ -227,13 +258,21 @@ int unet_finalize(UNet& u) {
       hs.pop_back();
       const TensorDesc ta = n.tensors[h], tb = n.tensors[skip];
       DDMI_REQUIRE(ta.H == tb.H && ta.W == tb.W, "skip connection spatial mismatch");
-      Op cat;
-      cat.kind = OP_CONCAT;
-      cat.in = h;
-      cat.in2 = skip;
-      cat.out = n.new_tensor(ta.C + tb.C, ta.H, ta.W);
-      n.ops.push_back(cat);
-      DDMI_TRY(build_resblock(u, pre + "0.", cat.out, mc * c.channel_mult[level], &h));
+      const int cout = mc * c.channel_mult[level];
+      static const bool no_cat = !(getenv("DDMI_KEEP_CONCAT") && getenv("DDMI_KEEP_CONCAT")[0] == '1');  // diagnostics
+      if (ta.C + tb.C != cout && no_cat) {  // th.cat([h, hs.pop()], 1) is read in place (dual-source GN, split skip conv)
+        ResW w;
+        DDMI_TRY(make_unet_resblock(u, pre + "0.", ta.C + tb.C, cout, &w, ta.C));
+        DDMI_TRY(emit_resblock_cat(n, w, h, skip, &h));
+      } else {
+        Op cat;
+        cat.kind = OP_CONCAT;
+        cat.in = h;
+        cat.in2 = skip;
+        cat.out = n.new_tensor(ta.C + tb.C, ta.H, ta.W);
+        n.ops.push_back(cat);
+        DDMI_TRY(build_resblock(u, pre + "0.", cat.out, cout, &h));
+      }
       int sub = 1;
       if (in_list(c.attention_resolutions, c.n_attn, ds)) {
         DDMI_TRY(build_attnblock(u, pre + std::to_string(sub) + ".", h, &h));

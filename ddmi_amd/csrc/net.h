@@ -103,7 +103,7 @@ struct Net {
   int dev_upload(const float* src, int64_t n, float** out);
   int make_conv(const std::string& wkey, const std::string& bkey, int* idx);   // [Cout,Cin,K,K] or [Cout,Cin,1] / [Cout,Cin]
   int make_gn(const std::string& prefix, int* idx);
-  int op_gn(int in, int gn, int silu, float eps);
+  int op_gn(int in, int gn, int silu, float eps, int in2 = -1);  // in2 >= 0: GroupNorm of the channel concat [in | in2]
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
   int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
   int plan();   // liveness + arena + workspaces

@@ -125,12 +125,13 @@ int Net::make_gn(const std::string& prefix, int* idx) {
   return DDMI_OK;
 }
 
-int Net::op_gn(int in, int gn, int silu, float eps) {
+int Net::op_gn(int in, int gn, int silu, float eps, int in2) {
   const TensorDesc& t = tensors[in];
   Op o;
   o.kind = OP_GN;
   o.in = in;
-  o.out = new_tensor(t.C, t.H, t.W, -1, t.bmul);
+  o.in2 = in2;
+  o.out = new_tensor(t.C + (in2 >= 0 ? tensors[in2].C : 0), t.H, t.W, -1, t.bmul);
   o.bmul = t.bmul;
   o.gn = gn;
   o.silu = silu;
@@ -377,10 +378,14 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
       case OP_GN: {
         const TensorDesc& t = tensors[o.in];
         const GNW& g = gns[o.gn];
-        DDMI_REQUIRE(g.C == t.C, "groupnorm channel mismatch");
+        // in2 >= 0: GroupNorm of the channel concatenation [in | in2] without materialising it
+        const int C = t.C + (o.in2 >= 0 ? tensors[o.in2].C : 0);
+        const void* x2 = o.in2 >= 0 ? tptr(o.in2) : nullptr;
+        DDMI_REQUIRE(g.C == C, "groupnorm channel mismatch");
         double* st = gn_stats;
-        DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, t.C, s));
-        DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, t.C, s));
+        DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, C, s, 0, 1, x2, t.C));
+        DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, C, s, nullptr,
+                                 1, x2, t.C));
         break;
       }
       case OP_CONV: {
