@@ -96,6 +96,7 @@ SYMBOLS = {
     "ddmi_mlp3d_finalize": (_I, [_VP]),
     "ddmi_hdpe_mlp3d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _VP, _I, _I, _VP]),
     "ddmi_mlp3d_destroy": (_I, [_VP]),
+    "ddmi_unet_set_graph": (_I, [_VP, _I]),
     "ddmi_unet3_create": (_I, [C.POINTER(UnetCfg), _I, _I, _I, C.POINTER(_VP)]),
     "ddmi_decoderv_create": (_I, [C.POINTER(DecoderVCfg), C.POINTER(_VP)]),
     "ddmi_decoderv_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),

@@ -74,6 +74,11 @@ int ddmi_unet_finalize(ddmi_unet* h) {
   if (h->u.net.finalized) return ddmi_fail(DDMI_ERR_STATE, "already finalized");
   return h->u.size1 > 0 ? unet3_finalize(h->u) : unet_finalize(h->u);
 }
+int ddmi_unet_set_graph(ddmi_unet* h, int enabled) {
+  DDMI_REQUIRE(h, "null handle");
+  h->u.use_graph = enabled != 0;
+  return DDMI_OK;
+}
 int ddmi_unet3_create(const ddmi_unet_cfg* cfg, int size1, int size2, int size3, ddmi_unet** out) {
   DDMI_REQUIRE(size1 > 0 && size2 > 0 && size3 > 0, "unet3_create: sizes must be positive");
   DDMI_TRY(ddmi_unet_create(cfg, out));

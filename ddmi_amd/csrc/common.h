@@ -20,6 +20,7 @@ static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 void ddmi_set_error(const std::string& msg);
 int ddmi_fail(int code, const std::string& msg);
+const char* ddmi_error_cstr();
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \

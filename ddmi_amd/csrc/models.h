@@ -13,6 +13,13 @@ struct UNet {
   float *freqs = nullptr, *te_w0 = nullptr, *te_b0 = nullptr, *te_w1 = nullptr, *te_b1 = nullptr;
   float *emb_w = nullptr, *emb_b = nullptr;
   float* tbuf = nullptr;         // [B][mc] temb | [B][E] | [B][E] | [B][emb_total]
+  // optional hipGraph replay of the whole forward (ddmi_unet_set_graph): ~900 launches of a small-batch forward cost
+  // more host + dispatch time than GPU time; a captured graph is keyed by (B, x, t, out, uniform_t) - a sampling loop
+  // ping-pongs between two x buffers, so two graphs serve it
+  struct GraphEntry { int B; const void* x; const void* t; void* out; bool uniform; hipGraphExec_t exec; };
+  bool use_graph = false;
+  std::vector<GraphEntry> graphs;
+  ~UNet();
 };
 int unet_finalize(UNet& u);
 // weight bundles of the blocks shared by the image and video networks (created once, emitted per tensor)

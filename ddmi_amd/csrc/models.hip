@@ -5,6 +5,7 @@
 #include "models.h"
 #include "prof.h"
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 
@@ -315,12 +316,55 @@ int unet_finish(UNet& u) {
   return n.plan();
 }
 
+UNet::~UNet() {
+  for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+}
+
+static int unet_forward_launch(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s);
+
 int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s) {
   Net& n = u.net;
   if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "unet not finalized");
   DDMI_REQUIRE(x && t && eps_out, "unet_forward: null pointer");
   DDMI_REQUIRE(B >= 1 && B <= n.max_batch, "unet_forward: batch exceeds max_batch");
   prof_begin_forward();
+  if (!u.use_graph || prof_active()) return unet_forward_launch(u, x, t, eps_out, B, s);
+  for (auto& g : u.graphs)
+    if (g.B == B && g.x == x && g.t == t && g.out == eps_out && g.uniform == u.uniform_t) {
+      HIP_TRY(hipGraphLaunch(g.exec, s));
+      return DDMI_OK;
+    }
+  // first call with these buffers: one plain run (lazy one-time setup such as kernel attributes must not happen inside a
+  // capture), then capture the same launches and keep the executable graph
+  DDMI_TRY(unet_forward_launch(u, x, t, eps_out, B, s));
+  if (u.graphs.size() >= 8) return DDMI_OK;  // an unbounded set of buffers: stay on the launch path
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = unet_forward_launch(u, x, t, eps_out, B, s);
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != DDMI_OK || e != hipSuccess || graph == nullptr) {
+    if (getenv("DDMI_GRAPH_DEBUG"))
+      fprintf(stderr, "ddmi: graph capture failed: rc=%d (%s) hip=%s\n", rc, ddmi_error_cstr(), hipGetErrorString(e));
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    u.use_graph = false;  // capture is not possible here (e.g. a legacy-stream restriction): fall back for good
+    return DDMI_OK;       // the plain run above already produced this call's result
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    if (getenv("DDMI_GRAPH_DEBUG")) fprintf(stderr, "ddmi: graph instantiate failed: %s\n", hipGetErrorString(e));
+    u.use_graph = false;
+    return DDMI_OK;
+  }
+  if (getenv("DDMI_GRAPH_DEBUG")) fprintf(stderr, "ddmi: captured a forward graph (B=%d)\n", B);
+  u.graphs.push_back(UNet::GraphEntry{B, x, t, eps_out, u.uniform_t, exec});
+  return DDMI_OK;  // the plain run above already produced this call's result
+}
+
+static int unet_forward_launch(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s) {
+  Net& n = u.net;
   const int mc = u.cfg.model_channels, E = u.emb_dim;
   float* temb = u.tbuf;                       // [B][mc]
   float* e1 = temb + (size_t)B * mc;          // [B][E]

@@ -182,6 +182,8 @@ class UNetModel:
         self._state = {}  # packed on device now
         if getattr(self, "_uniform_t", False):
             _lib.check(L.ddmi_unet_set_uniform_t(h, 1))
+        if getattr(self, "_use_graph", False):
+            _lib.check(L.ddmi_unet_set_graph(h, 1))
         return self
 
     def _create(self, L, cfg, h):
@@ -198,6 +200,13 @@ class UNetModel:
         self._uniform_t = bool(enabled)
         if self._handle is not None:
             _lib.check(_lib.lib().ddmi_unet_set_uniform_t(self._handle, int(enabled)))
+        return self
+
+    def set_graph(self, enabled: bool):
+        """Replay the forward as a hipGraph for repeated (batch, buffers) - small-batch latency; see ddmi_unet_set_graph."""
+        self._use_graph = bool(enabled)
+        if self._handle is not None:
+            _lib.check(_lib.lib().ddmi_unet_set_graph(self._handle, int(enabled)))
         return self
 
     def forward(self, x, timesteps=None, context=None, y=None, out=None, **kwargs):

@@ -71,6 +71,10 @@ int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps
 /* promise that every element of `t` equals t[0] in the following forwards (true for every sampling loop of
  * diffusion/ddpm.py: :294, :349): the time-embedding path then runs for one row instead of B */
 int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled);
+/* replay the forward as a hipGraph: the first call with a given (B, x, t, eps_out) runs and captures the launches, later
+ * calls with the same buffers are one hipGraphLaunch.  Worth it when the forward is launch-bound (batch <~ 16: ~900
+ * kernels of a few microseconds); at large batch it changes nothing.  The stream must not be the legacy null stream. */
+int ddmi_unet_set_graph(ddmi_unet* h, int enabled);
 int ddmi_unet_destroy(ddmi_unet* h);
 /* bytes held by the handle: [0] packed weights, [1] activation arena, [2] split-K slabs */
 int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]);
