@@ -34,12 +34,17 @@ def _newest_header() -> float:
     return max(os.path.getmtime(p) for p in deps)
 
 
+# per-file extras.  k_attention: keep MFMA results in VGPRs - the softmax between the two matrix products is VALU work on
+# the score accumulators, and with AGPR accumulators the compiler brackets it with ~80 v_accvgpr moves per 64-key tile
+EXTRA_FLAGS = {"k_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _compile(src: str, force: bool, hdr_mtime: float) -> str:
     obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_mtime):
         return obj
-    cmd = [hipcc(), *FLAGS, "-c", path, "-o", obj]
+    cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -398,13 +398,17 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
       float tmax = -INFINITY;
+      if (tail) {  // wave-uniform: only the last tile pays for the key-range masks
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kt * KT + 16 * f + 4 * lg + j >= N) sc[qf][f][j] = -INFINITY;
+      }
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (tail && kt * KT + 16 * f + 4 * lg + j >= N) sc[qf][f][j] = -INFINITY;
-          tmax = fmaxf(tmax, sc[qf][f][j]);
-        }
+        for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, sc[qf][f][j]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run[qf], tmax * sscale);
