@@ -287,7 +287,7 @@ template <int D> __device__ __forceinline__ int att_vswz(int key) {
   else return 2 * (key & 7);
 }
 
-template <int D, int QF>
+template <int D, int QF, bool SEG3>
 __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   using T = bf16_t;
   constexpr int KT = 64, RB = D * 2, TILE = KT * RB;
@@ -304,6 +304,12 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   const int d = a.d;
   const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
   const float sscale = a.scale * 1.44269504088896341f;
+  // token n of sample b -> (segment, row); with one segment (every per-plane / image attention) this is a plain offset
+  auto row_of = [&](int n, int* seg) -> int64_t {
+    if constexpr (SEG3) return att_row(a, b, n, seg);
+    *seg = 0;
+    return (int64_t)b * a.seg_len[0] + n;
+  };
 
   // ---- Q fragments ------------------------------------------------------------------------------------
   bf16x8 qb[QF][NKK];
@@ -313,8 +319,8 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
     const int q_idx = blockIdx.x * (64 * QF) + (wave * QF + qf) * 16 + lr;
     q_ok[qf] = q_idx < N;
     int seg = 0;
-    int64_t r = att_row(a, b, q_ok[qf] ? q_idx : 0, &seg);
-    const T* qp = (const T*)a.qkv[seg] + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
+    int64_t r = row_of(q_ok[qf] ? q_idx : 0, &seg);
+    const T* qp = (const T*)(SEG3 ? a.qkv[seg] : a.qkv[0]) + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk)
       qb[qf][kk] = q_ok[qf] && kk * 32 + 8 * lg < d ? *reinterpret_cast<const bf16x8*>(qp + kk * 32 + 8 * lg) : bf16x8{};
@@ -330,8 +336,8 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
       int kg = kt * KT + key;
       kg = kg < N ? kg : N - 1;  // rows past the end repeat the last key: finite data, scores masked below
       int seg = 0;
-      int64_t r = att_row(a, b, kg, &seg);
-      const T* base = (const T*)a.qkv[seg] + r * a.ld_qkv + h * a.hs_qkv + slot * 8;
+      int64_t r = row_of(kg, &seg);
+      const T* base = (const T*)(SEG3 ? a.qkv[seg] : a.qkv[0]) + r * a.ld_qkv + h * a.hs_qkv + slot * 8;
       const bool cok = slot * 8 < d;
       kreg[it] = cok ? *reinterpret_cast<const bf16x8*>(base + a.k_off) : bf16x8{};
       vreg[it] = cok ? *reinterpret_cast<const bf16x8*>(base + a.v_off) : bf16x8{};
@@ -457,8 +463,8 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
     if (!q_ok[qf]) continue;
     const float inv = 1.0f / l_run[qf];
     int seg = 0;
-    int64_t r = att_row(a, b, q_idx, &seg);
-    T* op = (T*)a.out[seg] + r * a.ld_out + h * a.hs_out;
+    int64_t r = row_of(q_idx, &seg);
+    T* op = (T*)(SEG3 ? a.out[seg] : a.out[0]) + r * a.ld_out + h * a.hs_out;
 #pragma unroll
     for (int df = 0; df < NDF; ++df) {
       const int c0 = 16 * df + 4 * lg;
@@ -475,15 +481,18 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 template <int D, int QF>
 static int launch_attention_v2(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = 4 * 64 * D * 2;
-  auto kern = attention_v2_kernel<D, QF>;
+  auto kern1 = attention_v2_kernel<D, QF, false>;
+  auto kern3 = attention_v2_kernel<D, QF, true>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
   dim3 grid(cdiv(N, 64 * QF), a.B * a.heads);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(kern3, grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
