@@ -192,3 +192,27 @@ def test_image_pipeline_matches_oracle_and_is_batch_invariant(golden):
     assert rel_err(img, ref["img"]) < TOL_FP32
     solo = pipe.generate([11], base_seed=5)
     assert rel_err(solo[0], img[2]) < 1e-5
+
+
+def test_unet_graph_replay_is_bit_identical(golden):
+    """ddmi_unet_set_graph: the captured hipGraph of a forward replays the very same launches."""
+    cfgs = golden.json("configs.json")
+    unet = make_unet(cfgs["TOY_UNET_B"], "U2b.unet", "bf16", max_batch=2)
+    x = torch.from_numpy(iw.normal("graph", "x", (2, 16, 16, 16))).to(DEV)
+    t = torch.tensor([5, 9], dtype=torch.int64, device=DEV)
+    side = torch.cuda.Stream()  # stream capture is not allowed on the legacy default stream
+    with torch.cuda.stream(side):
+        ref = unet(x, t).clone()
+        unet.set_graph(True)
+        out = torch.empty_like(ref)
+        for _ in range(3):  # capture, then two replays
+            unet(x, t, out=out)
+        side.synchronize()
+        assert torch.equal(out, ref)
+        x2 = x * 0.5  # same buffers, new contents: the graph reads the buffers, not a snapshot
+        x.copy_(x2)
+        unet(x, t, out=out)
+        unet.set_graph(False)
+        ref2 = unet(x, t)
+        side.synchronize()
+        assert torch.equal(out, ref2)
