@@ -125,8 +125,18 @@ int unet3_finalize(UNet& u) {
       DDMI_REQUIRE(n.tensors[h.xy].H == n.tensors[skip.xy].H && n.tensors[h.tp].H == n.tensors[skip.tp].H &&
                        n.tensors[h.tp].W == n.tensors[skip.tp].W,
                    "unet3: skip connection shape mismatch (sizes must be divisible by 2^(levels-1))");
-      h = concat_pair(n, h, skip);
-      DDMI_TRY(res(pre + "0.", h, mc * c.channel_mult[level], &h));
+      const int cat_c = n.tensors[h.xy].C + n.tensors[skip.xy].C, cout = mc * c.channel_mult[level];
+      if (cat_c != cout) {  // th.cat([h, hs.pop()], 1) read in place (dual-source GroupNorm, split skip convolution)
+        ResW w;
+        DDMI_TRY(make_unet_resblock(u, pre + "0.", cat_c, cout, &w, n.tensors[h.xy].C));
+        Pair o;
+        DDMI_TRY(emit_resblock_cat(n, w, h.xy, skip.xy, &o.xy));
+        DDMI_TRY(emit_resblock_cat(n, w, h.tp, skip.tp, &o.tp));
+        h = o;
+      } else {
+        h = concat_pair(n, h, skip);
+        DDMI_TRY(res(pre + "0.", h, cout, &h));
+      }
       int sub = 1;
       if (in_list_v(c.attention_resolutions, c.n_attn, ds)) {
         DDMI_TRY(attn(pre + std::to_string(sub) + ".", h, &h));
