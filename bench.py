@@ -183,12 +183,14 @@ def main():
             "config": {"workload": f"AFHQ 256x256, {args.nfe}-step DDPM (p_sample_loop, T={args.nfe}) + D2C-VAE decode + "
                                    "fused HDPE plane sampling/coordinate MLP, random-init named-seed weights",
                        "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "latent": [64, 64, 64],
-                       "parallelism": f"sample-parallel x{world} (independent chains, all-gather of finished images)"},
+                       "parallelism": f"sample-parallel x{world} (independent chains, all-gather of finished images)",
+                       "noise": "per-chain Philox streams drawn in the sampler-step kernel" if args.rng == "philox"
+                                else "one torch device generator per chain"},
             "roofline": roof, "kernel_time_share": breakdown,
             "last_step_phase_ms": {k: round(v, 2) for k, v in phase_ms.items()},
             "unet_memory_bytes": pipe.unet.memory(),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
