@@ -38,6 +38,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.UnetCfg) == 4 * (6 + 8 + 1 + 8 + 3)
     assert ctypes.sizeof(_lib.Decoder2dCfg) == 4 * (7 + 8 + 1 + 8 + 1 + 8 + 3)
     assert ctypes.sizeof(_lib.Mlp2dCfg) == 4 * 5
+    assert ctypes.sizeof(_lib.DecoderVCfg) == 4 * (6 + 4 * 9 + 3)
     assert ctypes.sizeof(_lib.StepCoefs) == 4 * 9
 
 
@@ -66,6 +67,33 @@ def test_manifests_match_reference_state_dicts(golden):
     assert same(mlp_manifest(**cfgs["MLP_CFG"]), man["M1.mlp"])
     nparams = sum(int(np.prod(s)) for _, s in unet_manifest(**AFHQ_UNET))
     assert abs(nparams - 519.2e6) < 0.2e6
+
+
+def test_video_manifests_match_reference_state_dicts(golden):
+    """Key names and shapes of the video classes' state dicts, as captured from the reference (gen_golden_video.py)."""
+    from ddmi_amd import video
+    man = golden.json("manifests_video.json")
+    cfgs = golden.json("configs_video.json")
+    for ref, mine in ((man["V1.unet3"], video.unet3_manifest(**cfgs["TOY_UNET_V"])),
+                      (man["V2.vit"], video.decoderv_manifest(cfgs["TOY_DDV"], cfgs["TOY_EMBED_V"])),
+                      (man["V3.mlpv"], video.mlpv_manifest(**cfgs["MLPV_CFG"]))):
+        assert {k: tuple(v) for k, v in ref.items()} == dict(mine)
+
+
+def test_video_config_and_pipeline_shapes():
+    """configs/ldm/skytimelapse.yaml in the reference's schema -> VideoPipeline (no GPU work): token-sequence length,
+    [1,C,1] mixing logit of the video domain (ddpm.py:152-159), DDIM selected by sampling_timesteps < timesteps."""
+    import argparse
+    import os
+    from ddmi_amd.config import load_ldm_args
+    from ddmi_amd.pipeline import VideoPipeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = load_ldm_args(os.path.join(root, "configs", "ldm", "skytimelapse.yaml"), argparse.Namespace())
+    assert a.domain == "video"
+    p = VideoPipeline(a.unetconfig, a.ddconfig, a.mlpconfig, a.ddpmconfig, a.embed_dim, frames=int(a.data_config.frames))
+    assert p.unet.seq_len == p.vae.seq_len == 32 * 32 + 2 * 32 * 16
+    assert p.ddpm.mixing_logit.shape == (1, 64, 1) and p.ddpm.is_ddim_sampling and p.ddpm.sampling_timesteps == 200
+    assert len(p.unet.manifest()) > 0 and sum(int(np.prod(s)) for _, s in p.unet.manifest()) == 767856704  # 767.9 M (SURVEY a14)
 
 
 def test_product_schedule_bitexact_vs_reference(golden):
