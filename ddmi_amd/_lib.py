@@ -45,6 +45,11 @@ class DecoderVCfg(C.Structure):
                 ("attn_heads", C.c_int), ("max_batch", C.c_int), ("numerics", C.c_int)]
 
 
+class McubesGrid(C.Structure):
+    _fields_ = [("volume", C.c_void_p), ("dtype", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("pad", C.c_int), ("pad_value", C.c_float), ("isovalue", C.c_double)]
+
+
 class Mlp2dCfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("ch", C.c_int), ("latent_dim", C.c_int),
                 ("numerics", C.c_int)]
@@ -117,6 +122,10 @@ SYMBOLS = {
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),
     "ddmi_op_attention_legacy": (_I, [_VP, _VP, _I, _I, _I, _I]),
     "ddmi_op_timestep_embedding": (_I, [_VP, _VP, _I, _I]),
+    "ddmi_mcubes_workspace_bytes": (_I, [C.POINTER(McubesGrid), C.POINTER(C.c_size_t)]),
+    "ddmi_mcubes_count": (_I, [C.POINTER(McubesGrid), _VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _VP]),
+    "ddmi_mcubes_emit": (_I, [C.POINTER(McubesGrid), _VP, _VP, _VP, _I, C.c_double, _VP]),
+    "ddmi_image_to_u8": (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -238,6 +238,42 @@ int ddmi_hdpe_mlpv(ddmi_mlpv* h, const void* const* planes, const int* plane_hw,
 int ddmi_mlpv_destroy(ddmi_mlpv* h);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Post-path consumers: what the reference does with the path's outputs, on the device.
+ * --------------------------------------------------------------------------------------------------------- */
+/* Marching cubes on a device-resident logit grid: replaces `libmcubes.marching_cubes(occ_hat_padded, threshold)`
+ * (convocc/src/conv_onet/generation.py:162; convocc/src/utils/libmcubes/mcubes.pyx:22-27, pywrapper.cpp:89-127,
+ * marchingcubes.h:21-237, marchingcubes.cpp:290-326) with IDENTICAL output: the same vertex numbering and triangle
+ * order as the reference's sequential sweep and bit-identical float64 coordinates.
+ *   volume      device pointer, C-contiguous [nx][ny][nz], dtype 0 = float32, 1 = float64
+ *   pad = 1     treats the grid as np.pad(volume, 1, constant_values=pad_value) (generation.py:160-161) without
+ *               materialising the padded copy; pad = 0 takes the array as it is
+ *   isovalue    the caller rounds it to C float first, as mcubes.pyx:22 (`float isovalue`) does
+ * Two calls, because the sizes of the outputs are data dependent:
+ *   ddmi_mcubes_count  classifies the cells and scans the counts into `workspace` (ddmi_mcubes_workspace_bytes, device
+ *                      memory), synchronises `stream` and returns the number of vertices and triangles;
+ *   ddmi_mcubes_emit   writes vertices [n_vertices][3] float64 and triangles [n_triangles][3] int64 (device pointers).
+ *                      normalize != 0 fuses extract_mesh's vertex post-processing (generation.py:165-183, vol_bound
+ *                      None): v -= 0.5; v -= 1; v /= (n_axis - 1); v = box_size * (v - 0.5), rounded op by op in
+ *                      float64 like numpy, n_axis being the UNPADDED grid size.
+ * A volume with fewer than 2 points along an axis yields 0 / 0 (the reference's loops never run). */
+typedef struct ddmi_mcubes_grid {
+  const void* volume;
+  int dtype;
+  int nx, ny, nz;
+  int pad;
+  float pad_value;
+  double isovalue;
+} ddmi_mcubes_grid;
+int ddmi_mcubes_workspace_bytes(const ddmi_mcubes_grid* grid, size_t* bytes);
+int ddmi_mcubes_count(const ddmi_mcubes_grid* grid, void* workspace, int64_t* n_vertices, int64_t* n_triangles, void* stream);
+int ddmi_mcubes_emit(const ddmi_mcubes_grid* grid, const void* workspace, double* vertices, int64_t* triangles,
+                     int normalize, double box_size, void* stream);
+/* Image write-out of the FID / sample-saving loop (evals/eval.py:226-233): img [B,C,H,W] fp32 (the MLP's output,
+ * unclamped or clamped) -> out [B,H,W,C] uint8 = trunc(((clamp(img,-1,1) + 1) / 2) * 255), each step rounded in fp32
+ * exactly as torch / numpy do, so the bytes equal the reference's `(fake_img * 255).astype(np.uint8)`. */
+int ddmi_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Diagnostic single-op entry points (used by the parity tests; reference-layout tensors in, reference-layout
  * tensors out; they allocate temporaries and synchronise - not for the hot path).
  * --------------------------------------------------------------------------------------------------------- */

@@ -1,0 +1,103 @@
+"""Post-path consumers on the GPU through the C ABI: marching cubes bit-identical to the
+reference's sequential libmcubes (vertices, triangles AND their order), extract_mesh, and the uint8 image write-out."""
+import numpy as np
+import pytest
+import torch
+
+from ddmi_amd import mcubes
+from oracle import mcubes_oracle as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CASES = ["rand_f32", "rand_f32_iso", "ties_f64", "iso_rounding_f64", "single_cell", "no_cells", "no_surface", "all_inside"]
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_vectors(golden, name):
+    c = golden.npz("mcubes_cases.npz")
+    v, f = mcubes.marching_cubes(c[f"{name}.volume"], float(c[f"{name}.iso"]))  # numpy in -> numpy out, like libmcubes
+    assert v.dtype == np.float64 and f.dtype == np.uint64
+    assert same(v, c[f"{name}.vertices"]) and same(f, c[f"{name}.triangles"])
+
+
+@pytest.mark.parametrize("tag", ["mesh_t02", "mesh_t05"])
+def test_extract_mesh_vectors(golden, tag):
+    c = golden.npz("mcubes_cases.npz")
+    occ = torch.from_numpy(c[f"{tag}.occ"]).to(DEV)
+    v, f = mcubes.extract_mesh(occ, float(c[f"{tag}.threshold"]), float(c[f"{tag}.padding"]))
+    assert v.is_cuda and v.dtype == torch.float64 and f.dtype == torch.int64
+    assert same(v.cpu().numpy(), c[f"{tag}.vertices"]) and same(f.cpu().numpy().astype(np.uint64), c[f"{tag}.triangles"])
+
+
+@pytest.mark.parametrize("shape,iso,dtype", [((33, 31, 35), 0.1, np.float32), ((20, 40, 10), -0.7, np.float64),
+                                              ((2, 70, 3), 0.0, np.float32), ((65, 64, 63), 0.25, np.float32),
+                                              ((130, 130, 130), 1.5, np.float32)])
+def test_random_volumes_against_oracle(shape, iso, dtype):
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.standard_normal(shape).astype(dtype)
+    v, f = mcubes.marching_cubes(vol, iso)
+    rv, rf = M.marching_cubes(vol, iso)
+    assert same(v, rv) and same(f, rf)
+
+
+def test_virtual_border_equals_np_pad():
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((30, 28, 26)).astype(np.float32)
+    dv = torch.from_numpy(vol).to(DEV)
+    v1, f1 = mcubes.marching_cubes(dv, -0.2, pad=1, pad_value=-1e6)
+    rv, rf = M.marching_cubes(np.pad(vol, 1, "constant", constant_values=-1e6), -0.2)
+    assert same(v1.cpu().numpy(), rv) and same(f1.cpu().numpy().astype(np.uint64), rf)
+
+
+def _smooth_field(n, seed=0):
+    g = torch.linspace(-1, 1, n, device=DEV)
+    x, y, z = torch.meshgrid(g, g, g, indexing="ij")
+    r = torch.sqrt((x - 0.05) ** 2 + (y + 0.02) ** 2 + (z - 0.03) ** 2)
+    return (4.0 * (0.62 - r) + 0.3 * torch.sin(7 * x) * torch.cos(5 * y + z)).float()
+
+
+def test_extract_mesh_128_against_oracle():
+    occ = _smooth_field(128)
+    v, f = mcubes.extract_mesh(occ, 0.2, 0.1)
+    rv, rf = M.extract_mesh(occ.cpu().numpy(), 0.2, 0.1)
+    assert same(v.cpu().numpy(), rv) and same(f.cpu().numpy().astype(np.uint64), rf)
+
+
+def test_extract_mesh_256_is_a_closed_surface():
+    # BASELINE's largest grid (256^3 + border = 17 M cells): size-independent properties instead of the oracle
+    occ = _smooth_field(256)
+    v, f = mcubes.extract_mesh(occ, 0.2, 0.1)
+    nv = v.shape[0]
+    assert nv > 100000 and int(f.min()) == 0 and int(f.max()) == nv - 1
+    assert torch.unique(f).numel() == nv                      # every vertex is used
+    assert float(v.abs().max()) <= 0.55 * (1 + 2.0 / 255)    # inside the (1 + padding) box (plus the border cell)
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = torch.minimum(e[:, 0], e[:, 1]) * nv + torch.maximum(e[:, 0], e[:, 1])
+    _, cnt = torch.unique(key, return_counts=True)
+    assert bool((cnt == 2).all())                             # watertight: every edge in exactly two triangles
+    assert nv - cnt.numel() + f.shape[0] == 2                 # Euler characteristic of a sphere-like surface
+    # a second run gives the same bytes (no atomics, no ordering dependence)
+    v2, f2 = mcubes.extract_mesh(occ, 0.2, 0.1)
+    assert torch.equal(v, v2) and torch.equal(f, f2)
+
+
+def test_images_to_uint8_is_bit_exact():
+    rng = np.random.default_rng(3)
+    img = (1.3 * rng.standard_normal((3, 3, 32, 48))).astype(np.float32)
+    img.reshape(-1)[:8] = [-1.0, 1.0, 0.0, -0.0, 1.0 - 2 ** -24, -1.0 + 2 ** -24, 0.00392157, 7.5]
+    # every fp32 x whose (x+1)/2*255 lands next to an integer boundary
+    k = np.arange(256, dtype=np.float64)
+    edge = (2 * k / 255 - 1).astype(np.float32)
+    img.reshape(-1)[8:8 + 256] = edge
+    img.reshape(-1)[264:264 + 256] = np.nextafter(edge, np.float32(-2))
+    img.reshape(-1)[520:520 + 256] = np.nextafter(edge, np.float32(2))
+    out = mcubes.images_to_uint8(torch.from_numpy(img).to(DEV)).cpu().numpy()
+    fake = torch.from_numpy(img).clamp(-1., 1.)          # evals/eval.py:226-232 restated
+    fake2 = (fake + 1) / 2
+    want = np.stack([(fake2[b].numpy().transpose(1, 2, 0) * 255).astype(np.uint8) for b in range(img.shape[0])])
+    assert out.dtype == np.uint8 and out.shape == (3, 32, 48, 3)
+    assert np.array_equal(out, want)

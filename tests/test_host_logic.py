@@ -40,6 +40,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Mlp2dCfg) == 4 * 5
     assert ctypes.sizeof(_lib.DecoderVCfg) == 4 * (6 + 4 * 9 + 3)
     assert ctypes.sizeof(_lib.StepCoefs) == 4 * 9
+    assert ctypes.sizeof(_lib.McubesGrid) == 8 + 4 * 6 + 8  # pointer, dtype, nx, ny, nz, pad, pad_value, double
 
 
 def test_errors_are_reported_without_a_gpu():
