@@ -305,3 +305,47 @@ def occupancy_grid_logits(mlp: MLP3D, planes, nx: int, padding: float = 0.1):
         _GRID_CACHE[key] = pts
     logits = mlp(pts[None].expand(B, -1, -1).contiguous(), planes).logits
     return logits.reshape(B, nx, nx, nx)
+
+
+class TriMesh:
+    """What Generator3D hands back in place of trimesh.Trimesh(vertices, triangles, process=False) (generation.py:195-197;
+    trimesh is not a dependency here): the arrays, and `export` for the Wavefront .obj the sampling loops write
+    (tools/ldm/occupancy.py:218,228)."""
+
+    def __init__(self, vertices, faces):
+        self.vertices, self.faces = vertices, faces
+
+    def export(self, path: str):
+        import numpy as np
+        with open(path, "w") as f:
+            np.savetxt(f, self.vertices, fmt="v %.8f %.8f %.8f")
+            np.savetxt(f, np.asarray(self.faces, dtype=np.int64) + 1, fmt="f %d %d %d")
+        return path
+
+
+class Generator3D:
+    """Generator3D.generate_mesh_fromdiffusion (convocc/src/conv_onet/generation.py:66-121, 146-207) for the branch the
+    shipped configs take (upsampling_steps 0, vol_bound None, no refinement / simplification / normals): decode the latent
+    to tri-planes, evaluate the fused plane sampling + MLP3D on the dense (1+padding) grid in one launch, and extract the
+    iso-surface ON THE DEVICE (csrc/k_mcubes.hip) - the resolution0^3 logit grid is never copied to the host.
+    Defaults follow get_generator (convocc/src/conv_onet/config.py:117-128) over convocc/configs/default.yaml."""
+
+    def __init__(self, threshold: float = 0.5, resolution0: int = 256, upsampling_steps: int = 0, padding: float = 0.1,
+                 refinement_step: int = 0, simplify_nfaces=None, with_normals: bool = False, **_ignored):
+        if upsampling_steps != 0:
+            raise NotImplementedError("MISE refinement (upsampling_steps > 0) is outside the path: the dense grid costs "
+                                      "one fused launch here")
+        if refinement_step or simplify_nfaces is not None or with_normals:
+            raise NotImplementedError("mesh refinement / simplification / normals are outside the path")
+        self.threshold, self.resolution0, self.padding = threshold, resolution0, padding
+
+    def generate_mesh_fromdiffusion(self, latent, vaemodel, mlp, device=None):
+        """-> (mesh, mesh2): mesh = TriMesh(vertices float64 [nv,3], faces int64 [nf,3]) on the host, mesh2 = the
+        device-resident pair pytorch3d's Meshes is built from (verts float32 [1,nv,3], faces int64 [1,nf,3])."""
+        from .mcubes import extract_mesh
+        planes = vaemodel.decode(latent)
+        grid = occupancy_grid_logits(mlp, planes, self.resolution0, self.padding)
+        assert grid.shape[0] == 1, "the reference extracts one mesh per call (tools/ldm/occupancy.py:216-217)"
+        v, f = extract_mesh(grid[0], self.threshold, self.padding)
+        mesh2 = {"verts": v.float().unsqueeze(0), "faces": f.unsqueeze(0)}
+        return TriMesh(v.cpu().numpy(), f.cpu().numpy()), mesh2

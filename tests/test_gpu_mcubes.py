@@ -101,3 +101,31 @@ def test_images_to_uint8_is_bit_exact():
     want = np.stack([(fake2[b].numpy().transpose(1, 2, 0) * 255).astype(np.uint8) for b in range(img.shape[0])])
     assert out.dtype == np.uint8 and out.shape == (3, 32, 48, 3)
     assert np.array_equal(out, want)
+
+
+def test_generator3d_end_to_end(golden, tmp_path):
+    """Generator3D.generate_mesh_fromdiffusion: latent -> tri-planes -> dense logits -> mesh, all on the device.  The mesh
+    must be exactly what the reference's extract_mesh (oracle, pinned to marchingcubes.cpp) makes of the SAME logit grid."""
+    from ddmi_amd.occupancy import MLP3D, Autoencoder3D, Generator3D, occupancy_grid_logits
+    from helpers import named_state
+    cfgs = golden.json("configs.json")
+    vae = Autoencoder3D(cfgs["TOY_DD3"], cfgs["TOY_EMBED3"], numerics="fp32", max_batch=1)
+    vae.load_state_dict(named_state("O1.vae3d", vae.manifest()))
+    mlp = MLP3D(numerics="fp32")
+    mlp.load_state_dict(named_state("O1.mlp3d", mlp.manifest()))
+    z = torch.from_numpy(golden.npz("O1_occupancy.npz")["z"][:1]).to(DEV)
+    grid = occupancy_grid_logits(mlp, vae.decode(z), 48, 0.1)[0]
+    thr = float(torch.sigmoid(grid.median()))          # random weights: put the surface where the logits are
+    gen = Generator3D(threshold=thr, resolution0=48, upsampling_steps=0, padding=0.1)
+    mesh, mesh2 = gen.generate_mesh_fromdiffusion(z, vae, mlp, DEV)
+    rv, rf = M.extract_mesh(grid.cpu().numpy(), thr, 0.1)
+    assert len(rf) > 1000
+    assert same(mesh.vertices, rv) and same(mesh.faces.astype(np.uint64), rf)
+    assert mesh2["verts"].shape == (1, len(rv), 3) and mesh2["verts"].dtype == torch.float32
+    assert mesh2["faces"].shape == (1, len(rf), 3) and mesh2["faces"].dtype == torch.int64
+    path = mesh.export(str(tmp_path / "generation.obj"))
+    lines = open(path).read().splitlines()
+    assert len(lines) == len(rv) + len(rf) and lines[0].startswith("v ") and lines[-1].startswith("f ")
+    assert int(lines[-1].split()[1]) == int(rf[-1, 0]) + 1   # .obj indices are 1-based
+    with pytest.raises(NotImplementedError):
+        Generator3D(upsampling_steps=2)
