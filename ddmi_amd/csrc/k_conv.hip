@@ -46,7 +46,7 @@ struct ConvK {
   int tile_map;                             // 0 row-major, 1 XCD-contiguous m-major, 2 XCD-contiguous n-major
   int paired;                               // pipe kernel: paired-fragment instantiation (order 3 / 4)
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
-  int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier
+  int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier, 8 no epilogue
   float out_scale;
   uint64_t x_bytes;                         // activation extent in bytes (per batch entry); may exceed 2 GiB
   unsigned w_bytes;                         // weight extent (per batch entry) for the range check
@@ -199,6 +199,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV]
 template <typename T, int FM, int FN, bool PAIRED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
                                               int lg, int hw) {
+  if (a.dbg & 8) return;
   T* __restrict__ yg = a.y ? (T*)a.y + (int64_t)blockIdx.y * a.y_bstride : nullptr;
   const T* __restrict__ rg = (const T*)a.res;
   constexpr int NPAIR = PAIRED ? FN / 2 : 0;
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 15, lg = lane >> 4;
+
 
 #pragma unroll
   for (int p = 0; p < NST - 1; ++p)
