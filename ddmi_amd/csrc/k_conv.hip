@@ -46,8 +46,9 @@ struct ConvK {
   int tile_map;                             // 0 row-major, 1 XCD-contiguous m-major, 2 XCD-contiguous n-major
   int paired;                               // pipe kernel: paired-fragment instantiation (order 3 / 4)
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
-  int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier, 8 no epilogue
+  int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier, 8 no epilogue, 16 general epilogue only
   float out_scale;
+  unsigned long long* ts;                   // diagnostics (DDMI_CONV_TS): per-workgroup phase timestamps, ring kernel only
   uint64_t x_bytes;                         // activation extent in bytes (per batch entry); may exceed 2 GiB
   unsigned w_bytes;                         // weight extent (per batch entry) for the range check
   int64_t x_bstride, w_bstride, y_bstride;  // element strides for blockIdx.y (batched GEMM mode)
@@ -196,10 +197,113 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV]
   }
 }
 
+// The common case of the bf16 kernels - plain NHWC output, the wave's whole channel range exists, all of the wave's rows
+// in one sample - without the per-element generality of the path below.  That path waits for every bias / embedding /
+// residual load right where it is issued (48 dependent round trips per wave) and re-derives every address: measured with
+// DDMI_CONV_TS on the 448->1344 1x1 conv, its epilogue took 4.2 us of a 24 us tile BEFORE any store was issued.  Here the
+// per-channel constant (bias + the sample's embedding row) is loaded once per wave, the residual rows of fragment row
+// i+1 are in flight while row i is converted and stored, and there is one 64-bit address per fragment row.
+template <int FM, int FN>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
+                                                   int lg, int hw) {
+  using T = bf16_t;
+  constexpr int NPAIR = FN / 2;
+  constexpr bool ODD = (FN & 1) != 0;
+  if (m_base >= a.M) return;
+  T* __restrict__ yg = (T*)a.y + (int64_t)blockIdx.y * a.y_bstride;
+  const T* __restrict__ rg = (const T*)a.res;
+  const int n_pair = n_base + 8 * lg;                             // + 32 p: eight consecutive channels of pair p
+  const int n_odd = n_base + frag_chan<FN, true>(FN - 1, lg);     // the unpaired last fragment: four channels
+
+  f32x4 cb[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) cb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      cb[2 * p] = *reinterpret_cast<const f32x4*>(a.bias + n_pair + 32 * p);
+      cb[2 * p + 1] = *reinterpret_cast<const f32x4*>(a.bias + n_pair + 32 * p + 4);
+    }
+    if constexpr (ODD) cb[FN - 1] = *reinterpret_cast<const f32x4*>(a.bias + n_odd);
+  }
+  if (a.emb) {
+    int be = m_base / hw;   // wave-uniform: the caller checked that the wave's rows share a sample
+    if (a.emb_mod) {
+      be -= be >= a.emb_mod ? a.emb_mod : 0;
+      be -= be >= a.emb_mod ? a.emb_mod : 0;
+    }
+    const float* pe = a.emb + (int64_t)be * a.emb_stride;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      cb[2 * p] += *reinterpret_cast<const f32x4*>(pe + n_pair + 32 * p);
+      cb[2 * p + 1] += *reinterpret_cast<const f32x4*>(pe + n_pair + 32 * p + 4);
+    }
+    if constexpr (ODD) cb[FN - 1] += *reinterpret_cast<const f32x4*>(pe + n_odd);
+  }
+
+  bf16x8 rp[2][NPAIR > 0 ? NPAIR : 1];
+  bf16x4 ro[2];
+  auto load_res = [&](int i, int slot) {
+    const int m = m_base + i * 16 + lr;
+    if (m < a.M) {
+      const T* row = rg + (int64_t)m * a.Cout;
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) rp[slot][p] = *reinterpret_cast<const bf16x8*>(row + n_pair + 32 * p);
+      if constexpr (ODD) ro[slot] = *reinterpret_cast<const bf16x4*>(row + n_odd);
+    }
+  };
+  if (rg) load_res(0, 0);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    if (rg && i + 1 < FM) load_res(i + 1, (i + 1) & 1);
+    const int m = m_base + i * 16 + lr;
+    if (m >= a.M) continue;
+    T* row = yg + (int64_t)m * a.Cout;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[i][2 * p][e] + cb[2 * p][e];
+        v[4 + e] = acc[i][2 * p + 1][e] + cb[2 * p + 1][e];
+      }
+      if (rg) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rp[i & 1][p][e];
+      }
+      bf16x8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (bf16_t)(v[e] * a.out_scale);
+      *reinterpret_cast<bf16x8*>(row + n_pair + 32 * p) = t;
+    }
+    if constexpr (ODD) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][FN - 1][e] + cb[FN - 1][e];
+      if (rg) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)ro[i & 1][e];
+      }
+      bf16x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = (bf16_t)(v[e] * a.out_scale);
+      *reinterpret_cast<bf16x4*>(row + n_odd) = t;
+    }
+  }
+}
+
 template <typename T, int FM, int FN, bool PAIRED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
                                               int lg, int hw) {
   if (a.dbg & 8) return;
+  if constexpr (PAIRED && sizeof(T) == 2 && (FM == 2 || FM == 4)) {
+    // wave-uniform test (m_base, n_base and the kernel arguments are): FM * 16 is 32 or 64, a power of two
+    if (!(a.dbg & 16) && a.ws == nullptr && a.y_nchw == nullptr && n_base + FN * 16 <= a.Cout &&
+        (a.emb == nullptr || (hw & (FM * 16 - 1)) == 0)) {
+      conv_epilogue_fast<FM, FN>(a, acc, m_base, n_base, lr, lg, hw);
+      return;
+    }
+  }
   T* __restrict__ yg = a.y ? (T*)a.y + (int64_t)blockIdx.y * a.y_bstride : nullptr;
   const T* __restrict__ rg = (const T*)a.res;
   constexpr int NPAIR = PAIRED ? FN / 2 : 0;
@@ -273,6 +377,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  unsigned long long* const ts = a.ts && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 ? a.ts + 8 * blockIdx.x : nullptr;
+  if (ts) {
+    ts[0] = wall_clock64();
+    ts[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) |   // XCC_ID
+            __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);                               // HW_ID
+  }
   const TileMN tmn = conv_tile_of_block(a.tile_map, a.tiles_n);
   const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -380,7 +490,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
 
   const int lr = lane & 15, lg = lane >> 4;
 
-
+  if (ts) ts[1] = wall_clock64();
 #pragma unroll
   for (int p = 0; p < NST - 1; ++p)
     if (s_begin + p < s_end && !(a.dbg & 1)) load_stage(p);
@@ -394,6 +504,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     else if (NST > 4 && ahead == NST - 4) wait_vmcnt<(NST > 4 ? L * (NST - 4) : 0)>();
     else wait_vmcnt<0>();
     if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
+    if (ts && s == s_begin) ts[2] = wall_clock64();
     if (s + NST - 1 < s_end && !(a.dbg & 1)) load_stage(buf == 0 ? NST - 1 : buf - 1);  // refill the released buffer
 
     const unsigned char* sa = smem + buf * STAGE_BYTES;
@@ -420,7 +531,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
   }
+  if (ts) ts[3] = wall_clock64();
   conv_epilogue<T, FM, FN, true>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+  if (ts) {
+    ts[4] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = wall_clock64();   // this wave's stores acknowledged
+  }
 }
 
 // =====================================================================================================
@@ -1199,6 +1316,47 @@ static int launch_cfg(ConvK k, int splitk, int batch, hipStream_t s) {
   return DDMI_OK;
 }
 
+// DDMI_CONV_TS=1: the 6th ring launch of the process prints, for a few CUs, what each workgroup that ran there did when
+// (100 MHz wall clock, us since the kernel's first workgroup): index setup, first stage landed, K loop, epilogue issue,
+// store acknowledgement, and the gap to the next workgroup of the same slot.
+static void conv_dump_timeline(const unsigned long long* ts_dev, int n, hipStream_t s) {
+  std::vector<unsigned long long> h((size_t)n * 8);
+  if (hipStreamSynchronize(s) != hipSuccess) return;
+  if (hipMemcpy(h.data(), ts_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  unsigned long long t_min = ~0ull, t_max = 0;
+  for (int i = 0; i < n; ++i) { t_min = std::min(t_min, h[8 * i]); t_max = std::max(t_max, h[8 * i + 6]); }
+  struct Rec { unsigned key; int wg; };
+  std::vector<Rec> order(n);
+  for (int i = 0; i < n; ++i) {
+    unsigned hw = (unsigned)h[8 * i + 5], xcc = (unsigned)(h[8 * i + 5] >> 32) & 15;
+    unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+    order[i] = {(xcc << 12) | (se << 8) | (sh << 4) | cu, i};
+  }
+  std::sort(order.begin(), order.end(), [&](const Rec& a, const Rec& b) {
+    return a.key != b.key ? a.key < b.key : h[8 * a.wg] < h[8 * b.wg];
+  });
+  fprintf(stderr, "[conv timeline] %d workgroups, kernel span %.1f us\n", n, (t_max - t_min) / 100.0);
+  int cus = 0;
+  double sum[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const unsigned long long* t = &h[8 * order[i].wg];
+    for (int q = 0; q < 4; ++q) sum[q] += (t[q + 1] - t[q]) / 100.0;
+    sum[4] += (t[6] - t[4]) / 100.0;
+    sum[5] += (t[6] - t[0]) / 100.0;
+  }
+  fprintf(stderr, "  mean per workgroup: setup %.2f  first-stage %.2f  k-loop %.2f  epilogue-issue %.2f  store-ack %.2f  total %.2f us\n",
+          sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n);
+  for (int i = 0; i < n && cus < 2; ++i) {
+    if (i && order[i].key != order[i - 1].key) ++cus;
+    if (cus >= 2) break;
+    const unsigned long long* t = &h[8 * order[i].wg];
+    unsigned hw = (unsigned)t[5];
+    fprintf(stderr, "  cu %05x tg %u wg %5d: start %8.2f  setup %5.2f  first-stage %5.2f  k-loop %6.2f  epilogue %5.2f  ack %5.2f  end %8.2f\n",
+            order[i].key, (hw >> 16) & 15, order[i].wg, (t[0] - t_min) / 100.0, (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0,
+            (t[3] - t[2]) / 100.0, (t[4] - t[3]) / 100.0, (t[6] - t[4]) / 100.0, (t[6] - t_min) / 100.0);
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int KPS, int NST>
 static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
   constexpr int lds = NST * KPS * (BM + BN) * 64 + WM * WN * 1024;
@@ -1211,6 +1369,13 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  static const bool want_ts = getenv("DDMI_CONV_TS") != nullptr;
+  static unsigned long long* ts_dev = nullptr;
+  static int ts_launch = 0;
+  if (want_ts) {
+    if (!ts_dev) HIP_TRY(hipMalloc(&ts_dev, sizeof(unsigned long long) * 8 * 65536));
+    k.ts = grid.x <= 65536 ? ts_dev : nullptr;
+  }
   {
     double flops, bytes;
     conv_work(k, batch, 2, &flops, &bytes);
@@ -1220,6 +1385,7 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
+  if (k.ts && ++ts_launch == 6) conv_dump_timeline(ts_dev, (int)grid.x, s);
   return DDMI_OK;
 }
 
