@@ -48,7 +48,7 @@ struct ConvK {
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
   int dbg;                                  // diagnostics (DDMI_CONV_DBG): 1 no DMA, 2 no ds_read/MFMA, 4 no barrier, 8 no epilogue, 16 general epilogue only
   float out_scale;
-  unsigned long long* ts;                   // diagnostics (DDMI_CONV_TS): per-workgroup phase timestamps, ring kernel only
+  unsigned long long* ts;                   // diagnostics (DDMI_CONV_TS): per-workgroup phase timestamps (ring and halo kernels)
   uint64_t x_bytes;                         // activation extent in bytes (per batch entry); may exceed 2 GiB
   unsigned w_bytes;                         // weight extent (per batch entry) for the range check
   int64_t x_bstride, w_bstride, y_bstride;  // element strides for blockIdx.y (batched GEMM mode)
@@ -783,6 +783,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  unsigned long long* const ts = a.ts && tid == 0 && blockIdx.z == 0 ? a.ts + 8 * blockIdx.x : nullptr;
+  if (ts) {
+    ts[0] = wall_clock64();
+    ts[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) |   // XCC_ID
+            __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);                               // HW_ID
+  }
   const TileMN tmn = conv_tile_of_block(a.tile_map, a.tiles_n);
   const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -882,12 +888,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int nstage = (cb_end - cb_begin) * 9;
   bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
 
+  if (ts) ts[1] = wall_clock64();
   if (nstage > 0) {
     for (int g = wave; g < GH; g += NW) load_halo_group(g, cb_begin, 0);
     load_b_stage(cb_begin, 0, 0, true);
     load_b_stage(cb_begin, 1, 1, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (ts) ts[2] = wall_clock64();
     read_frags(0, 0, 0, 0, xa, wa);
   }
   // one flat stage loop; (cb, tap, kw, shift, hbuf) are scalar state so nothing per-tap gets unrolled or hoisted
@@ -917,7 +925,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, 0, xa, wa);
     if (c1) mma(xb, wb);
   }
+  if (ts) ts[3] = wall_clock64();
   conv_epilogue<T, FM, FN, true>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+  if (ts) {
+    ts[4] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = wall_clock64();
+  }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KPS>
@@ -1357,6 +1371,14 @@ static void conv_dump_timeline(const unsigned long long* ts_dev, int n, hipStrea
   }
 }
 
+static unsigned long long* conv_ts_buffer(int n_workgroups) {
+  static const bool want = getenv("DDMI_CONV_TS") != nullptr;
+  static unsigned long long* dev = nullptr;
+  if (!want || n_workgroups > 65536) return nullptr;
+  if (!dev && hipMalloc(&dev, sizeof(unsigned long long) * 8 * 65536) != hipSuccess) return nullptr;
+  return dev;
+}
+
 template <int BM, int BN, int WM, int WN, int KPS, int NST>
 static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
   constexpr int lds = NST * KPS * (BM + BN) * 64 + WM * WN * 1024;
@@ -1369,13 +1391,8 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  static const bool want_ts = getenv("DDMI_CONV_TS") != nullptr;
-  static unsigned long long* ts_dev = nullptr;
   static int ts_launch = 0;
-  if (want_ts) {
-    if (!ts_dev) HIP_TRY(hipMalloc(&ts_dev, sizeof(unsigned long long) * 8 * 65536));
-    k.ts = grid.x <= 65536 ? ts_dev : nullptr;
-  }
+  k.ts = conv_ts_buffer((int)grid.x);
   {
     double flops, bytes;
     conv_work(k, batch, 2, &flops, &bytes);
@@ -1385,7 +1402,7 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
-  if (k.ts && ++ts_launch == 6) conv_dump_timeline(ts_dev, (int)grid.x, s);
+  if (k.ts && ++ts_launch == 6) conv_dump_timeline(k.ts, (int)grid.x, s);
   return DDMI_OK;
 }
 
@@ -1435,9 +1452,12 @@ static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_halo<bf16,256x" + std::to_string(BN) + ">";
     PROF_SCOPE(name.c_str(), flops, bytes, s);
+    k.ts = conv_ts_buffer((int)grid.x);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
+  static int ts_launch = 0;
+  if (k.ts && ++ts_launch == 6) conv_dump_timeline(k.ts, (int)grid.x, s);
   return DDMI_OK;
 }
 
