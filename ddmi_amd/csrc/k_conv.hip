@@ -774,8 +774,6 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   constexpr int GB = BN / 8, B_PER = (GB + NW - 1) / NW;
   constexpr int ROWB = 128, SZ = 2;
   constexpr int H_BYTES = HALO_MAX_ROWS * ROWB, B_BYTES = BN * ROWB;
-  unsigned char* const smem_base = nullptr;
-  (void)smem_base;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const HB = smem;                 // [2][H_BYTES]
   unsigned char* const BB = smem + 2 * H_BYTES;   // [2][B_BYTES]
