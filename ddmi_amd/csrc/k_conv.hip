@@ -43,6 +43,7 @@ struct ConvK {
   int NS;       // total stages
   int SPS;      // stages per split
   int tiles_n;
+  int up4;                                  // x2 nearest upsample + 3x3 as four 2x2 parity convolutions (blockIdx.y = 2 dy + dx)
   int tile_map;                             // 0 row-major, 1 XCD-contiguous m-major, 2 XCD-contiguous n-major
   int paired;                               // pipe kernel: paired-fragment instantiation (order 3 / 4)
   int chan_major;                           // K walk order (ring kernel): taps innermost when set
@@ -97,6 +98,20 @@ __device__ __forceinline__ TileMN conv_tile_of_block(int tile_map, int tiles_n) 
     t.n = id - t.m * tiles_n;
   }
   return t;
+}
+
+// ---- x2 nearest upsample fused into a 3x3 convolution, computed on the SOURCE grid ---------------------------------
+// Output pixel (2y+dy, 2x+dx) of conv3x3(upsample2(x)) only ever sees the 2x2 source neighbourhood rows {y-1+dy, y+dy},
+// columns {x-1+dx, x+dx}: the three taps of each axis collapse onto two source pixels.  So the op is four 2x2
+// convolutions over the source image - one per output parity, weights pre-summed (conv_pack_up4_kernel) - with
+// 16 tap-products per 2x2 output block instead of 36: 2.25x fewer FLOPs, same result up to the rounding of the summed
+// weights.  blockIdx.y is the parity; M counts source pixels; the epilogue scatters rows to (2y+dy, 2x+dx).
+__device__ __forceinline__ int conv_pad_h(const ConvK& a) { return a.up4 ? a.pad - (int)(blockIdx.y >> 1) : a.pad; }
+__device__ __forceinline__ int conv_pad_w(const ConvK& a) { return a.up4 ? a.pad - (int)(blockIdx.y & 1) : a.pad; }
+__device__ __forceinline__ int64_t conv_out_row(const ConvK& a, int m, int b, int hw) {
+  if (!a.up4) return m;
+  const int r = m - b * hw, y = r / a.Wout, x = r - y * a.Wout;
+  return ((int64_t)b * (2 * a.Hout) + 2 * y + (int)(blockIdx.y >> 1)) * (2 * a.Wout) + 2 * x + (int)(blockIdx.y & 1);
 }
 
 // ---- fragment pairing ---------------------------------------------------------------------------------------------
@@ -180,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV]
     for (int e = 0; e < NV; ++e) a.y_nchw[((int64_t)b * a.Cout + n + e) * hw + r] = v[e];
     return;
   }
-  T* p = yg + (int64_t)m * a.Cout + n;
+  T* p = yg + conv_out_row(a, m, b, hw) * a.Cout + n;
   if constexpr (IS_BF16 && NV == 8) {
     bf16x8 t;
 #pragma unroll
@@ -258,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
     if (rg && i + 1 < FM) load_res(i + 1, (i + 1) & 1);
     const int m = m_base + i * 16 + lr;
     if (m >= a.M) continue;
-    T* row = yg + (int64_t)m * a.Cout;
+    T* row = yg + (a.up4 ? conv_out_row(a, m, m / hw, hw) : (int64_t)m) * a.Cout;
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
       float v[8];
@@ -414,8 +429,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     int r = ok ? m - b * hw : 0;
     int oh = r / a.Wout, ow = r - oh * a.Wout;
     a_ok[i] = ok;
-    a_ih0[i] = oh * a.stride - a.pad;
-    a_iw0[i] = ow * a.stride - a.pad;
+    a_ih0[i] = oh * a.stride - conv_pad_h(a);
+    a_iw0[i] = ow * a.stride - conv_pad_w(a);
     a_coff[i] = slot * EPS;
     a_pix[i] = (ok ? b - b_first : 0) * a.Hin * a.Win;
     a_base[i] = ((a_pix[i] + a_ih0[i] * a.Win + a_iw0[i]) * a.Cin + a_coff[i]) * SZ;
@@ -609,8 +624,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
     int b = ok ? m / hw : 0;
     int r = ok ? m - b * hw : 0;
     int oh = r / a.Wout, ow = r - oh * a.Wout;
-    int ih0 = ok ? oh * a.stride - a.pad + 0x400 : 0;
-    a_row[i] = ((ok ? b - b_first : 0) << 24) | (ih0 << 12) | (ow * a.stride - a.pad + 0x400);
+    int ih0 = ok ? oh * a.stride - conv_pad_h(a) + 0x400 : 0;
+    a_row[i] = ((ok ? b - b_first : 0) << 24) | (ih0 << 12) | (ow * a.stride - conv_pad_w(a) + 0x400);
   }
   const int sample_bytes = a.Hin * a.Win * a.Cin * SZ, coff_b = coff * SZ;
   // weight rows: group i of a wave sits 8*NW rows after group 0 - a scalar step, so one base register serves all
@@ -989,8 +1004,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(ConvK a) {
     int r = ok ? m - b * hw : 0;
     int oh = r / a.Wout, ow = r - oh * a.Wout;
     a_ok[i] = ok;
-    a_ih0[i] = oh * a.stride - a.pad;
-    a_iw0[i] = ow * a.stride - a.pad;
+    a_ih0[i] = oh * a.stride - conv_pad_h(a);
+    a_iw0[i] = ow * a.stride - conv_pad_w(a);
     a_coff[i] = slot * EPS;
     a_pix[i] = (ok ? b - b_first : 0) * a.Hin * a.Win;  // pixel index of the sample's first pixel
     a_base[i] = ((a_pix[i] + a_ih0[i] * a.Win + a_iw0[i]) * a.Cin + a_coff[i]) * SZ;
@@ -1267,6 +1282,10 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
   k.emb_stride = a.emb_stride; k.emb_mod = a.emb_mod;
   k.M = a.B * a.Hout * a.Wout;
+  if (a.ups == 3) {   // four parity convolutions on the source grid (conv_out_row scatters the rows)
+    k.up4 = 1; k.ups = 0; k.Hout = a.Hin; k.Wout = a.Win; k.M = a.B * a.Hin * a.Win;
+    k.w_bstride = (int64_t)a.Cout * a.KH * a.KW * a.Cin;
+  }
   k.CPT = cdiv(a.Cin, 32);
   k.NK = k.CPT * a.KH * a.KW;
   k.NS = kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(k.NK, kps);
@@ -1278,7 +1297,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   uint64_t wb = (uint64_t)a.Cout * a.KH * a.KW * a.Cin * dt_size(dt);
   // weights and the few samples one tile can touch must fit a 2 GiB descriptor; the whole activation need not
   uint64_t per_sample = (uint64_t)a.Hin * a.Win * a.Cin * dt_size(dt);
-  uint64_t span = (uint64_t)(256 / std::max(1, a.Hout * a.Wout) + 2) * per_sample;
+  uint64_t span = (uint64_t)(256 / std::max(1, k.Hout * k.Wout) + 2) * per_sample;
   DDMI_REQUIRE(wb < 0x80000000ull && (span < 0x7FFFFFFFull || xb < 0x7FFFFFFFull), "conv: tensor exceeds the 2 GiB buffer-descriptor range");
   k.x_bytes = xb;
   k.w_bytes = (unsigned)wb;
@@ -1286,7 +1305,11 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   return DDMI_OK;
 }
 
+// GEMM rows of one launch slice: output pixels, or SOURCE pixels per parity for the parity form of upsample + 3x3
+static int conv_rows(const ConvArgs& a) { return a.ups == 3 ? a.B * a.Hin * a.Win : a.B * a.Hout * a.Wout; }
+
 int conv_pick_splitk(const ConvArgs& a, int dt) {
+  if (a.ups == 3) return 1;
   int M = a.B * a.Hout * a.Wout;
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   int tiles = cdiv(M, t.bm) * cdiv(a.Cout, t.bn);
@@ -1500,9 +1523,15 @@ static int check_conv(const ConvArgs& a, int dt) {
   DDMI_REQUIRE(a.Cin % eps == 0, "conv: Cin must be a multiple of the 16-byte vector");
   DDMI_REQUIRE(a.Cout % 4 == 0, "conv: Cout must be a multiple of 4");
   DDMI_REQUIRE(!a.emb || a.emb_stride % 4 == 0, "conv: emb_stride must be a multiple of 4");
-  DDMI_REQUIRE((a.KH == 1 && a.KW == 1) || (a.KH == 3 && a.KW == 3), "conv: kernel must be 1x1 or 3x3");
   DDMI_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride must be 1 or 2");
   DDMI_REQUIRE(!(a.ups && a.stride != 1), "conv: fused upsample needs stride 1");
+  if (a.ups == 3) {   // parity form of upsample + 3x3: weights [4][Cout][2*2*Cin] from launch_pack_conv_up4
+    DDMI_REQUIRE(dt == DT_BF16 && a.KH == 2 && a.KW == 2 && a.pad == 1, "conv: parity upsample is a bf16 2x2 form");
+    DDMI_REQUIRE(a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win, "conv: output size mismatch");
+    DDMI_REQUIRE(!a.emb && !a.res && !a.y_nchw && a.splitk <= 1, "conv: parity upsample takes bias only, no split-K");
+    return DDMI_OK;
+  }
+  DDMI_REQUIRE((a.KH == 1 && a.KW == 1) || (a.KH == 3 && a.KW == 3), "conv: kernel must be 1x1 or 3x3");
   int hin = a.ups == 1 ? 2 * a.Hin : a.Hin, win = a.ups ? 2 * a.Win : a.Win;
   DDMI_REQUIRE(a.Hout == (hin + 2 * a.pad - a.KH) / a.stride + 1 && a.Wout == (win + 2 * a.pad - a.KW) / a.stride + 1,
                "conv: output size mismatch");
@@ -1513,7 +1542,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   DDMI_TRY(check_conv(a, dt));
   int splitk = std::max(1, a.splitk);
   DDMI_REQUIRE(splitk == 1 || a.splitk_ws, "conv: split-K needs a workspace");
-  int M = a.B * a.Hout * a.Wout;
+  int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   ConvK k;
@@ -1531,7 +1560,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
     }
     k.tile_map = tm < 0 ? 0 : tm;
   }
-  DDMI_TRY(dispatch(k, t, dt, splitk, 1, s));
+  DDMI_TRY(dispatch(k, t, dt, splitk, a.ups == 3 ? 4 : 1, s));
   if (splitk > 1) DDMI_TRY(launch_splitk_finish(a, dt, s));
   return DDMI_OK;
 }
@@ -1573,7 +1602,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
   *best = ConvPlan{};
   if (dt != DT_BF16) return DDMI_OK;
   DDMI_TRY(check_conv(a0, dt));
-  const int M = a0.B * a0.Hout * a0.Wout;
+  const int M = conv_rows(a0);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
@@ -1589,7 +1618,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     int tiles = cdiv(M, rc.bm) * cdiv(a0.Cout, rc.bn);
     int NS = rc.kps < 0 ? cdiv(a0.Cin, 64) * a0.KH * a0.KW : cdiv(cdiv(a0.Cin, 32) * a0.KH * a0.KW, rc.kps);
     for (int sk : kSplits) {
-      if (sk > 1 && (tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
+      if (sk > 1 && (a0.ups == 3 || tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
       if (rc.kps == -2 && sk > cdiv(a0.Cin, 64)) continue;
       if ((size_t)sk * M * a0.Cout * sizeof(float) > ws_bytes && sk > 1) continue;
       const int n_walk = (a0.KH * a0.KW > 1 && rc.kps != -2) ? 2 : 1;

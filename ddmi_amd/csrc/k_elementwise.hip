@@ -276,6 +276,35 @@ int launch_pack_conv_weight(const float* w, void* packed, int dt, int Cout, int 
   return DDMI_OK;
 }
 
+// parity form of (nearest x2 upsample -> 3x3 conv), see k_conv.hip conv_out_row: packed [Cout][9][Cin] bf16 ->
+// [4][Cout][2*2][Cin] bf16, parity p = 2 dy + dx, tap (a, b) of the 2x2 source neighbourhood = the sum of the 3x3 taps
+// that land on that source pixel: rows dy = 0: a0 <- {kh 0}, a1 <- {1, 2};  dy = 1: a0 <- {0, 1}, a1 <- {2} (same for columns)
+__global__ void conv_pack_up4_kernel(const bf16_t* __restrict__ w9, bf16_t* __restrict__ out, int Cout, int Cin) {
+  const int64_t n = (int64_t)4 * Cout * 4 * Cin;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int ci = (int)(i % Cin);
+    int64_t r = i / Cin;
+    const int tap = (int)(r & 3);
+    r >>= 2;
+    const int co = (int)(r % Cout), par = (int)(r / Cout);
+    const int dy = par >> 1, dx = par & 1, ta = tap >> 1, tb = tap & 1;
+    const int kh0 = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), kh1 = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+    const int kw0 = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kw1 = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) acc += (float)w9[((int64_t)co * 9 + kh * 3 + kw) * Cin + ci];
+    out[i] = (bf16_t)acc;
+  }
+}
+int launch_pack_conv_up4(const void* packed9, void* out, int Cout, int Cin, hipStream_t s) {
+  const int64_t n = (int64_t)16 * Cout * Cin;
+  const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  hipLaunchKernelGGL(conv_pack_up4_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)packed9, (bf16_t*)out, Cout, Cin);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -30,6 +30,8 @@ int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int H
 int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s, int ld = 0, int off = 0);
 int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int dt, int64_t npix, hipStream_t s);
 int launch_pack_conv_weight(const float* w_oihw, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s);
+// bf16 packed [Cout][9][Cin] -> parity form [4][Cout][4][Cin] of (x2 nearest upsample -> 3x3 conv); ConvArgs.ups = 3
+int launch_pack_conv_up4(const void* packed9, void* out, int Cout, int Cin, hipStream_t s);
 int launch_cast_f32(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 // planes [P*Bn][HW][C] <-> channels [Bn][HW][P*C] (reverse=1: channels -> planes); tri-plane decoders
 int launch_planes_channels(const void* planes, void* chans, int dt, int Bn, int HW, int C, int P, int reverse, hipStream_t s);
@@ -66,7 +68,9 @@ struct ConvArgs {
   float* y_nchw;      // optional fp32 NCHW output (model boundary)
   float* splitk_ws;   // fp32 [splitk][M][Cout] partial slabs when splitk > 1
   int B, Hin, Win, Cin, Hout, Wout, Cout;
-  int KH, KW, stride, pad, ups;   // ups: fused nearest upsample of the input, 1 = x2 on both axes, 2 = x2 along W only
+  int KH, KW, stride, pad, ups;   // ups: fused nearest upsample of the input, 1 = x2 on both axes, 2 = x2 along W only,
+                                  // 3 = x2 on both axes in parity form (bf16): Hin/Win = source, KH = KW = 2, pad = 1,
+                                  //     w = launch_pack_conv_up4's [4][Cout][4][Cin], 2.25x fewer FLOPs than 1
   int emb_stride;
   int emb_mod;        // > 0: row of `emb` = sample % emb_mod (planes stacked along the batch axis share the embedding)
   int splitk;

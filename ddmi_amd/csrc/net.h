@@ -24,6 +24,7 @@ struct ConvW {
   void* w = nullptr;      // packed [Cout][taps*Cin], network dtype
   float* bias = nullptr;  // [Cout] fp32 (may be null)
   int Cout = 0, Cin = 0, K = 1;
+  void* w_up4 = nullptr;  // bf16 parity form for a fused x2 upsample (launch_pack_conv_up4), made when an op needs it
 };
 
 struct GNW {

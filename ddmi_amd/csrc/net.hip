@@ -143,8 +143,20 @@ int Net::op_gn(int in, int gn, int silu, float eps, int in2) {
 
 int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale) {
   const TensorDesc& t = tensors[in];
-  const ConvW& c = convs[conv];
+  ConvW& c = convs[conv];
   int pad = c.K / 2;
+  // x2 nearest upsample + 3x3 conv in the bf16 network: four 2x2 parity convolutions on the source grid (k_conv.hip)
+  static const bool up4 = !(getenv("DDMI_CONV_UP4") && atoi(getenv("DDMI_CONV_UP4")) == 0);
+  if (up4 && dt == DT_BF16 && ups == 1 && c.K == 3 && stride == 1 && res < 0 && emb_off < 0 && !c.w_up4) {
+    const size_t bytes = (size_t)16 * c.Cout * c.Cin * dt_size(dt);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    dev_allocs.push_back(p);
+    DDMI_TRY(launch_pack_conv_up4(c.w, p, c.Cout, c.Cin, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    weight_bytes += bytes;
+    c.w_up4 = p;
+  }
   int hin = ups == 1 ? 2 * t.H : t.H, win = ups ? 2 * t.W : t.W;
   int ho = (hin + 2 * pad - c.K) / stride + 1, wo = (win + 2 * pad - c.K) / stride + 1;
   Op o;
@@ -177,6 +189,9 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   int hin = o.ups == 1 ? 2 * ti.H : ti.H, win = o.ups ? 2 * ti.W : ti.W;
   a->Hout = (hin + 2 * o.pad - c.K) / o.stride + 1;
   a->Wout = (win + 2 * o.pad - c.K) / o.stride + 1;
+  if (o.ups == 1 && c.w_up4 && o.res < 0 && o.emb_off < 0) {  // parity form: same output, 2x2 taps on the source grid
+    a->w = c.w_up4; a->ups = 3; a->KH = a->KW = 2; a->pad = 1;
+  }
   a->out_scale = o.scale;
   a->splitk = 1;
 }

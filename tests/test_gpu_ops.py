@@ -134,6 +134,33 @@ def test_conv2d_every_bf16_variant(cfg):
         L.ddmi_debug_conv_config(-1)
 
 
+UPSAMPLE_CASES = [(2, 64, 8, 8, 64), (1, 224, 16, 16, 224), (3, 32, 5, 7, 96), (2, 448, 32, 32, 448), (5, 128, 4, 4, 224)]
+
+
+@pytest.mark.parametrize("case", UPSAMPLE_CASES)
+def test_conv2d_upsample_parity_form(case):
+    """bf16: nearest x2 upsample + 3x3 conv runs as four 2x2 parity convolutions on the source grid with pre-summed
+    weights (k_conv.hip conv_out_row) - borders, odd sizes, M tails, on the ring, pipe and small-tile kernels."""
+    B, Cin, H, W, Cout = case
+    tag = "convup%s" % (case,)
+    x = iw.normal(tag, "x", (B, Cin, H, W))
+    w = iw.normal(tag, "w", (Cout, Cin, 3, 3), 0.0, 1.0 / math.sqrt(Cin * 9))
+    b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+    ref = F.conv2d(F.interpolate(torch.from_numpy(x), scale_factor=2, mode="nearest"), torch.from_numpy(w),
+                   torch.from_numpy(b), padding=1)
+    L = _lib.lib()
+    try:
+        for cfg in (-1, 7, 11, 13, 16, 17):
+            _lib.check(L.ddmi_debug_conv_config(cfg))
+            got = conv_op(x, w, b, 1, 1, "bf16")
+            assert got.shape == ref.shape
+            assert rel_err(got, ref) < 1.5e-2, (cfg, case)
+            assert float((got - ref).abs().max()) < 0.03 * float(ref.abs().max()), (cfg, case)
+    finally:
+        L.ddmi_debug_conv_config(-1)
+    assert rel_err(conv_op(x, w, b, 1, 1, "fp32"), ref) < 2e-5   # the parity path stays on the plain fused-upsample form
+
+
 def test_philox_noise_streams():
     """ddmi_randn_fill / ddmi_ddpm_step_rng: per-chain counter-based normals.  Moments, independence across chains and
     steps, determinism, independence of the batch composition, and the step kernel drawing exactly the fill's values."""
