@@ -170,6 +170,36 @@ def test_afhq_decoder_and_mlp_full_size_vs_oracle():
     assert rel_err(rgb16, ref_rgb) < TOL_BF16
 
 
+@pytest.mark.parametrize("R", [384, 512, 1024])
+def test_arbitrary_resolution_decode_full_size(R):
+    """the same latent decoded at R != 256 (README.md:136, celebahq runs 512): scale injection
+    si = 256 / R != 1 and query points between plane texels, on the full-size planes and MLP.  The oracle evaluates a
+    band of rows of the R x R grid (the kernel takes any [1,2,h,w] coordinate grid); the whole frame is also produced."""
+    from ddmi_amd.autoencoder import Autoencoder  # noqa: F401  (make_vae)
+    z = iw.normal("afhq", "z", (1, 64, 64, 64))
+    vae = make_vae(AFHQ_DD, AFHQ_EMBED, "afhq.vae", "fp32", max_batch=1)
+    planes = vae.decode(torch.from_numpy(z).to(DEV))
+    ref_planes = [p.cpu() for p in planes]   # the decoder has its own oracle test: feed the oracle the same planes
+    mlp = make_mlp("afhq.mlp", "fp32")
+    mst = named_state("afhq.mlp", mlp.manifest())
+    si = get_scale_injection(R)
+    assert si == 256 / R and si != 1
+    coords = generation_coords(R)
+    assert rel_err(coords, O.generate_coords(R)) < 2e-7
+    rows = slice(R // 2 - 3, R // 2 + 3)       # six rows through the middle of the frame
+    band = coords[:, :, rows, :].contiguous()
+    ref = O.image_mlp(O.to_state(mst), band, ref_planes, O.scale_injection(R))
+    got = mlp(band, hdbf=planes, si=si)
+    assert got.shape == (1, 3, 6, R)
+    assert rel_err(got, ref) < TOL_FP32
+    full = mlp(coords, hdbf=planes, si=si)
+    assert full.shape == (1, 3, R, R) and bool(torch.isfinite(full).all())
+    assert torch.equal(full[:, :, rows, :], got)   # a point's value does not depend on what else is in the launch
+    mlp16 = make_mlp("afhq.mlp", "bf16")
+    got16 = mlp16(band, hdbf=[p.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for p in planes], si=si)
+    assert rel_err(got16, ref) < TOL_BF16
+
+
 def test_image_pipeline_matches_oracle_and_is_batch_invariant(golden):
     """ddmi_amd.pipeline.ImagePipeline (tools/ldm/image.py:225-249) on the toy configuration, parity mode: the whole
     chain - x_T and per-step noise drawn inside the library from per-sample Philox streams - equals the oracle's chain
