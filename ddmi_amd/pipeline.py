@@ -182,3 +182,71 @@ class VideoPipeline:
             outs.append(self.mlp(self.coords(), self.vae.decode(zz)).clamp_(-1.0, 1.0))
         vid = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
         return (vid, z) if return_latent else vid
+
+
+class OccupancyPipeline:
+    """tools/ldm/occupancy.py:205-230 (`LDMTrainer.eval` / `generate`, occupancy domain): sample([B, 3C, 16, 16]) -> per
+    sample Generator3D.generate_mesh_fromdiffusion (Autoencoder3D.decode -> dense MLP3D logits -> marching cubes, all on the
+    device) -> meshes.  Construction mirrors exp/stage.py:207-241; the generator settings are the ones get_generator
+    (convocc/src/conv_onet/config.py:117-128) reads from the convocc yaml: test.threshold, generation.resolution_0,
+    generation.upsampling_steps, data.padding."""
+
+    def __init__(self, unetconfig: Mapping, ddconfig: Mapping, mlpconfig: Mapping, ddpmconfig: Mapping, embed_dim: int,
+                 threshold: float = 0.2, resolution0: int = 256, upsampling_steps: int = 0, padding: float = 0.1,
+                 numerics: str = "bf16", max_batch: int = 2, device: str = "cuda:0"):
+        from .occupancy import MLP3D, Autoencoder3D, Generator3D
+        self.device = device
+        self.numerics = numerics
+        self.max_batch = int(max_batch)
+        ucfg = {k: v for k, v in dict(unetconfig).items() if k not in ("size1", "size2", "size3")}
+        self.unet = UNetModel(**ucfg, numerics=numerics, max_batch=max_batch)
+        self.vae = Autoencoder3D(ddconfig, embed_dim, numerics=numerics, max_batch=1)
+        self.mlp = MLP3D(**dict(mlpconfig), numerics=numerics)
+        cfg = {k: v for k, v in dict(ddpmconfig).items() if k != "domain"}   # 4-D latents: the image form of the sampler
+        self.ddpm = DDPM(model=self.unet, **cfg)
+        self.mesh_gen = Generator3D(threshold=threshold, resolution0=resolution0, upsampling_steps=upsampling_steps,
+                                    padding=padding)
+        self.latent_shape = (int(dict(unetconfig)["in_channels"]), int(dict(unetconfig)["image_size"]),
+                             int(dict(unetconfig)["image_size"]))
+
+    def load_named_seed(self, tag: str = "shapenet"):
+        self.unet.load_state_dict(initweights.fill_state(tag + ".unet", self.unet.manifest()))
+        self.vae.load_state_dict(initweights.fill_state(tag + ".vae", self.vae.manifest()))
+        self.mlp.load_state_dict(initweights.fill_state(tag + ".mlp", self.mlp.manifest()))
+        self.ddpm.load_state_dict({"mixing_logit": initweights.fill_state(tag + ".ddpm", [("mixing_logit", (1, self.ddpm.channels, 1, 1))])["mixing_logit"]},
+                                  strict=False)
+        return self
+
+    def load_checkpoint(self, path: str, use_ema: bool = True):
+        """`ldm-last.pt` of tools/ldm/occupancy.py (same keys as the image trainer; the PointNet encoder is not on this path)."""
+        import torch
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.vae.load_state_dict(ck["vaemodel"], strict=False)
+        self.mlp.load_state_dict(ck["mlp"], strict=True)
+        diff = ck["diffusion"]
+        if use_ema and "ema" in ck:
+            ema = {k[len("ema_model."):]: v for k, v in ck["ema"].items() if k.startswith("ema_model.")}
+            if ema:
+                diff = ema
+        diff = {k: v for k, v in diff.items() if k != "lvlb_weights" and k != "logvar"}
+        self.ddpm.load_state_dict(diff, strict=True)
+        return self
+
+    def finalize(self):
+        idx = int(str(self.device).split(":")[1]) if ":" in str(self.device) else 0
+        self.unet.finalize(idx)
+        self.unet.set_uniform_t(True)
+        self.vae.finalize(idx)
+        self.mlp.finalize(idx)
+        return self
+
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False):
+        """One TriMesh per GLOBAL sample index (per-sample noise streams, so the set does not depend on batching or on the
+        number of GPUs); meshes are extracted one latent at a time, as the reference does (tools/ldm/occupancy.py:216-217)."""
+        import torch
+        B = len(indices)
+        dev = torch.device(self.device)
+        seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
+        z = self.ddpm.sample([B, *self.latent_shape], seeds=seeds, device=dev)
+        meshes = [self.mesh_gen.generate_mesh_fromdiffusion(z[j:j + 1].contiguous(), self.vae, self.mlp, dev)[0] for j in range(B)]
+        return (meshes, z) if return_latent else meshes

@@ -2,7 +2,8 @@
 """Entry point with the reference's surface: `python main.py --exp ldm --configs configs/ldm/afhq.yaml [--seed 777]`
 (reference main.py:54-65), also under `accelerate launch` / `torch.distributed.run` (one process per GPU).
 
-Only the generation path is implemented (`data.mode: gen | eval` of the `ldm` experiment, image and video domains): gen writes a
+Only the generation path is implemented (`data.mode: gen | eval` of the `ldm` experiment; image, video and occupancy domains;
+occupancy writes one Wavefront .obj per sample, tools/ldm/occupancy.py:205-230): image gen writes a
 grid of `test_batch_size` samples like tools/ldm/image.py:225-249; eval runs the sample-parallel 10k-image loop of
 evals/eval.py:215-234 (images written as PNG shards; Inception scoring needs downloaded weights and is out of scope).
 """
@@ -24,14 +25,16 @@ def main(args):
     from ddmi_amd.pipeline import ImagePipeline
 
     args = load_ldm_args(args.configs, args)
-    if args.domain not in ("image", "video") or args.DiT:
-        raise SystemExit(f"domain '{args.domain}' / DiT: use ddmi_amd.occupancy for occupancy; DiT is out of scope")
+    if args.domain not in ("image", "video", "occupancy") or args.DiT:
+        raise SystemExit(f"domain '{args.domain}' / DiT is out of scope (SURVEY.md 8): image, video and occupancy generation only")
     random_seed(args.seed)
     rank, local_rank, world = D.init_process_group()
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     dc = args.data_config
     B = int(dc.test_batch_size)
+    if args.domain == "occupancy":  # exp/stage.py:207-241, tools/ldm/occupancy.py:205-230
+        return occupancy_main(args, dc, B, rank, world, dev)
     if args.domain == "video":  # exp/stage.py:245-262, tools/ldm/video.py:214-236
         from ddmi_amd.pipeline import VideoPipeline
         pipe = VideoPipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
@@ -76,6 +79,51 @@ def main(args):
             print(f"wrote {total} samples")
     else:
         raise SystemExit("data.mode must be gen or eval (training is out of scope)")
+
+
+def generator_settings(dc):
+    """What convocc's get_generator (conv_onet/config.py:117-128) reads: the convocc yaml named by data.conv_config over
+    convocc/configs/default.yaml when that tree is present, else the `data.generation` block of our config."""
+    import yaml
+    g = dict(dc.get("generation") or {})
+    out = {"threshold": float(g.get("threshold", 0.5)), "resolution0": int(g.get("resolution_0", 256)),
+           "upsampling_steps": int(g.get("upsampling_steps", 0)), "padding": float(g.get("padding", 0.1))}
+    for path in ("convocc/configs/default.yaml", dc.get("conv_config")):
+        if path and os.path.exists(path):
+            with open(path) as f:
+                c = yaml.safe_load(f) or {}
+            out["threshold"] = float(c.get("test", {}).get("threshold", out["threshold"]))
+            out["resolution0"] = int(c.get("generation", {}).get("resolution_0", out["resolution0"]))
+            out["upsampling_steps"] = int(c.get("generation", {}).get("upsampling_steps", out["upsampling_steps"]))
+            out["padding"] = float(c.get("data", {}).get("padding", out["padding"]))
+    return out
+
+
+def occupancy_main(args, dc, B, rank, world, dev):
+    """`gen`: one batch of meshes per rank -> results/generation-<index>.obj (tools/ldm/occupancy.py:222-230 writes one);
+    `eval`: the 5 000-shape loop of tools/ldm/occupancy.py:205-219, sharded over the ranks by global sample index."""
+    from ddmi_amd.pipeline import OccupancyPipeline
+    pipe = OccupancyPipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
+                             numerics=args.numerics, max_batch=B, device=dev, **generator_settings(dc))
+    ckpt = os.path.join(dc.save_pth, "ldm-last.pt")
+    if os.path.exists(ckpt):
+        print("Loading Pretrained Models!")
+        pipe.load_checkpoint(ckpt)
+    else:
+        print(f"{ckpt} not found: using named-seed synthetic weights")
+        pipe.load_named_seed("shapenet")
+    pipe.finalize()
+    out_dir = os.path.join(dc.save_pth, "results" if args.mode == "gen" else os.path.join("results", "eval"))
+    os.makedirs(out_dir, exist_ok=True)
+    if args.mode not in ("gen", "eval"):
+        raise SystemExit("data.mode must be gen or eval (training is out of scope)")
+    total = world * B if args.mode == "gen" else int(os.environ.get("DDMI_EVAL_SAMPLES", 5000)) // (world * B) * (world * B)
+    print("Generating shape!" if args.mode == "gen" else f"Generating {total} shapes for evaluation!")
+    for start in range(rank * B, total, world * B):       # disjoint global sample indices per rank
+        idx = list(range(start, start + B))
+        for i, mesh in zip(idx, pipe.generate(idx, base_seed=args.seed)):
+            mesh.export(os.path.join(out_dir, f"generation-{i}.obj"))
+    print("Finished generating shapes!")
 
 
 if __name__ == "__main__":

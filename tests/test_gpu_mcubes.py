@@ -129,3 +129,25 @@ def test_generator3d_end_to_end(golden, tmp_path):
     assert int(lines[-1].split()[1]) == int(rf[-1, 0]) + 1   # .obj indices are 1-based
     with pytest.raises(NotImplementedError):
         Generator3D(upsampling_steps=2)
+
+
+def test_occupancy_pipeline_is_batch_invariant(golden):
+    """OccupancyPipeline (tools/ldm/occupancy.py:205-230 / exp/stage.py:207-241): latent chains -> meshes; a sample's mesh
+    depends only on (base_seed, global index), not on what else is in the batch."""
+    from ddmi_amd.pipeline import OccupancyPipeline
+    cfgs = golden.json("configs.json")
+    ucfg = dict(size1=4, size2=4, size3=4, image_size=4, in_channels=48, out_channels=48, model_channels=32,
+                channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2], num_head_channels=32)
+    dcfg = dict(timesteps=1000, image_size=4, channels=48, clip_denoised=False, mixed_prediction=True, mixed_init=-6,
+                sampling_timesteps=4, ddim_sampling_eta=0.0, domain="occupancy")
+    pipe = OccupancyPipeline(ucfg, cfgs["TOY_DD3"], cfgs["MLP3D_CFG"], dcfg, cfgs["TOY_EMBED3"], threshold=0.5,
+                             resolution0=32, upsampling_steps=0, padding=0.1, numerics="fp32", max_batch=3, device=DEV)
+    pipe.load_named_seed("toyocc").finalize()
+    meshes, z = pipe.generate([5, 6, 7], base_seed=11, return_latent=True)
+    assert z.shape == (3, 48, 4, 4) and len(meshes) == 3
+    assert all(m.vertices.dtype == np.float64 and m.faces.shape[1] == 3 for m in meshes)
+    assert sum(len(m.faces) for m in meshes) > 0
+    alone = pipe.generate([7], base_seed=11)[0]
+    assert same(alone.vertices, meshes[2].vertices) and same(alone.faces, meshes[2].faces)
+    other = pipe.generate([8], base_seed=11)[0]
+    assert not (same(other.vertices, meshes[2].vertices) and same(other.faces, meshes[2].faces))

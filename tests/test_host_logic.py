@@ -177,3 +177,26 @@ def test_checkpoint_ingestion_maps_reference_keys(tmp_path):
     torch.save({"vaemodel": t(vae_full), "mlp": t(mlp), "diffusion": t(bad)}, path)
     with pytest.raises(ValueError, match="schedule buffer"):
         pipe.load_checkpoint(str(path))
+
+
+def test_shipped_configs_parse_like_the_reference_schema():
+    """configs/ldm/*.yaml: the reference's schema (model.params.{unet,dd,mlp,ddpm}config, data.*), every domain main.py runs."""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from ddmi_amd.config import load_ldm_args
+    import main as entry
+    want = {"afhq": ("image", 224, [1, 2, 4, 6], 256), "celebahq": ("image", 256, [1, 2, 4, 8], 512),
+            "skytimelapse": ("video", 256, [1, 2, 4, 6], 256), "shapenet": ("occupancy", 256, [1, 2, 4, 6], None)}
+    for name, (domain, mc, mult, res) in want.items():
+        a = load_ldm_args(os.path.join(root, "configs", "ldm", name + ".yaml"), argparse.Namespace())
+        assert a.domain == domain and a.mode == "gen" and not a.DiT
+        assert a.unetconfig.model_channels == mc and list(a.unetconfig.channel_mult) == mult
+        assert a.data_config.get("test_resolution") == res
+        assert a.ddpmconfig.timesteps >= a.ddpmconfig.sampling_timesteps
+    a = load_ldm_args(os.path.join(root, "configs", "ldm", "shapenet.yaml"), argparse.Namespace())
+    # convocc get_generator's inputs (conv_onet/config.py:117-128): shapenet_3plane.yaml over default.yaml
+    assert entry.generator_settings(a.data_config) == {"threshold": 0.2, "resolution0": 256, "upsampling_steps": 0, "padding": 0.1}
+    assert a.unetconfig.in_channels == 3 * a.embed_dim and a.ddpmconfig.domain == "occupancy"
