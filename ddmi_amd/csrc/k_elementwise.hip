@@ -279,7 +279,10 @@ int launch_pack_conv_weight(const float* w, void* packed, int dt, int Cout, int 
 // parity form of (nearest x2 upsample -> 3x3 conv), see k_conv.hip conv_out_row: packed [Cout][9][Cin] bf16 ->
 // [4][Cout][2*2][Cin] bf16, parity p = 2 dy + dx, tap (a, b) of the 2x2 source neighbourhood = the sum of the 3x3 taps
 // that land on that source pixel: rows dy = 0: a0 <- {kh 0}, a1 <- {1, 2};  dy = 1: a0 <- {0, 1}, a1 <- {2} (same for columns)
-__global__ void conv_pack_up4_kernel(const bf16_t* __restrict__ w9, bf16_t* __restrict__ out, int Cout, int Cin) {
+// SRC = float: w9 is the raw [Cout][Cin][3][3] fp32 tensor (the sums are rounded to bf16 ONCE, so the parity form carries
+// less weight-rounding error than the plain form); SRC = bf16_t: the packed [Cout][9][Cin] weights
+template <typename SRC>
+__global__ void conv_pack_up4_kernel(const SRC* __restrict__ w9, bf16_t* __restrict__ out, int Cout, int Cin) {
   const int64_t n = (int64_t)4 * Cout * 4 * Cin;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -293,14 +296,23 @@ __global__ void conv_pack_up4_kernel(const bf16_t* __restrict__ w9, bf16_t* __re
     const int kw0 = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kw1 = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
     float acc = 0.f;
     for (int kh = kh0; kh <= kh1; ++kh)
-      for (int kw = kw0; kw <= kw1; ++kw) acc += (float)w9[((int64_t)co * 9 + kh * 3 + kw) * Cin + ci];
+      for (int kw = kw0; kw <= kw1; ++kw)
+        acc += sizeof(SRC) == 4 ? (float)w9[((int64_t)co * Cin + ci) * 9 + kh * 3 + kw]
+                                : (float)w9[((int64_t)co * 9 + kh * 3 + kw) * Cin + ci];
     out[i] = (bf16_t)acc;
   }
 }
 int launch_pack_conv_up4(const void* packed9, void* out, int Cout, int Cin, hipStream_t s) {
   const int64_t n = (int64_t)16 * Cout * Cin;
   const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
-  hipLaunchKernelGGL(conv_pack_up4_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)packed9, (bf16_t*)out, Cout, Cin);
+  hipLaunchKernelGGL(conv_pack_up4_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)packed9, (bf16_t*)out, Cout, Cin);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_pack_conv_up4_f32(const float* w_oihw, void* out, int Cout, int Cin, hipStream_t s) {
+  const int64_t n = (int64_t)16 * Cout * Cin;
+  const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  hipLaunchKernelGGL(conv_pack_up4_kernel<float>, dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)out, Cout, Cin);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

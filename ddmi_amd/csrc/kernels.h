@@ -32,6 +32,8 @@ int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int d
 int launch_pack_conv_weight(const float* w_oihw, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s);
 // bf16 packed [Cout][9][Cin] -> parity form [4][Cout][4][Cin] of (x2 nearest upsample -> 3x3 conv); ConvArgs.ups = 3
 int launch_pack_conv_up4(const void* packed9, void* out, int Cout, int Cin, hipStream_t s);
+// the same from the raw fp32 [Cout][Cin][3][3] tensor: the tap sums are rounded to bf16 once
+int launch_pack_conv_up4_f32(const float* w_oihw, void* out, int Cout, int Cin, hipStream_t s);
 int launch_cast_f32(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 // planes [P*Bn][HW][C] <-> channels [Bn][HW][P*C] (reverse=1: channels -> planes); tri-plane decoders
 int launch_planes_channels(const void* planes, void* chans, int dt, int Bn, int HW, int C, int P, int reverse, hipStream_t s);

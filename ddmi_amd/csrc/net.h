@@ -25,6 +25,7 @@ struct ConvW {
   float* bias = nullptr;  // [Cout] fp32 (may be null)
   int Cout = 0, Cin = 0, K = 1;
   void* w_up4 = nullptr;  // bf16 parity form for a fused x2 upsample (launch_pack_conv_up4), made when an op needs it
+  std::string wkey;       // state-dict key of the raw fp32 weight (make_conv), valid until finalize drops the host copies
 };
 
 struct GNW {

@@ -107,7 +107,9 @@ int Net::make_conv(const std::string& wkey, const std::string& bkey, int* idx) {
     DDMI_REQUIRE(b->numel() == w->shape[0], "bias size mismatch: " + bkey);
     bias = &b->data;
   }
-  return make_conv_host(w->data, (int)w->shape[0], (int)w->shape[1], K, bias, idx);
+  DDMI_TRY(make_conv_host(w->data, (int)w->shape[0], (int)w->shape[1], K, bias, idx));
+  convs[*idx].wkey = wkey;
+  return DDMI_OK;
 }
 
 int Net::make_gn(const std::string& prefix, int* idx) {
@@ -152,8 +154,20 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
     dev_allocs.push_back(p);
-    DDMI_TRY(launch_pack_conv_up4(c.w, p, c.Cout, c.Cin, 0));
-    HIP_TRY(hipDeviceSynchronize());
+    const HostTensor* raw = c.wkey.empty() ? nullptr : find(c.wkey);
+    if (raw && raw->numel() == (int64_t)c.Cout * c.Cin * 9) {   // sum the taps in fp32, round once
+      float* tmp = nullptr;
+      HIP_TRY(hipMalloc((void**)&tmp, raw->data.size() * sizeof(float)));
+      hipError_t e = hipMemcpy(tmp, raw->data.data(), raw->data.size() * sizeof(float), hipMemcpyHostToDevice);
+      int rc = e == hipSuccess ? launch_pack_conv_up4_f32(tmp, p, c.Cout, c.Cin, 0) : ddmi_fail(DDMI_ERR_HIP, "weight upload failed");
+      hipError_t e2 = hipDeviceSynchronize();
+      (void)hipFree(tmp);
+      DDMI_TRY(rc);
+      HIP_TRY(e2);
+    } else {
+      DDMI_TRY(launch_pack_conv_up4(c.w, p, c.Cout, c.Cin, 0));
+      HIP_TRY(hipDeviceSynchronize());
+    }
     weight_bytes += bytes;
     c.w_up4 = p;
   }
