@@ -102,6 +102,12 @@ def main():
                     help="per-chain noise: in-kernel Philox streams (default) or one torch generator per chain")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no
+        # HIP call), the ranks are CHILD processes (never an exec of this one) and their status is ours.
+        from ddmi_amd.dist import launch_ranks
+        sys.exit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     import torch
     from ddmi_amd import _lib
     from ddmi_amd import dist as D

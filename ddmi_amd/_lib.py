@@ -89,6 +89,8 @@ SYMBOLS = {
     "ddmi_mlp2d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),
     "ddmi_mlp2d_finalize": (_I, [_VP]),
     "ddmi_hdpe_mlp2d": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _F, _VP, _VP, _I, _I, _VP]),
+    "ddmi_hdpe_mlp2d_rng": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _VP, _F, _VP, _VP, _I, _I, _VP]),
+    "ddmi_mlp2d_noise_nonzero": (_I, [_VP, C.POINTER(_I)]),
     "ddmi_mlp2d_destroy": (_I, [_VP]),
     "ddmi_decoder3d_create": (_I, [C.POINTER(Decoder2dCfg), C.POINTER(_I), _I, C.POINTER(_VP)]),
     "ddmi_decoder3d_load_weight": (_I, [_VP, C.c_char_p, _VP, _I64P, _I]),

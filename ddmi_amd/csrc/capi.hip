@@ -207,7 +207,18 @@ int ddmi_mlp2d_finalize(ddmi_mlp2d* h) {
 int ddmi_hdpe_mlp2d(ddmi_mlp2d* h, const void* const* planes, const int* plane_hw, int layout, const float* coords,
                     float si, const float* noise, float* rgb_out, int B, int N, void* stream) {
   DDMI_REQUIRE(h, "null handle");
-  return mlp2d_forward(h->m, planes, plane_hw, layout, coords, si, noise, rgb_out, B, N, (hipStream_t)stream);
+  return mlp2d_forward(h->m, planes, plane_hw, layout, coords, si, noise, nullptr, rgb_out, B, N, (hipStream_t)stream);
+}
+int ddmi_hdpe_mlp2d_rng(ddmi_mlp2d* h, const void* const* planes, const int* plane_hw, int layout, const float* coords,
+                        float si, const uint64_t* seeds, float* rgb_out, int B, int N, void* stream) {
+  DDMI_REQUIRE(h && seeds, "mlp2d_rng: null handle / seeds");
+  return mlp2d_forward(h->m, planes, plane_hw, layout, coords, si, nullptr, seeds, rgb_out, B, N, (hipStream_t)stream);
+}
+int ddmi_mlp2d_noise_nonzero(ddmi_mlp2d* h, int* out) {
+  DDMI_REQUIRE(h && out, "mlp2d_noise_nonzero: null argument");
+  if (!h->m.finalized) return ddmi_fail(DDMI_ERR_STATE, "mlp2d not finalized");
+  *out = h->m.noise_nonzero ? 1 : 0;
+  return DDMI_OK;
 }
 int ddmi_mlp2d_destroy(ddmi_mlp2d* h) {
   delete h;

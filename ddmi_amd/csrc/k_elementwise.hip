@@ -2,6 +2,7 @@
 // timestep embedding and the small fp32 dense layers of the time-embedding path.
 #include "kernels.h"
 #include "prof.h"
+#include "philox.h"
 
 // =====================================================================================================
 // Fused eps-mix -> x0 -> x_{t-1} step.  Replaces diffusion/ddpm.py:257-281 (p_mean_variance + p_sample) and
@@ -9,36 +10,6 @@
 // algorithmic traffic with the write), keeps everything in registers.
 // Layout NCHW fp32 (the sampler state keeps the reference's layout); mixing_logit is [C].
 // =====================================================================================================
-// ---- counter-based noise: Philox4x32-10 (Salmon et al., SC'11) keyed by the SAMPLE's 64-bit seed ----------------------
-// normal(seed, tag, e) for element e of a sample depends on nothing else, so a chain's noise is the same whatever batch
-// or GPU it runs in (the sharding invariant of ddmi_amd/dist.py), and the sampler step can draw it in registers instead
-// of reading a [B, C, HW] tensor that 256 per-sample generator launches filled.  Counter = (e / 4, tag, 0x44444d49, 0);
-// `tag` = step index (0xFFFFFFFF for x_T).  Four uniforms -> four normals by Box-Muller.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ void normal4(uint64_t seed, unsigned tag, unsigned quad, float (&z)[4]) {
-  unsigned r[4];
-  philox4x32_10(quad, tag, 0x44444d49u, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
-  // u in (0, 1]: 24-bit mantissas, never 0 so the logarithm is finite
-  const float u0 = ((r[0] >> 8) + 1) * (1.0f / 16777216.0f), u1 = (r[1] >> 8) * (1.0f / 16777216.0f);
-  const float u2 = ((r[2] >> 8) + 1) * (1.0f / 16777216.0f), u3 = (r[3] >> 8) * (1.0f / 16777216.0f);
-  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-  float s0, c0, s1, c1;
-  sincospif(2.0f * u1, &s0, &c0);
-  sincospif(2.0f * u3, &s1, &c1);
-  z[0] = ra * c0; z[1] = ra * s0; z[2] = rb * c1; z[3] = rb * s1;
-}
-
 // out[b][e] = normal(seeds[b], tag, e), e < n (n a multiple of 4)
 __global__ void __launch_bounds__(256) randn_fill_kernel(float* __restrict__ out, const uint64_t* __restrict__ seeds,
                                                          int64_t nquad_per_sample, int64_t total_quads, unsigned tag) {

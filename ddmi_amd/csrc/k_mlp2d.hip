@@ -16,6 +16,7 @@
 // next to conv1 and is merged in the conv3 epilogue; for block 4 (identity skip) the same registers carry x3.
 #include "kernels.h"
 #include "prof.h"
+#include "philox.h"
 
 #define MLP_CH 256
 #define MLP_F 64
@@ -57,12 +58,27 @@ struct MlpK {
   const float* coords;
   const void* w;
   const float* fb;
-  const float* noise;
+  const float* noise;       // explicit NoiseInjection draws [12][B][N], or
+  const uint64_t* seeds;    // per-sample Philox seeds [B]: draw c of point p = normal(seeds[b], PHILOX_TAG_INJECT + c, p)
   const float* noise_w;
   float* rgb;
   int B, N;
   int64_t total;  // B*N
 };
+
+// NoiseInjection term of StyledConv `conv_idx` for global point gp (0 when the launch carries no noise source)
+__device__ __forceinline__ float mlp_noise(const MlpK& a, int conv_idx, int64_t gp) {
+  if (a.noise == nullptr && a.seeds == nullptr) return 0.f;
+  if (gp >= a.total) return 0.f;
+  const float nw = a.noise_w[conv_idx];
+  if (a.noise != nullptr) return nw * a.noise[(int64_t)conv_idx * a.total + gp];
+  if (nw == 0.f) return 0.f;
+  const int b = (int)(gp / a.N);
+  const unsigned p = (unsigned)(gp - (int64_t)b * a.N);
+  float z[4];
+  normal4(a.seeds[b], PHILOX_TAG_INJECT + (unsigned)conv_idx, p >> 2, z);
+  return nw * z[p & 3];
+}
 
 // ---- bilinear gather of one plane into F[P][FP] ---------------------------------------------------------
 template <typename T>
@@ -211,15 +227,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) mlp2d_kernel(Ml
   // epilogue of a StyledConv: +noise, FusedLeakyReLU -> write bf16/fp32 activations to Xout
   auto act_store = [&](int conv_idx, T* Xout) {
     const float* bias = a.fb + MLP_FB_BIAS(conv_idx);
-    float nw = a.noise ? a.noise_w[conv_idx] : 0.f;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       int row = 16 * mf + lr;
-      float nz = 0.f;
-      if (a.noise) {
-        int64_t gp = tile0 + row;
-        if (gp < a.total) nz = nw * a.noise[(int64_t)conv_idx * a.total + gp];
-      }
+      const float nz = mlp_noise(a, conv_idx, tile0 + row);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         int n = nbase + 16 * nf + 4 * lg;
@@ -246,15 +257,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) mlp2d_kernel(Ml
   // epilogue of a block: x = (act(acc) + skip [+ skip_const]) / sqrt2 -> Xout, and keep x in skp (for block 4)
   auto block_out = [&](int conv_idx, int skip_const_idx, T* Xout) {
     const float* bias = a.fb + MLP_FB_BIAS(conv_idx);
-    float nw = a.noise ? a.noise_w[conv_idx] : 0.f;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       int row = 16 * mf + lr;
-      float nz = 0.f;
-      if (a.noise) {
-        int64_t gp = tile0 + row;
-        if (gp < a.total) nz = nw * a.noise[(int64_t)conv_idx * a.total + gp];
-      }
+      const float nz = mlp_noise(a, conv_idx, tile0 + row);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         int n = nbase + 16 * nf + 4 * lg;
@@ -362,27 +368,335 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) mlp2d_kernel(Ml
   }
 }
 
+// =====================================================================================================================
+// bf16 perf kernel, second generation.
+//
+// What bounded the first one (round-1 profile: 0.53 PFLOP/s): a 64-point workgroup streams ALL 1.9 MB of folded weights
+// from L2 for 122 MFLOP of work = 64 FLOP per L2 byte; 2.5 PFLOP/s would need 39 TB/s of L2 reads (the chip gives ~34
+// aggregate, ~17 for row gathers).  The lever is points per workgroup:
+//   * P = 128 points per workgroup (one workgroup per CU): half the weight bytes per FLOP.  LDS (157.7 KB): two
+//     activation buffers [128][256+16] bf16 + one feature tile [128][64+8].
+//   * 4 x PW waves: wave (cw, pw) owns output channels [64 cw, 64 cw + 64) of points [pw P/PW, (pw+1) P/PW): weight
+//     fragments stay wave-private (L2 -> registers, no LDS traffic for them), activation fragments come from LDS at
+//     2048 B per point and layer = half of the LDS bandwidth at full MFMA rate.
+//   * weights are stored in FRAGMENT order ([16-row group][32-wide k step][lane][8]): one wave load = 1 KiB contiguous
+//     = 8 whole cache lines (row-major they were 16 half lines), issued one k-step ahead of their MFMAs, the first of a
+//     pass before the previous pass's epilogue and barrier.
+//   * the skip path no longer lives in 64 more accumulator registers for the length of a block: the block input stays in
+//     its LDS buffer (conv1/conv2 outputs go to the OTHER buffer, conv2 in place), and conv3's pass continues, after
+//     its activation, with the skip matrix over [input | features] on top of the same accumulators.
+//   * the bilinear gather of the next plane is issued (global -> registers) before conv3's pass and committed to LDS
+//     after the block's last read of the current features, so its HBM/L2 latency hides under ~12 us of MFMA work.
+// =====================================================================================================================
+#define MV2_P 128
+#define MV2_XP 272
+#define MV2_FP 72
+
+// element offset of the 1 KiB fragment block (16-row group g, k-step ks) of matrix i; lane l adds 8 l
+__device__ __forceinline__ int mv2_wfrag(int i_off, int KS, int g, int ks) { return i_off + ((g * KS + ks) << 9); }
+
+template <int NT> struct Mv2Gather {   // one plane's texels in flight: P*8 (point, 8-channel group) items over NT threads
+  static constexpr int ITEMS = MV2_P * 8 / NT;
+  bf16x8 t[ITEMS][4];
+  float w[ITEMS][4];
+};
+
+template <int NT>
+__device__ __forceinline__ void mv2_gather_issue(const MlpK& a, int pl, int64_t tile0, Mv2Gather<NT>& g) {
+  const int S = a.hw[pl];
+  const bf16_t* plane = (const bf16_t*)a.planes[pl];
+#pragma unroll
+  for (int j = 0; j < Mv2Gather<NT>::ITEMS; ++j) {
+    const int it = threadIdx.x + j * NT;
+    const int pi = it >> 3, cg = it & 7;
+    int64_t gp = tile0 + pi;
+    const bool live = gp < a.total;
+    if (!live) gp = a.total - 1;  // a valid address; the weights below are zeroed
+    const int b = (int)(gp / a.N);
+    const int p = (int)(gp - (int64_t)b * a.N);
+    const float gx = a.coords[2 * p], gy = a.coords[2 * p + 1];
+    // F.grid_sample: unnormalise (align_corners=False), clip to border, bilinear corners
+    float ix = ((gx + 1.f) * S - 1.f) * 0.5f, iy = ((gy + 1.f) * S - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(S - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(S - 1));
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);
+    const bf16_t* base = plane + (int64_t)b * S * S * MLP_F + cg * 8;
+    g.t[j][0] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y0 * S + x0) * MLP_F);
+    g.t[j][1] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y0 * S + x1) * MLP_F);
+    g.t[j][2] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y1 * S + x0) * MLP_F);
+    g.t[j][3] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y1 * S + x1) * MLP_F);
+    const float m = live ? 1.f : 0.f;
+    g.w[j][0] = wy0 * wx0 * m; g.w[j][1] = wy0 * wx1 * m; g.w[j][2] = wy1 * wx0 * m; g.w[j][3] = wy1 * wx1 * m;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void mv2_gather_commit(const Mv2Gather<NT>& g, bf16_t* F) {
+#pragma unroll
+  for (int j = 0; j < Mv2Gather<NT>::ITEMS; ++j) {
+    const int it = threadIdx.x + j * NT;
+    const int pi = it >> 3, cg = it & 7;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)  // same operation order as the first-generation kernel and the fp32 parity kernel
+      o[e] = (bf16_t)((float)g.t[j][0][e] * g.w[j][0] + (float)g.t[j][1][e] * g.w[j][1] + (float)g.t[j][2][e] * g.w[j][2] +
+                      (float)g.t[j][3][e] * g.w[j][3]);
+    *reinterpret_cast<bf16x8*>(F + pi * MV2_FP + cg * 8) = o;
+  }
+}
+
+// weight fragments of k-step ks of a 256-row matrix for this wave's four 16-row groups
+__device__ __forceinline__ void mv2_wload(const bf16_t* __restrict__ Wall, int off, int KS, int cw, int ks, int lane,
+                                          bf16x8 (&dst)[4]) {
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+    dst[nf] = *reinterpret_cast<const bf16x8*>(Wall + mv2_wfrag(off, KS, 4 * cw + nf, ks) + 8 * lane);
+}
+
+// acc[mf][nf] += W[64 cw + 16 nf + r][k] * IN[prow0 + 16 mf + r][k] over KX channels of X then KF of F.
+// wq[0] must already hold the fragments of k-step 0 (mv2_wload, issued before the previous pass's epilogue); inside the
+// pass weights (L2 -> registers) and activations (LDS -> registers) are fetched one k-step ahead of their MFMAs - with two
+// waves per SIMD a k-step is ~500 cycles of MFMA issue.  The k loop stays rolled (two steps per trip, static ring
+// slots): fully unrolled, the 116 k-steps of the kernel kept ~100 address registers alive and spilled.
+template <int MF, int KX, int KF>
+__device__ __forceinline__ void mv2_pass(const bf16_t* __restrict__ X, const bf16_t* __restrict__ F,
+                                         const bf16_t* __restrict__ Wall, int off, int cw, int prow0, int lane,
+                                         bf16x8 (&wq)[2][4], f32x4 (&acc)[MF][4]) {
+  constexpr int KS = (KX + KF) / 32;
+  static_assert(KS % 2 == 0, "two k-steps per trip");
+  const int lr = lane & 15, lg = lane >> 4;
+  const bf16_t* xrow = X + (prow0 + lr) * MV2_XP + 8 * lg;
+  const bf16_t* frow = F + (prow0 + lr) * MV2_FP + 8 * lg - KX;
+  auto xload = [&](int ks, bf16x8(&xf)[MF]) {
+    const int k0 = ks * 32;
+    const bf16_t* p = (k0 >= KX) ? frow + k0 : xrow + k0;
+    const int pitch = (k0 >= KX) ? 16 * MV2_FP : 16 * MV2_XP;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const bf16x8*>(p + mf * pitch);
+  };
+  auto mma = [&](const bf16x8(&w)[4], const bf16x8(&x)[MF]) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nf], x[mf], acc[mf][nf], 0, 0, 0);
+  };
+  bf16x8 xq[2][MF];
+  xload(0, xq[0]);
+#pragma unroll 1
+  for (int ks = 0; ks < KS; ks += 2) {
+    mv2_wload(Wall, off, KS, cw, ks + 1, lane, wq[1]);
+    xload(ks + 1, xq[1]);
+    mma(wq[0], xq[0]);
+    if (ks + 2 < KS) {
+      mv2_wload(Wall, off, KS, cw, ks + 2, lane, wq[0]);
+      xload(ks + 2, xq[0]);
+    }
+    mma(wq[1], xq[1]);
+  }
+}
+
+template <int PW, bool NOISE>
+__global__ void __launch_bounds__(256 * PW, 1) mlp2d_v2_kernel(MlpK a) {
+  constexpr int NT = 256 * PW;
+  constexpr int MF = MV2_P / PW / 16;
+  constexpr float SQRT2 = 1.41421356237309515f, RSQRT2 = 0.70710678118654752f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* X0 = (bf16_t*)smem;
+  bf16_t* X1 = X0 + MV2_P * MV2_XP;
+  bf16_t* F = X1 + MV2_P * MV2_XP;
+
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: weight addresses live in SGPRs
+  const int cw = wave & 3, pw = wave >> 2;
+  const int prow0 = pw * (MV2_P / PW);
+  const int64_t tile0 = (int64_t)blockIdx.x * MV2_P;
+  const bf16_t* Wall = (const bf16_t*)a.w;
+
+  f32x4 acc[MF][4];
+  bf16x8 wq[2][4];
+  Mv2Gather<NT> gq;
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // k-step 0 of the next matrix into the ring (issued before the previous pass's epilogue / barrier)
+  auto wprime = [&](int mat_off, int KS) { mv2_wload(Wall, mat_off, KS, cw, 0, lane, wq[0]); };
+  // StyledConv epilogue: + noise, FusedLeakyReLU.  store = write bf16 rows to Xout; otherwise the value stays in acc
+  auto activate = [&](int conv_idx, bf16_t* Xout) {
+    const float* bias = a.fb + MLP_FB_BIAS(conv_idx);
+    f32x4 b4[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) b4[nf] = *reinterpret_cast<const f32x4*>(bias + 64 * cw + 16 * nf + 4 * lg);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int row = prow0 + 16 * mf + lr;
+      float nz = 0.f;
+      if constexpr (NOISE) nz = mlp_noise(a, conv_idx, tile0 + row);  // checkpoints with non-zero noise.weight only
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        f32x4 v = acc[mf][nf];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = NOISE ? v[e] + nz + b4[nf][e] : v[e] + b4[nf][e];
+          v[e] = (t > 0.f ? t : 0.2f * t) * SQRT2;
+        }
+        acc[mf][nf] = v;
+        if (Xout != nullptr) {
+          bf16x4 q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x4*>(Xout + row * MV2_XP + 64 * cw + 16 * nf + 4 * lg) = q;
+        }
+      }
+    }
+  };
+  // block output: x = (acc [+ skip constant] [+ identity skip from Xid]) / sqrt2 -> Xout
+  auto block_store = [&](int skip_const_idx, const bf16_t* Xid, bf16_t* Xout) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int n = 64 * cw + 16 * nf + 4 * lg;
+      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (skip_const_idx >= 0) sc = *reinterpret_cast<const f32x4*>(a.fb + MLP_FB_SKIP(skip_const_idx) + n);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int row = prow0 + 16 * mf + lr;
+        f32x4 v = acc[mf][nf];
+        if (Xid != nullptr) {
+          const bf16x4 xi = *reinterpret_cast<const bf16x4*>(Xid + row * MV2_XP + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)xi[e];
+        }
+        bf16x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = (bf16_t)((v[e] + sc[e]) * RSQRT2);
+        *reinterpret_cast<bf16x4*>(Xout + row * MV2_XP + n) = q;
+      }
+    }
+  };
+
+  // ---- one StyledResBlock.  IN = block input buffer (unused when KX == 0), TMP = the other buffer; the block's output
+  //      lands in TMP.  m1, ms, m2, m3 = matrix indices of conv1, skip (-1: identity), conv2, conv3; c0 = index of conv1
+  //      among the 12 StyledConvs; next_plane >= 0: gather that plane into F for the following block; next_mat = the
+  //      matrix whose first k-steps are primed before the last barrier.
+#define MV2_BLOCK(IN, TMP, KX, KF, m1, ms, m2, m3, c0, skip_idx, next_plane, next_off, next_KS)                        \
+  {                                                                                                                   \
+    zero();                                                                                                           \
+    mv2_pass<MF, KX, KF>(IN, F, Wall, mlp_w_off(m1), cw, prow0, lane, wq, acc);                                       \
+    wprime(mlp_w_off(m2), 8);                                                                                         \
+    activate((c0), TMP);                                                                                              \
+    __syncthreads();                                                                                                  \
+    zero();                                                                                                           \
+    mv2_pass<MF, 256, 0>(TMP, F, Wall, mlp_w_off(m2), cw, prow0, lane, wq, acc);                                      \
+    wprime(mlp_w_off(m3), 8);                                                                                         \
+    __syncthreads(); /* every wave has read TMP: conv2 writes it in place */                                          \
+    activate((c0) + 1, TMP);                                                                                          \
+    if ((next_plane) >= 0) mv2_gather_issue<NT>(a, (next_plane), tile0, gq);                                          \
+    __syncthreads();                                                                                                  \
+    zero();                                                                                                           \
+    mv2_pass<MF, 256, 0>(TMP, F, Wall, mlp_w_off(m3), cw, prow0, lane, wq, acc);                                      \
+    if ((ms) >= 0) wprime(mlp_w_off((ms) >= 0 ? (ms) : 0), ((KX) + (KF)) / 32);                                       \
+    activate((c0) + 2, nullptr);                                                                                      \
+    __syncthreads(); /* every wave has read TMP: the block output goes there */                                       \
+    if ((ms) >= 0) mv2_pass<MF, KX, KF>(IN, F, Wall, mlp_w_off((ms) >= 0 ? (ms) : 0), cw, prow0, lane, wq, acc);      \
+    if ((next_KS) > 0) wprime((next_off), (next_KS));                                                                 \
+    block_store((skip_idx), (ms) >= 0 ? nullptr : IN, TMP);                                                           \
+    if ((next_plane) >= 0) {                                                                                          \
+      __syncthreads(); /* every wave is done with the current features */                                             \
+      mv2_gather_commit<NT>(gq, F);                                                                                   \
+    }                                                                                                                 \
+    __syncthreads();                                                                                                  \
+  }
+
+  mv2_gather_issue<NT>(a, 0, tile0, gq);
+  wprime(mlp_w_off(0), 2);
+  mv2_gather_commit<NT>(gq, F);
+  __syncthreads();
+  //          IN  TMP  KX  KF  m1  ms  m2  m3  c0 skip next_plane  next matrix
+  MV2_BLOCK(X1, X0, 0, 64, 0, 1, 2, 3, 0, 0, 1, mlp_w_off(4), 10);     // block 1: input f0            -> X0
+  MV2_BLOCK(X0, X1, 256, 64, 4, 5, 6, 7, 3, 1, 2, mlp_w_off(8), 10);   // block 2: input [x1 | f1]     -> X1
+  MV2_BLOCK(X1, X0, 256, 64, 8, 9, 10, 11, 6, 2, -1, mlp_w_off(12), 8);  // block 3: input [x2 | f2]   -> X0
+  MV2_BLOCK(X0, X1, 256, 0, 12, -1, 13, 14, 9, -1, -1, 0, 0);          // block 4: identity skip       -> X1
+#undef MV2_BLOCK
+  // ================= ToRGB: 256 -> 3 (rows padded to 16), 16-point fragments split over the waves ======================
+  {
+    constexpr int MFT = (MV2_P / 16) / (4 * PW);
+    f32x4 r[MFT];
+#pragma unroll
+    for (int i = 0; i < MFT; ++i) r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wall + mv2_wfrag(mlp_w_off(15), 8, 0, ks) + 8 * lane);
+#pragma unroll
+      for (int i = 0; i < MFT; ++i) {
+        const int row = 16 * (wave * MFT + i) + lr;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(X1 + row * MV2_XP + ks * 32 + 8 * lg);
+        r[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, r[i], 0, 0, 0);
+      }
+    }
+    if (lg == 0) {
+      const f32x4 rb = *reinterpret_cast<const f32x4*>(a.fb + MLP_FB_RGB);
+#pragma unroll
+      for (int i = 0; i < MFT; ++i) {
+        const int64_t gp = tile0 + 16 * (wave * MFT + i) + lr;
+        if (gp < a.total) {
+          const int b = (int)(gp / a.N);
+          const int p = (int)(gp - (int64_t)b * a.N);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a.rgb[((int64_t)b * 3 + c) * a.N + p] = r[i][c] + rb[c];
+        }
+      }
+    }
+  }
+}
+
+// host side of the fragment order: row-major [rows][K] fp32 -> [rows/16][K/32][64 lanes][8]
+void mlp2d_pack_fragment_order(const float* src, float* dst) {
+  for (int i = 0; i < 16; ++i) {
+    const int K = mlp_w_k(i), R = mlp_w_rows(i), KS = K / 32, off = mlp_w_off(i);
+    for (int g = 0; g < R / 16; ++g)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e)
+            dst[off + (((g * KS + ks) * 64 + l) << 3) + e] = src[off + (16 * g + (l & 15)) * K + 32 * ks + 8 * (l >> 4) + e];
+  }
+}
+
+template <int PW, bool NOISE> static int launch_mlp2d_v2(const MlpK& k, hipStream_t s) {
+  const size_t lds = (size_t)(2 * MV2_P * MV2_XP + MV2_P * MV2_FP) * sizeof(bf16_t);
+  static bool set = false;
+  if (!set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2d_v2_kernel<PW, NOISE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set = true;
+  }
+  hipLaunchKernelGGL((mlp2d_v2_kernel<PW, NOISE>), dim3((unsigned)cdiv64(k.total, MV2_P)), dim3(256 * PW), lds, s, k);
+  return DDMI_OK;
+}
+
 int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s) {
   MlpK k{};
   for (int i = 0; i < 3; ++i) {
     k.planes[i] = a.planes[i];
     k.hw[i] = a.plane_hw[i];
   }
-  k.coords = a.coords; k.w = a.w; k.fb = a.fb; k.noise = a.noise; k.noise_w = a.noise_w; k.rgb = a.rgb;
+  k.coords = a.coords; k.w = a.w; k.fb = a.fb; k.noise = a.noise; k.seeds = a.seeds; k.noise_w = a.noise_w; k.rgb = a.rgb;
   k.B = a.B; k.N = a.N; k.total = (int64_t)a.B * a.N;
   // algorithmic work: 954,112 MAC per point (mlp.py:28-32); bytes: planes read once + rgb written
   double plane_bytes = 0;
   for (int i = 0; i < 3; ++i) plane_bytes += (double)a.B * a.plane_hw[i] * a.plane_hw[i] * 64 * dt_size(dt);
   PROF_SCOPE("mlp2d_fused", 2.0 * 954112.0 * (double)k.total, plane_bytes + 12.0 * (double)k.total, s);
-  if (dt == DT_BF16) {
-    using L = MlpL<bf16_t>;
-    size_t lds = (size_t)(2 * L::P * L::XP + L::P * L::FP) * sizeof(bf16_t);
-    static bool set = false;
-    if (!set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2d_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      set = true;
-    }
-    hipLaunchKernelGGL(mlp2d_kernel<bf16_t>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+  if (dt == DT_BF16) {  // weights in fragment order (mlp2d_pack_fragment_order)
+    static const int pw = [] { const char* e = getenv("DDMI_MLP2D_PW"); return e ? atoi(e) : 2; }();
+    const bool nz = k.noise != nullptr || k.seeds != nullptr;
+    int rc;
+    if (nz) rc = launch_mlp2d_v2<2, true>(k, s);
+    else if (pw == 1) rc = launch_mlp2d_v2<1, false>(k, s);
+    else rc = launch_mlp2d_v2<2, false>(k, s);
+    DDMI_TRY(rc);
   } else {
     using L = MlpL<float>;
     size_t lds = (size_t)(2 * L::P * L::XP + L::P * L::FP) * sizeof(float);

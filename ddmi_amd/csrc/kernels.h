@@ -128,6 +128,7 @@ struct Mlp2dArgs {
   const void* w;           // packed folded weights, see mlp2d.hip
   const float* fb;         // packed fp32 biases / folded constants
   const float* noise;      // [12][B][N] or null
+  const uint64_t* seeds;   // [B] per-sample Philox seeds or null: NoiseInjection drawn in the kernel when noise == null
   const float* noise_w;    // [12]
   float* rgb;              // [B,3,N]
   int B, N;
@@ -135,6 +136,8 @@ struct Mlp2dArgs {
 int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s);
 size_t mlp2d_weight_elems();
 size_t mlp2d_fb_elems();
+// bf16 handles keep their folded weights in MFMA fragment order: row-major [rows][K] -> [rows/16][K/32][64 lanes][8]
+void mlp2d_pack_fragment_order(const float* src_row_major, float* dst);
 
 // ---- fused tri-plane sampling + occupancy MLP (MLP3D) -----------------------------------------------------
 struct Mlp3dArgs {

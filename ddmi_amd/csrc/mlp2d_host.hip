@@ -174,6 +174,11 @@ static int fold_for_si(Mlp2d& m, float si, hipStream_t s) {
     const HostTensor& rb = m.host.at("torgb.bias");
     for (int c = 0; c < 3; ++c) fb[15 * 256 + c] = rb.data[c];
   }
+  if (m.dt == DT_BF16) {  // the bf16 kernel streams MFMA fragments: [16-row group][k step][lane][8]
+    std::vector<float> Wf(W.size());
+    mlp2d_pack_fragment_order(W.data(), Wf.data());
+    W.swap(Wf);
+  }
   // upload (fp32 staging -> cast to the network dtype on device)
   float* stage = nullptr;
   HIP_TRY(hipMalloc((void**)&stage, W.size() * sizeof(float)));
@@ -189,9 +194,14 @@ static int fold_for_si(Mlp2d& m, float si, hipStream_t s) {
 }
 
 int mlp2d_forward(Mlp2d& m, const void* const* planes, const int* plane_hw, int layout, const float* coords, float si,
-                  const float* noise, float* rgb, int B, int N, hipStream_t s) {
+                  const float* noise, const uint64_t* seeds, float* rgb, int B, int N, hipStream_t s) {
   if (!m.finalized) return ddmi_fail(DDMI_ERR_STATE, "mlp2d not finalized");
   DDMI_REQUIRE(planes && plane_hw && coords && rgb && B > 0 && N > 0, "mlp2d_forward: bad arguments");
+  // NoiseInjection (blocks.py:286-297) adds weight * N(0,1) on every call; a checkpoint with non-zero noise.weight must
+  // not silently lose that term
+  if (m.noise_nonzero && !noise && !seeds)
+    return ddmi_fail(DDMI_ERR_INVALID, "mlp2d_forward: this MLP has non-zero NoiseInjection weights - pass the 12 draws "
+                                       "(noise) or per-sample seeds (ddmi_hdpe_mlp2d_rng)");
   if (!m.have_cache || m.cached_si != si) DDMI_TRY(fold_for_si(m, si, s));  // once per distinct si (synchronises)
   const void* pl[3] = {planes[0], planes[1], planes[2]};
   std::vector<void*> tmp;
@@ -216,6 +226,7 @@ int mlp2d_forward(Mlp2d& m, const void* const* planes, const int* plane_hw, int 
   }
   a.coords = coords; a.w = m.w_dev; a.fb = m.fb_dev;
   a.noise = (noise && m.noise_nonzero) ? noise : nullptr;
+  a.seeds = (!a.noise && seeds && m.noise_nonzero) ? seeds : nullptr;
   a.noise_w = m.noise_w_dev;
   a.rgb = rgb; a.B = B; a.N = N;
   int rc = launch_mlp2d(a, m.dt, s);

@@ -78,7 +78,7 @@ struct Mlp2d {
 };
 int mlp2d_finalize(Mlp2d& m);
 int mlp2d_forward(Mlp2d& m, const void* const* planes, const int* plane_hw, int layout, const float* coords, float si,
-                  const float* noise, float* rgb, int B, int N, hipStream_t s);
+                  const float* noise, const uint64_t* seeds, float* rgb, int B, int N, hipStream_t s);
 
 struct Mlp3d {
   ddmi_mlp2d_cfg cfg{};   // in_ch 3, out_ch 1, ch 256, latent_dim 64

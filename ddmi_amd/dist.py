@@ -37,6 +37,35 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def launch_ranks(n: int, script: str, argv: Sequence[str], extra_env: Optional[dict] = None) -> int:
+    """Starts `script argv...` as n ranks of one node (`python -m torch.distributed.run`, rendezvous on 127.0.0.1 at a
+    free port) and returns the launcher's exit status.  For entry points invoked WITHOUT torchrun (`python bench.py
+    --gpus 8`): call this before anything initialises the GPU - the ranks are child processes, never an exec of a
+    process that holds a HIP context."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    env.update(extra_env or {})
+    return subprocess.call(cmd, env=env)
+
+
+def group_size(device) -> int:
+    """Number of ranks that take part in a collective right now (sum of ones over the group): what bench.py reports as
+    `nccl_ranks`."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
 def shard_indices(total: int, rank: int, world: int) -> List[int]:
     """Global sample indices owned by `rank` (round-robin, so any prefix of the index space is balanced)."""
     return list(range(rank, total, world))

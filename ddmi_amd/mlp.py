@@ -46,6 +46,7 @@ class MLP:
         self._state: Dict[str, np.ndarray] = {}
         self._handle = None
         self._coords_cache = {}
+        self.noise_nonzero = False
 
     def manifest(self):
         return mlp_manifest(self.in_ch, self.latent_dim, self.out_ch, self.ch)
@@ -65,6 +66,8 @@ class MLP:
         if missing and strict:
             raise KeyError(f"missing keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
         self._state = got
+        # NoiseInjection (blocks.py:286-297): weight * N(0,1) per StyledConv; zero at init, possibly not in a checkpoint
+        self.noise_nonzero = any(bool(np.any(v != 0)) for k, v in got.items() if k.endswith("noise.weight"))
         self._destroy()
         return self
 
@@ -102,10 +105,12 @@ class MLP:
         self._handle = h
         return self
 
-    def forward(self, coords, hdbf, si=1, noise=None):
+    def forward(self, coords, hdbf, si=1, noise=None, seeds=None):
         """coords [1,2,R,R] (channel 0 = x, 1 = y; convert_to_coord_format_2d), hdbf = 3 planes coarse -> fine,
-        si = scale injection.  `noise` (optional [12,B,R*R]) replaces the NoiseInjection draws (blocks.py:293-295),
-        only relevant for checkpoints whose `noise.weight` are non-zero.  Returns [B,3,R,R] fp32."""
+        si = scale injection.  NoiseInjection (blocks.py:293-295, only relevant for checkpoints whose `noise.weight` are
+        non-zero): `noise` [12,B,R*R] = the 12 draws given explicitly, or `seeds` [B] int64 = per-sample Philox seeds, drawn
+        inside the kernel; with neither, a per-call torch seed is drawn (the reference draws fresh noise on every call) -
+        the term is never dropped.  Returns [B,3,R,R] fp32."""
         import torch
         assert hdbf is not None and len(hdbf) == 3  # mlp.py:42
         dev = hdbf[0].device
@@ -130,12 +135,20 @@ class MLP:
         out = torch.empty((B, self.out_ch, R_h, R_w), device=dev, dtype=torch.float32)
         ptrs = (C.c_void_p * 3)(*[p.data_ptr() for p in planes])
         hw = (C.c_int * 3)(*[int(p.shape[2]) for p in planes])
-        nz = None
         if noise is not None:
             nz = torch.as_tensor(noise).to(device=dev, dtype=torch.float32).reshape(12, B, N).contiguous()
-        _lib.check(_lib.lib().ddmi_hdpe_mlp2d(self._handle, ptrs, hw, layout, pts.data_ptr(), float(si),
-                                              nz.data_ptr() if nz is not None else None, out.data_ptr(), B, N,
-                                              _lib.stream_ptr()))
+            _lib.check(_lib.lib().ddmi_hdpe_mlp2d(self._handle, ptrs, hw, layout, pts.data_ptr(), float(si),
+                                                  nz.data_ptr(), out.data_ptr(), B, N, _lib.stream_ptr()))
+        elif self.noise_nonzero:
+            if seeds is None:  # fresh noise per call, like `new_empty(...).normal_()` on the global generator
+                seeds = torch.randint(0, 2 ** 62, (B,), dtype=torch.int64)
+            sd = torch.as_tensor(seeds).to(device=dev, dtype=torch.int64).contiguous()
+            assert sd.numel() == B, "one seed per sample"
+            _lib.check(_lib.lib().ddmi_hdpe_mlp2d_rng(self._handle, ptrs, hw, layout, pts.data_ptr(), float(si),
+                                                      sd.data_ptr(), out.data_ptr(), B, N, _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().ddmi_hdpe_mlp2d(self._handle, ptrs, hw, layout, pts.data_ptr(), float(si), None,
+                                                  out.data_ptr(), B, N, _lib.stream_ptr()))
         return out
 
     __call__ = forward

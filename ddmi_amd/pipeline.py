@@ -18,6 +18,30 @@ from .mlp import MLP
 from .unet import UNetModel
 
 
+RNG_MODES = ("philox", "torch", "reference")
+
+
+def _load_checkpoint_into(pipe, path: str, use_ema: bool, vae_strict: bool):
+    """Shared by the three pipelines: see ddmi_amd/checkpoint.py for the file layouts (tools/ldm/image.py:70-88,
+    tools/ldm/video.py:68-83, tools/ldm/occupancy.py:76-94).  Returns 'ldm' or 'stage1'."""
+    from . import checkpoint as CK
+    st = CK.sampling_states(CK.read_checkpoint(path), use_ema=use_ema)
+    pipe.vae.load_state_dict(st["vae"], strict=vae_strict)
+    pipe.mlp.load_state_dict(st["mlp"], strict=True)
+    if st["diffusion"] is not None:
+        pipe.ddpm.load_state_dict(st["diffusion"], strict=True)
+    return st["kind"]
+
+
+def reference_draws(shape, device):
+    """rng='reference' (SURVEY 8a a24): the noise of the reference's PyTorch-CPU path, `torch.randn(shape)` from the global
+    CPU generator in the reference's draw order - x_T (ddpm.py:288 / :343), then one draw per step (ddpm.py:278 via
+    noise_like; ddpm.py:363 randn_like on every non-final DDIM step, also when eta == 0).  Returns (x_T, step_noise)."""
+    import torch
+    x_T = torch.randn(tuple(shape))
+    return x_T.to(device), (lambda i: torch.randn(tuple(shape)))
+
+
 class ImagePipeline:
     def __init__(self, unetconfig: Mapping, ddconfig: Mapping, mlpconfig: Mapping, ddpmconfig: Mapping, embed_dim: int,
                  test_resolution: int = 256, numerics: str = "bf16", max_batch: int = 8, device: str = "cuda:0"):
@@ -44,20 +68,10 @@ class ImagePipeline:
         return self
 
     def load_checkpoint(self, path: str, use_ema: bool = True):
-        """`ldm-last.pt` as written by tools/ldm/image.py:104-119: keys 'vaemodel', 'mlp', 'diffusion', 'ema'
-        ('ema' = ema_pytorch state: the sampling weights live under the `ema_model.` prefix, tools/ldm/image.py:64,240)."""
-        import torch
-        ck = torch.load(path, map_location="cpu", weights_only=False)
-        self.vae.load_state_dict(ck["vaemodel"], strict=True)
-        self.mlp.load_state_dict(ck["mlp"], strict=True)
-        diff = ck["diffusion"]
-        if use_ema and "ema" in ck:
-            ema = {k[len("ema_model."):]: v for k, v in ck["ema"].items() if k.startswith("ema_model.")}
-            if ema:
-                diff = ema
-        diff = {k: v for k, v in diff.items() if k != "lvlb_weights" and k != "logvar"}
-        self.ddpm.load_state_dict(diff, strict=True)
-        return self
+        """`ldm-last.pt` (resume / pretrained, tools/ldm/image.py:70-82) or the stage-1 `model-last.pt`
+        (tools/ldm/image.py:83-88: VAE + MLP only, the diffusion model keeps its current weights).  Read through the
+        restricted unpickler of ddmi_amd/checkpoint.py (the pickled `args` needs no omegaconf)."""
+        return _load_checkpoint_into(self, path, use_ema, vae_strict=True) and self
 
     def finalize(self):
         idx = int(str(self.device).split(":")[1]) if ":" in str(self.device) else 0
@@ -73,17 +87,29 @@ class ImagePipeline:
         return self._coords
 
     def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, events=None,
-                 rng: str = "philox"):
-        """One batch of finished samples for the given GLOBAL sample indices.  Every chain draws x_T and its per-step
-        noise from its own counter-based stream keyed by sample_seed(base_seed, index) (inside the sampler-step
-        kernel), so results do not depend on how indices are sharded over GPUs or batched."""
+                 rng: str = "philox", reseed: bool = True):
+        """One batch of finished samples for the given GLOBAL sample indices.
+        rng='philox' (default): every chain draws x_T, its per-step noise and its NoiseInjection noise from its own
+        counter-based stream keyed by sample_seed(base_seed, index) inside the kernels, so results do not depend on how
+        indices are sharded over GPUs or batched.
+        rng='reference': the reference's own noise - `torch.manual_seed(base_seed)` (utils/general_utils.py:16-23; skipped
+        with reseed=False to continue the stream as consecutive generate() calls of one reference process would) and
+        CPU `randn` in the reference's order: x_T, one per step, then the 12 NoiseInjection draws [B,1,R,R]
+        (blocks.py:293-295).  Same seed -> same samples as the reference's PyTorch-CPU path; depends on the batch."""
         import torch
+        assert rng in RNG_MODES, rng
         B = len(indices)
         dev = torch.device(self.device)
         shape = (B, self.embed_dim, self.latent_size, self.latent_size)
+        seeds = None
         if rng == "philox":
             seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
             z = self.ddpm.sample(list(shape), seeds=seeds, device=dev)
+        elif rng == "reference":
+            if reseed:
+                torch.manual_seed(int(base_seed))
+            x_T, draw = reference_draws(shape, dev)
+            z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
         else:  # rng == "torch": one torch device generator per chain (B small launches per step; kept for comparison)
             gens = []
             for i in indices:
@@ -103,7 +129,14 @@ class ImagePipeline:
         planes = self.vae.decode(z)
         if events:
             events[1].record()
-        img = self.mlp(self.coords(), hdbf=planes, si=get_scale_injection(self.test_resolution))
+        R = self.test_resolution
+        inj = None
+        if rng == "reference":   # the reference draws these whether or not noise.weight is zero (blocks.py:292-295)
+            inj = torch.stack([torch.empty(B, 1, R, R).normal_() for _ in range(12)]).reshape(12, B, R * R)
+            if not self.mlp.noise_nonzero:
+                inj = None       # consumed from the generator, not needed by the kernel
+        img = self.mlp(self.coords(), hdbf=planes, si=get_scale_injection(R), noise=inj,
+                       seeds=seeds if inj is None else None)
         img = img.clamp_(-1.0, 1.0)
         return (img, z) if return_latent else img
 
@@ -140,19 +173,9 @@ class VideoPipeline:
         return self
 
     def load_checkpoint(self, path: str, use_ema: bool = True):
-        """`ldm-last.pt` as written by tools/ldm/video.py:93-109 (same keys as the image trainer)."""
-        import torch
-        ck = torch.load(path, map_location="cpu", weights_only=False)
-        self.vae.load_state_dict(ck["vaemodel"], strict=False)   # encoder / TimeSformer entries are not on this path
-        self.mlp.load_state_dict(ck["mlp"], strict=True)
-        diff = ck["diffusion"]
-        if use_ema and "ema" in ck:
-            ema = {k[len("ema_model."):]: v for k, v in ck["ema"].items() if k.startswith("ema_model.")}
-            if ema:
-                diff = ema
-        diff = {k: v for k, v in diff.items() if k != "lvlb_weights" and k != "logvar"}
-        self.ddpm.load_state_dict(diff, strict=True)
-        return self
+        """`ldm-last.pt` (tools/ldm/video.py:68-79, written by :93-109) or the stage-1 `model-last.pt` (:80-82); the
+        encoder / TimeSformer entries of 'vaemodel' are not on this path."""
+        return _load_checkpoint_into(self, path, use_ema, vae_strict=False) and self
 
     def finalize(self):
         idx = int(str(self.device).split(":")[1]) if ":" in str(self.device) else 0
@@ -168,14 +191,23 @@ class VideoPipeline:
             self._coords = video_generation_coords(self.test_resolution, self.frames)
         return self._coords
 
-    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False):
-        """Finished clips for the given GLOBAL sample indices; per-sample generators as in ImagePipeline.generate."""
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, rng: str = "philox",
+                 reseed: bool = True):
+        """Finished clips for the given GLOBAL sample indices; `rng` as in ImagePipeline.generate (MLPVideo has no
+        NoiseInjection, so the reference draws x_T and the per-step noise only, tools/ldm/video.py:214-236)."""
         import torch
+        assert rng in ("philox", "reference"), rng
         B = len(indices)
         dev = torch.device(self.device)
         shape = (B, self.embed_dim, self.unet.seq_len)
-        seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
-        z = self.ddpm.sample(list(shape), seeds=seeds, device=dev)
+        if rng == "reference":
+            if reseed:
+                torch.manual_seed(int(base_seed))
+            x_T, draw = reference_draws(shape, dev)
+            z = self.ddpm.sample(list(shape), noise=x_T, step_noise=draw, device=dev)
+        else:
+            seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
+            z = self.ddpm.sample(list(shape), seeds=seeds, device=dev)
         outs = []
         for b0 in range(0, B, self.vae.max_batch):  # decode in slices: the 73k-token attention buffers are per sample
             zz = z[b0:b0 + self.vae.max_batch].contiguous()
@@ -218,19 +250,9 @@ class OccupancyPipeline:
         return self
 
     def load_checkpoint(self, path: str, use_ema: bool = True):
-        """`ldm-last.pt` of tools/ldm/occupancy.py (same keys as the image trainer; the PointNet encoder is not on this path)."""
-        import torch
-        ck = torch.load(path, map_location="cpu", weights_only=False)
-        self.vae.load_state_dict(ck["vaemodel"], strict=False)
-        self.mlp.load_state_dict(ck["mlp"], strict=True)
-        diff = ck["diffusion"]
-        if use_ema and "ema" in ck:
-            ema = {k[len("ema_model."):]: v for k, v in ck["ema"].items() if k.startswith("ema_model.")}
-            if ema:
-                diff = ema
-        diff = {k: v for k, v in diff.items() if k != "lvlb_weights" and k != "logvar"}
-        self.ddpm.load_state_dict(diff, strict=True)
-        return self
+        """`ldm-last.pt` (tools/ldm/occupancy.py:76-87) or the stage-1 `model-last.pt` (:88-94: 'vaemodel', 'mlp',
+        'pointnet'); the PointNet encoder is not on this path."""
+        return _load_checkpoint_into(self, path, use_ema, vae_strict=False) and self
 
     def finalize(self):
         idx = int(str(self.device).split(":")[1]) if ":" in str(self.device) else 0
@@ -240,13 +262,22 @@ class OccupancyPipeline:
         self.mlp.finalize(idx)
         return self
 
-    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False):
+    def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, rng: str = "philox",
+                 reseed: bool = True):
         """One TriMesh per GLOBAL sample index (per-sample noise streams, so the set does not depend on batching or on the
-        number of GPUs); meshes are extracted one latent at a time, as the reference does (tools/ldm/occupancy.py:216-217)."""
+        number of GPUs); meshes are extracted one latent at a time, as the reference does (tools/ldm/occupancy.py:216-217).
+        `rng` as in ImagePipeline.generate."""
         import torch
+        assert rng in ("philox", "reference"), rng
         B = len(indices)
         dev = torch.device(self.device)
-        seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
-        z = self.ddpm.sample([B, *self.latent_shape], seeds=seeds, device=dev)
+        if rng == "reference":
+            if reseed:
+                torch.manual_seed(int(base_seed))
+            x_T, draw = reference_draws((B, *self.latent_shape), dev)
+            z = self.ddpm.sample([B, *self.latent_shape], noise=x_T, step_noise=draw, device=dev)
+        else:
+            seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
+            z = self.ddpm.sample([B, *self.latent_shape], seeds=seeds, device=dev)
         meshes = [self.mesh_gen.generate_mesh_fromdiffusion(z[j:j + 1].contiguous(), self.vae, self.mlp, dev)[0] for j in range(B)]
         return (meshes, z) if return_latent else meshes

@@ -154,6 +154,16 @@ int ddmi_mlp2d_finalize(ddmi_mlp2d* h);
  * noise: optional [12,B,N] fp32 NoiseInjection draws (blocks.py:286-297), null = none; rgb_out [B,3,N] fp32 */
 int ddmi_hdpe_mlp2d(ddmi_mlp2d* h, const void* const* planes, const int* plane_hw, int layout, const float* coords,
                     float si, const float* noise, float* rgb_out, int B, int N, void* stream);
+/* The same with the NoiseInjection draws made inside the kernel: `torch.randn`-free replacement of
+ * `image.new_empty(batch,1,h,w).normal_()` (blocks.py:293-295).  seeds [B] uint64 on the device (one per sample, the
+ * per-chain seeds of ddmi_ddpm_step_rng); draw c (0..11, call order) of query point p of sample b is
+ * normal(seeds[b], 0xFFFE0000 + c, p) - what ddmi_randn_fill(out, seeds, B, N, 0xFFFE0000 + c) writes - so a sample's
+ * image does not depend on its batch.  A handle whose `noise.weight` tensors are all zero ignores the seeds; a handle
+ * with non-zero weights REFUSES ddmi_hdpe_mlp2d(noise = null): the term is never dropped silently. */
+int ddmi_hdpe_mlp2d_rng(ddmi_mlp2d* h, const void* const* planes, const int* plane_hw, int layout, const float* coords,
+                        float si, const uint64_t* seeds, float* rgb_out, int B, int N, void* stream);
+/* *out = 1 when any of the 12 `noise.weight` scalars is non-zero (after finalize) */
+int ddmi_mlp2d_noise_nonzero(ddmi_mlp2d* h, int* out);
 int ddmi_mlp2d_destroy(ddmi_mlp2d* h);
 
 /* ---------------------------------------------------------------------------------------------------------

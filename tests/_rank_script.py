@@ -1,0 +1,24 @@
+"""Run by tests/test_dist_gloo.py through ddmi_amd.dist.launch_ranks (the `python bench.py --gpus N` self-launch path):
+one rank of a world the launcher started; writes what it saw to argv[1]."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from ddmi_amd import dist as D  # noqa: E402
+
+rank, local_rank, world = D.init_process_group()  # gloo on a CPU-only host, nccl (= RCCL) on a GPU box
+dev = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
+local = torch.full((2, 3), float(rank), device=dev)
+full = D.all_gather_samples(local, world)
+rec = {"rank": rank, "world": world, "ranks": D.group_size(dev), "rows": full[:, 0].tolist(),
+       "backend": torch.distributed.get_backend() if world > 1 else None,
+       "max": D.max_over_ranks(float(rank), dev)}
+with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
+    json.dump(rec, f)
+D.barrier()
+if world > 1:
+    torch.distributed.destroy_process_group()

@@ -53,6 +53,20 @@ def test_sharded_generation_matches_single_process(tmp_path):
     assert torch.equal(D.generate_sharded(fake_generate, total, b_local, 0, 1), ref)
 
 
+def test_self_launch_starts_the_ranks(tmp_path):
+    """`python bench.py --gpus N` without torchrun: ddmi_amd.dist.launch_ranks starts N child ranks (here 2, gloo)."""
+    import json
+    from ddmi_amd import dist as D
+    rc = D.launch_ranks(2, os.path.join(ROOT, "tests", "_rank_script.py"), [str(tmp_path)])
+    assert rc == 0
+    for rank in range(2):
+        with open(os.path.join(tmp_path, f"rank{rank}.json")) as f:
+            rec = json.load(f)
+        assert rec["world"] == 2 and rec["ranks"] == 2 and rec["rows"] == [0.0, 0.0, 1.0, 1.0] and rec["max"] == 1.0
+    # a failing rank is the launcher's failure
+    assert D.launch_ranks(2, os.path.join(ROOT, "tests", "_rank_script.py"), [os.path.join(str(tmp_path), "missing")]) != 0
+
+
 def test_shard_helpers():
     from ddmi_amd import dist as D
     assert D.shard_indices(10, 1, 4) == [1, 5, 9]
