@@ -148,6 +148,9 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise DdmiError(f"{LIB_PATH} is missing: build it with `python -m ddmi_amd.build` "
                             "(hipcc --offload-arch=gfx950); ddmi_amd has no fallback path")
+        default_plans = os.path.join(HERE, "tuned", "conv_plans_mi355x.txt")
+        if os.path.exists(default_plans):   # read-only plans shipped with the package (net.hip: DDMI_TUNE_DEFAULT)
+            os.environ.setdefault("DDMI_TUNE_DEFAULT", default_plans)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

@@ -36,6 +36,7 @@ def load_ldm_args(path: str, args: argparse.Namespace = None) -> argparse.Namesp
     args.embed_dim = cfg.model.embed_dim
     args.resolution = p.ddconfig.resolution
     args.pretrained = cfg.model.get("pretrained", True)
+    args.resume = cfg.model.get("resume", False)
     args.use_fp16 = cfg.model.get("use_fp16", True)
     args.domain = cfg.data.domain
     args.mode = cfg.data.mode

@@ -82,6 +82,8 @@ struct ConvArgs {
                       // on the pipe kernel's paired-fragment instantiation (16-byte epilogue accesses)
   int tile_map;       // blockIdx -> tile: 0 = heuristic, -1 = row-major, 1 / 2 = XCD-contiguous m-major / n-major (k_conv.hip)
 };
+// bump when the meaning of (cfg, order) changes: plan files written for other tables are ignored (net.hip)
+#define CONV_PLAN_VERSION 2
 struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // result of conv_autotune (0 = heuristic)
 // times the candidate (configuration, K order, split-K) triples on the real buffers and returns the fastest;
 // `ws`/`ws_bytes`: split-K slab scratch for the trials.  Synchronises; only called at finalize.

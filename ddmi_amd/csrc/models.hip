@@ -339,7 +339,14 @@ int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int 
   DDMI_TRY(unet_forward_launch(u, x, t, eps_out, B, s));
   if (u.graphs.size() >= 8) return DDMI_OK;  // an unbounded set of buffers: stay on the launch path
   hipGraph_t graph = nullptr;
-  HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    // the legacy default stream (torch's current stream unless the caller switched) refuses capture: not an error of this
+    // call - its result exists already - just no graph for this handle
+    (void)hipGetLastError();
+    if (getenv("DDMI_GRAPH_DEBUG")) fprintf(stderr, "ddmi: stream capture refused on this stream; staying on the launch path\n");
+    u.use_graph = false;
+    return DDMI_OK;
+  }
   int rc = unet_forward_launch(u, x, t, eps_out, B, s);
   hipError_t e = hipStreamEndCapture(s, &graph);
   if (rc != DDMI_OK || e != hipSuccess || graph == nullptr) {

@@ -24,7 +24,8 @@ struct ConvW {
   void* w = nullptr;      // packed [Cout][taps*Cin], network dtype
   float* bias = nullptr;  // [Cout] fp32 (may be null)
   int Cout = 0, Cin = 0, K = 1;
-  void* w_up4 = nullptr;  // bf16 parity form for a fused x2 upsample (launch_pack_conv_up4), made when an op needs it
+  void* w_up4 = nullptr;  // bf16 parity form for a fused x2 upsample (launch_pack_conv_up4), made by plan() when an op
+  bool want_up4 = false;  // asked for it (op_conv only marks: it returns a tensor id, not a status)
   std::string wkey;       // state-dict key of the raw fp32 weight (make_conv), valid until finalize drops the host copies
 };
 
@@ -108,6 +109,7 @@ struct Net {
   int op_gn(int in, int gn, int silu, float eps, int in2 = -1);  // in2 >= 0: GroupNorm of the channel concat [in | in2]
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
   int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
+  int pack_up4_weights();  // parity-form weights of the marked upsample convolutions (called by plan)
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }
   size_t tbytes(int id, int B) const;

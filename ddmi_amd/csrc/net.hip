@@ -147,30 +147,10 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
   const TensorDesc& t = tensors[in];
   ConvW& c = convs[conv];
   int pad = c.K / 2;
-  // x2 nearest upsample + 3x3 conv in the bf16 network: four 2x2 parity convolutions on the source grid (k_conv.hip)
+  // x2 nearest upsample + 3x3 conv in the bf16 network: four 2x2 parity convolutions on the source grid (k_conv.hip).
+  // Only marked here - op_conv returns a TENSOR id, so nothing that can fail lives in it; plan() packs the weights.
   static const bool up4 = !(getenv("DDMI_CONV_UP4") && atoi(getenv("DDMI_CONV_UP4")) == 0);
-  if (up4 && dt == DT_BF16 && ups == 1 && c.K == 3 && stride == 1 && res < 0 && emb_off < 0 && !c.w_up4) {
-    const size_t bytes = (size_t)16 * c.Cout * c.Cin * dt_size(dt);
-    void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, bytes));
-    dev_allocs.push_back(p);
-    const HostTensor* raw = c.wkey.empty() ? nullptr : find(c.wkey);
-    if (raw && raw->numel() == (int64_t)c.Cout * c.Cin * 9) {   // sum the taps in fp32, round once
-      float* tmp = nullptr;
-      HIP_TRY(hipMalloc((void**)&tmp, raw->data.size() * sizeof(float)));
-      hipError_t e = hipMemcpy(tmp, raw->data.data(), raw->data.size() * sizeof(float), hipMemcpyHostToDevice);
-      int rc = e == hipSuccess ? launch_pack_conv_up4_f32(tmp, p, c.Cout, c.Cin, 0) : ddmi_fail(DDMI_ERR_HIP, "weight upload failed");
-      hipError_t e2 = hipDeviceSynchronize();
-      (void)hipFree(tmp);
-      DDMI_TRY(rc);
-      HIP_TRY(e2);
-    } else {
-      DDMI_TRY(launch_pack_conv_up4(c.w, p, c.Cout, c.Cin, 0));
-      HIP_TRY(hipDeviceSynchronize());
-    }
-    weight_bytes += bytes;
-    c.w_up4 = p;
-  }
+  if (up4 && dt == DT_BF16 && ups == 1 && c.K == 3 && stride == 1 && res < 0 && emb_off < 0) c.want_up4 = true;
   int hin = ups == 1 ? 2 * t.H : t.H, win = ups ? 2 * t.W : t.W;
   int ho = (hin + 2 * pad - c.K) / stride + 1, wo = (win + 2 * pad - c.K) / stride + 1;
   Op o;
@@ -210,7 +190,36 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   a->splitk = 1;
 }
 
+// parity-form weights [4][Cout][4][Cin] of the convolutions op_conv marked (want_up4); every failure is returned
+int Net::pack_up4_weights() {
+  for (ConvW& c : convs) {
+    if (!c.want_up4 || c.w_up4) continue;
+    const size_t bytes = (size_t)16 * c.Cout * c.Cin * dt_size(dt);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    dev_allocs.push_back(p);  // owned by the net from here on, whatever happens below
+    const HostTensor* raw = c.wkey.empty() ? nullptr : find(c.wkey);
+    if (raw && raw->numel() == (int64_t)c.Cout * c.Cin * 9) {   // sum the taps in fp32, round once
+      float* tmp = nullptr;
+      HIP_TRY(hipMalloc((void**)&tmp, raw->data.size() * sizeof(float)));
+      hipError_t e = hipMemcpy(tmp, raw->data.data(), raw->data.size() * sizeof(float), hipMemcpyHostToDevice);
+      int rc = e == hipSuccess ? launch_pack_conv_up4_f32(tmp, p, c.Cout, c.Cin, 0) : ddmi_fail(DDMI_ERR_HIP, "weight upload failed");
+      hipError_t e2 = hipDeviceSynchronize();
+      (void)hipFree(tmp);  // on every path
+      DDMI_TRY(rc);
+      HIP_TRY(e2);
+    } else {
+      DDMI_TRY(launch_pack_conv_up4(c.w, p, c.Cout, c.Cin, 0));
+      HIP_TRY(hipDeviceSynchronize());
+    }
+    weight_bytes += bytes;
+    c.w_up4 = p;
+  }
+  return DDMI_OK;
+}
+
 int Net::plan() {
+  DDMI_TRY(pack_up4_weights());
   const int nops = (int)ops.size();
   auto touch = [&](int id, int i, bool write) {
     if (id < 0) return;
@@ -305,22 +314,33 @@ int Net::plan() {
     float* tws = nullptr;
     HIP_TRY(hipMalloc((void**)&tws, tws_bytes));
     std::map<std::vector<int>, ConvPlan> cache;
-    // optional persistent plan cache (DDMI_TUNE_FILE): one line per shape "B Hin Win Cin Cout K stride ups cfg order splitk us"
-    const char* tune_file = getenv("DDMI_TUNE_FILE");
-    if (tune_file) {
-      if (FILE* f = fopen(tune_file, "r")) {
+    // plan files: one line per shape "B Hin Win Cin Cout K stride ups cfg order splitk us" after a "v <CONV_PLAN_VERSION>"
+    // header (a file written for other kernel tables is ignored).  DDMI_TUNE_FILE = read-write cache (new shapes are
+    // appended); DDMI_TUNE_DEFAULT = the read-only plans shipped with the package (ddmi_amd/tuned/), consulted for
+    // shapes the cache does not hold.  Timing-based picks differ from run to run; pinned plans make bf16 results
+    // bit-identical across processes and GPUs (ddmi_amd/dist.py broadcasts rank 0's file for the same reason).
+    auto read_plans = [&](const char* path, bool overwrite) {
+      FILE* f = path ? fopen(path, "r") : nullptr;
+      if (!f) return;
+      int ver = -1;
+      if (fscanf(f, " v %d", &ver) == 1 && ver == CONV_PLAN_VERSION) {
         int v[11];
         float us;
         while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7],
                       &v[8], &v[9], &v[10], &us) == 12) {
           ConvPlan p;
           p.cfg = v[8]; p.order = v[9]; p.splitk = v[10]; p.us = us;
-          cache[std::vector<int>(v, v + 8)] = p;
+          std::vector<int> key(v, v + 8);
+          if (overwrite || !cache.count(key)) cache[key] = p;
         }
-        fclose(f);
       }
-    }
-    size_t cached_before = cache.size();
+      fclose(f);
+    };
+    const char* tune_file = getenv("DDMI_TUNE_FILE");
+    read_plans(tune_file, true);
+    std::map<std::vector<int>, ConvPlan> own = cache;   // what the read-write file holds
+    read_plans(getenv("DDMI_TUNE_DEFAULT"), false);
+    std::map<std::vector<int>, ConvPlan> used;   // what this network's shapes resolved to (written back to the cache file)
     int rc = DDMI_OK;
     for (Op& o : ops) {
       if (o.kind != OP_CONV) continue;
@@ -335,6 +355,7 @@ int Net::plan() {
         if (rc != DDMI_OK) break;
         it = cache.emplace(key, p).first;
       }
+      used[key] = it->second;
       o.tuned = it->second;
       if (o.tuned.splitk > 1)
         splitk_bytes = std::max(splitk_bytes, (size_t)o.tuned.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
@@ -342,13 +363,18 @@ int Net::plan() {
     (void)hipDeviceSynchronize();
     (void)hipFree(tws);
     if (rc != DDMI_OK) return rc;
-    if (tune_file && cache.size() != cached_before) {
-      if (FILE* f = fopen(tune_file, "w")) {
-        for (auto& kv : cache) {
-          for (int x : kv.first) fprintf(f, "%d ", x);
-          fprintf(f, "%d %d %d %.2f\n", kv.second.cfg, kv.second.order, kv.second.splitk, kv.second.us);
+    if (tune_file) {   // the cache file = its own entries + every shape of this network (so it alone reproduces the run)
+      const size_t before = own.size();
+      for (auto& kv : used) own.emplace(kv.first, kv.second);
+      if (own.size() != before) {
+        if (FILE* f = fopen(tune_file, "w")) {
+          fprintf(f, "v %d\n", CONV_PLAN_VERSION);
+          for (auto& kv : own) {
+            for (int x : kv.first) fprintf(f, "%d ", x);
+            fprintf(f, "%d %d %d %.2f\n", kv.second.cfg, kv.second.order, kv.second.splitk, kv.second.us);
+          }
+          fclose(f);
         }
-        fclose(f);
       }
     }
     if (splitk_bytes) {  // re-size the slabs for the tuned splits

@@ -66,6 +66,31 @@ def group_size(device) -> int:
     return int(t.item())
 
 
+def finalize_with_shared_plans(finalize: Callable[[], object], rank: int, world: int) -> Optional[str]:
+    """Runs `finalize()` (pipeline.finalize: weight packing + per-shape convolution autotune) on every rank with ONE set of
+    convolution plans: rank 0 tunes into a plan file, its text is broadcast, the other ranks finalize from it.  The
+    autotuner is timing-based, so two ranks tuning on their own can pick different tiles / split-K for the same shape;
+    with shared plans the bf16 results of a sample are bit-identical whichever GPU produced it.  A user-pinned
+    DDMI_TUNE_FILE is respected as is.  Returns the plan file path (None for a single process)."""
+    if world == 1 or not dist.is_initialized() or os.environ.get("DDMI_TUNE_FILE"):
+        finalize()
+        return os.environ.get("DDMI_TUNE_FILE")
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"ddmi_conv_plans_{os.getpid()}_rank{rank}.txt")
+    text = [None]
+    if rank == 0:
+        os.environ["DDMI_TUNE_FILE"] = path
+        finalize()
+        text[0] = open(path).read() if os.path.exists(path) else ""
+    dist.broadcast_object_list(text, src=0)
+    if rank != 0:
+        with open(path, "w") as f:
+            f.write(text[0])
+        os.environ["DDMI_TUNE_FILE"] = path
+        finalize()
+    return path
+
+
 def shard_indices(total: int, rank: int, world: int) -> List[int]:
     """Global sample indices owned by `rank` (round-robin, so any prefix of the index space is balanced)."""
     return list(range(rank, total, world))

@@ -42,10 +42,13 @@ def seed_of(tag: str, key: str) -> int:
     return (hi << 32) | lo
 
 
-def std_normal(seed: int, n: int) -> np.ndarray:
-    """`n` approximately-N(0,1) float64 values, bit-reproducible (see module doc)."""
+_CHUNK = 1 << 17  # elements per block: the ~10 temporaries of a block stay cache-resident (a 16 M-element conv weight
+                  # otherwise walks 2.5 GB of fresh pages; same values either way - every element is a pure function of i)
+
+
+def _std_normal_block(seed: int, start: int, n: int) -> np.ndarray:
     with np.errstate(over="ignore"):
-        idx = np.arange(2 * n, dtype=np.uint64) * _GOLDEN + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+        idx = np.arange(2 * start, 2 * (start + n), dtype=np.uint64) * _GOLDEN + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
     z = _splitmix64(idx)
     s = np.zeros(2 * n, dtype=np.int64)
     for sh in (0, 16, 32, 48):
@@ -54,10 +57,27 @@ def std_normal(seed: int, n: int) -> np.ndarray:
     return (tot.astype(np.float64) - 8.0 * 32767.5) / _STD8
 
 
+def std_normal(seed: int, n: int) -> np.ndarray:
+    """`n` approximately-N(0,1) float64 values, bit-reproducible (see module doc)."""
+    if n <= _CHUNK:
+        return _std_normal_block(seed, 0, n)
+    out = np.empty(n, dtype=np.float64)
+    for a in range(0, n, _CHUNK):
+        b = min(n, a + _CHUNK)
+        out[a:b] = _std_normal_block(seed, a, b - a)
+    return out
+
+
 def normal(tag: str, key: str, shape: Sequence[int], mean: float = 0.0, std: float = 1.0) -> np.ndarray:
     n = int(np.prod(shape)) if len(shape) else 1
-    v = std_normal(seed_of(tag, key), n) * std + mean
-    return v.astype(np.float32).reshape(tuple(shape))
+    seed = seed_of(tag, key)
+    if n <= _CHUNK:
+        return (std_normal(seed, n) * std + mean).astype(np.float32).reshape(tuple(shape))
+    out = np.empty(n, dtype=np.float32)      # fp64 -> scale -> shift -> fp32 per block: the same per-element operations
+    for a in range(0, n, _CHUNK):
+        b = min(n, a + _CHUNK)
+        out[a:b] = (_std_normal_block(seed, a, b - a) * std + mean).astype(np.float32)
+    return out.reshape(tuple(shape))
 
 
 # --------------------------------------------------------------------------------------
@@ -87,16 +107,25 @@ def _rule(key: str, shape: Tuple[int, ...]) -> Tuple[float, float]:
 
 
 def fill_state(tag: str, manifest: Iterable[Tuple[str, Sequence[int]]]) -> Dict[str, np.ndarray]:
-    """Deterministic fp32 tensors for every `(key, shape)` of a state-dict manifest."""
-    out: Dict[str, np.ndarray] = {}
-    for key, shape in manifest:
-        shape = tuple(int(s) for s in shape)
+    """Deterministic fp32 tensors for every `(key, shape)` of a state-dict manifest.  Tensors are independent (each has its
+    own seed), so large manifests are filled by a few threads (numpy releases the GIL inside its loops)."""
+    items = [(key, tuple(int(s) for s in shape)) for key, shape in manifest]
+
+    def one(item):
+        key, shape = item
         mean, std = _rule(key, shape)
         if std == 0.0:
-            out[key] = np.full(shape, mean, dtype=np.float32)
-        else:
-            out[key] = normal(tag, key, shape, mean, std)
-    return out
+            return np.full(shape, mean, dtype=np.float32)
+        return normal(tag, key, shape, mean, std)
+
+    total = sum(int(np.prod(sh)) if len(sh) else 1 for _, sh in items)
+    if total < (1 << 22):
+        return {it[0]: one(it) for it in items}
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+        vals = list(ex.map(one, items))
+    return {it[0]: v for it, v in zip(items, vals)}
 
 
 def fill_like(tag: str, state: Mapping[str, "np.ndarray"]) -> Dict[str, np.ndarray]:

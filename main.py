@@ -43,19 +43,14 @@ def main(args):
     else:
         pipe = ImagePipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
                              test_resolution=int(dc.test_resolution), numerics=args.numerics, max_batch=B, device=dev)
-    ckpt = os.path.join(dc.save_pth, "ldm-last.pt")
-    if os.path.exists(ckpt):
-        print("Loading Pretrained Models!")
-        pipe.load_checkpoint(ckpt)
-    else:
-        print(f"{ckpt} not found: using named-seed synthetic weights")
-        pipe.load_named_seed("sky" if args.domain == "video" else "afhq")
+    load_weights(pipe, args, dc, "sky" if args.domain == "video" else "afhq")
     pipe.finalize()
     out_dir = os.path.join(dc.save_pth, "results")
     os.makedirs(out_dir, exist_ok=True)
+    gen = lambda idx, first: pipe.generate(idx, base_seed=args.seed, rng=args.rng, reseed=first)
     if args.mode == "gen":
         print("Random image generation!")
-        img = D.generate_sharded(lambda idx: pipe.generate(idx, base_seed=args.seed), world * B, B, rank, world)
+        img = D.generate_sharded(lambda idx: gen(idx, True), world * B, B, rank, world)
         if rank == 0 and args.domain == "video":  # [N, 3, T, H, W] -> uint8 [N, T, H, W, 3] (tools/ldm/video.py:231-236 writes frames)
             u8 = ((img + 1) / 2 * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 4, 1).cpu().numpy()
             np.save(os.path.join(out_dir, "generation_video.npy"), u8)
@@ -71,14 +66,62 @@ def main(args):
                 pass
             print("Finished generating images!")
     elif args.mode == "eval":
+        # evals/eval.py:215-234: `total_fake_number // batch_size` batches of samples, each written out as uint8.  Every
+        # batch is converted to uint8 ON THE DEVICE (ddmi_image_to_u8, bit-identical to the numpy expression) and only
+        # those bytes are gathered and written by rank 0 as one shard per global batch - fp32 samples never accumulate
+        # (10k images would be 7.9 GB per rank, 10k video clips 126 GB).
+        from ddmi_amd.mcubes import images_to_uint8
         total = int(os.environ.get("DDMI_EVAL_SAMPLES", 10000)) // (world * B) * (world * B)
-        img = D.generate_sharded(lambda idx: pipe.generate(idx, base_seed=args.seed), total, B, rank, world)
+        fid_dir = os.path.join(out_dir, "fid50k")   # tools/ldm/image.py:221
+        os.makedirs(fid_dir, exist_ok=True)
+        mine = D.shard_indices(total, rank, world)
+        for k in range(0, len(mine), B):
+            idx = mine[k:k + B]
+            img = gen(idx, k == 0)
+            if args.domain == "video":   # [B,3,T,H,W] -> frames as images [B*T,3,H,W]
+                Bv, Cv, Tv, Hv, Wv = img.shape
+                u8 = images_to_uint8(img.permute(0, 2, 1, 3, 4).reshape(Bv * Tv, Cv, Hv, Wv).contiguous()).reshape(Bv, Tv, Hv, Wv, Cv)
+            else:
+                u8 = images_to_uint8(img)
+            full = D.reorder_rank_major(D.all_gather_samples(u8, world), world, len(idx))
+            if rank == 0:
+                np.save(os.path.join(fid_dir, f"gen-{k // B:05d}.npy"), full.cpu().numpy())
         if rank == 0:
-            u8 = ((img + 1) / 2 * 255).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
-            np.save(os.path.join(out_dir, "fid_samples.npy"), u8)
-            print(f"wrote {total} samples")
+            print(f"wrote {total} samples to {fid_dir}")
     else:
         raise SystemExit("data.mode must be gen or eval (training is out of scope)")
+
+
+def load_weights(pipe, args, dc, tag):
+    """The reference's three start modes (tools/ldm/image.py:70-88): resume / pretrained -> ldm-last.pt, otherwise the
+    stage-1 model-last.pt; without any checkpoint on disk, named-seed synthetic weights.  A checkpoint fixes the length of
+    the noise schedule it was trained with: when the YAML's `timesteps` differs (e.g. the 250-step benchmark config), the
+    checkpoint's T is used and `sampling_timesteps` is kept, so DDPM.sample takes the DDIM path as the reference would."""
+    from ddmi_amd import checkpoint as CK
+    from ddmi_amd.ddpm import DDPM
+    path = CK.find_checkpoint(dc.save_pth, resume=bool(getattr(args, "resume", False)), pretrained=bool(args.pretrained))
+    if path is None:
+        print(f"no checkpoint under {dc.save_pth}: using named-seed synthetic weights")
+        pipe.load_named_seed(tag)
+        return
+    print("Loading Pretrained Models!" if path.endswith("ldm-last.pt") else "Load VAE checkpoints!")
+    T_ck = CK.checkpoint_sampler_config(CK.read_checkpoint(path))
+    if T_ck and T_ck["timesteps"] != pipe.ddpm.num_timesteps:
+        cfg = dict(args.ddpmconfig)
+        print(f"checkpoint schedule has T={T_ck['timesteps']} (config: {cfg.get('timesteps')}): sampling "
+              f"{cfg.get('sampling_timesteps')} steps over the checkpoint's schedule")
+        cfg["timesteps"] = T_ck["timesteps"]
+        if cfg.get("sampling_timesteps") is None or cfg["sampling_timesteps"] > cfg["timesteps"]:
+            cfg["sampling_timesteps"] = cfg["timesteps"]
+        if args.domain == "video":
+            cfg["domain"] = "video"
+        else:
+            cfg.pop("domain", None)
+        pipe.ddpm = DDPM(model=pipe.unet, **cfg)
+    if path.endswith("model-last.pt"):
+        print("stage-1 checkpoint: the diffusion model keeps its initialisation (named-seed weights)")
+        pipe.load_named_seed(tag)
+    pipe.load_checkpoint(path)
 
 
 def generator_settings(dc):
@@ -105,13 +148,7 @@ def occupancy_main(args, dc, B, rank, world, dev):
     from ddmi_amd.pipeline import OccupancyPipeline
     pipe = OccupancyPipeline(args.unetconfig, args.ddconfig, args.mlpconfig, args.ddpmconfig, args.embed_dim,
                              numerics=args.numerics, max_batch=B, device=dev, **generator_settings(dc))
-    ckpt = os.path.join(dc.save_pth, "ldm-last.pt")
-    if os.path.exists(ckpt):
-        print("Loading Pretrained Models!")
-        pipe.load_checkpoint(ckpt)
-    else:
-        print(f"{ckpt} not found: using named-seed synthetic weights")
-        pipe.load_named_seed("shapenet")
+    load_weights(pipe, args, dc, "shapenet")
     pipe.finalize()
     out_dir = os.path.join(dc.save_pth, "results" if args.mode == "gen" else os.path.join("results", "eval"))
     os.makedirs(out_dir, exist_ok=True)
@@ -121,7 +158,7 @@ def occupancy_main(args, dc, B, rank, world, dev):
     print("Generating shape!" if args.mode == "gen" else f"Generating {total} shapes for evaluation!")
     for start in range(rank * B, total, world * B):       # disjoint global sample indices per rank
         idx = list(range(start, start + B))
-        for i, mesh in zip(idx, pipe.generate(idx, base_seed=args.seed)):
+        for i, mesh in zip(idx, pipe.generate(idx, base_seed=args.seed, rng=args.rng, reseed=(start == rank * B))):
             mesh.export(os.path.join(out_dir, f"generation-{i}.obj"))
     print("Finished generating shapes!")
 
@@ -132,4 +169,7 @@ if __name__ == "__main__":
     parser.add_argument("--configs", type=str)
     parser.add_argument("--seed", type=int, default=777)
     parser.add_argument("--numerics", type=str, default="bf16", choices=["bf16", "fp32"])
+    parser.add_argument("--rng", type=str, default="philox", choices=["philox", "reference"],
+                        help="philox: per-sample counter-based streams (sharding-invariant); reference: torch.manual_seed(--seed) "
+                             "and CPU randn in the reference's draw order (same samples as the reference's CPU path)")
     main(parser.parse_args())

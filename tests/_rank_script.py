@@ -17,6 +17,19 @@ full = D.all_gather_samples(local, world)
 rec = {"rank": rank, "world": world, "ranks": D.group_size(dev), "rows": full[:, 0].tolist(),
        "backend": torch.distributed.get_backend() if world > 1 else None,
        "max": D.max_over_ranks(float(rank), dev)}
+
+
+def fake_finalize():
+    """What a finalize does with DDMI_TUNE_FILE (net.hip): reads the plan file if it exists, else tunes and writes it."""
+    p = os.environ.get("DDMI_TUNE_FILE")
+    if p and not os.path.exists(p):
+        with open(p, "w") as f:
+            f.write(f"v 2\nplans tuned by rank {rank}\n")
+    rec["finalized_from"] = open(p).read() if p else None
+
+
+os.environ.pop("DDMI_TUNE_FILE", None)
+D.finalize_with_shared_plans(fake_finalize, rank, world)
 with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
     json.dump(rec, f)
 D.barrier()

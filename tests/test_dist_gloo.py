@@ -63,6 +63,8 @@ def test_self_launch_starts_the_ranks(tmp_path):
         with open(os.path.join(tmp_path, f"rank{rank}.json")) as f:
             rec = json.load(f)
         assert rec["world"] == 2 and rec["ranks"] == 2 and rec["rows"] == [0.0, 0.0, 1.0, 1.0] and rec["max"] == 1.0
+        # one set of convolution plans for the whole job: every rank finalizes from rank 0's file
+        assert rec["finalized_from"] == "v 2\nplans tuned by rank 0\n"
     # a failing rank is the launcher's failure
     assert D.launch_ranks(2, os.path.join(ROOT, "tests", "_rank_script.py"), [os.path.join(str(tmp_path), "missing")]) != 0
 

@@ -177,3 +177,71 @@ def test_occupancy_decoder_and_mlp3d(golden):
     assert rel_err(grid, o1["grid6"]) < 2e-7
     one = tuple([pl[:1] for pl in lst] for lst in ref_planes)
     assert rel_err(O.mlp3d(state(golden, "O1.mlp3d"), grid[None], one)[0], o1["grid6_logits"]) < TOL
+
+
+# ---------------- G2 (BASELINE config 1) and G3 (same-seed draw order), captured by oracle/gen_golden_g2.py -------------
+def reference_draw_order(seed, shape, T, S, R, inject=True):
+    """The reference's draws from torch's global CPU generator inside one generate(): x_T (ddpm.py:288/343),
+    one randn per step (ddpm.py:278; :363 on every non-final DDIM step), then the 12 NoiseInjection normal_() draws
+    [B,1,R,R] (blocks.py:293-295)."""
+    torch.manual_seed(seed)
+    x_T = torch.randn(shape)
+    steps = [torch.randn(shape) for _ in range(S - 1 if S < T else T)]
+    inj = torch.stack([torch.empty(shape[0], 1, R, R).normal_() for _ in range(12)]).reshape(12, shape[0], R * R) if inject else None
+    return x_T, steps, inj
+
+
+@pytest.fixture(scope="module")
+def afhq_states():
+    from helpers import AFHQ_DD, AFHQ_UNET
+    from ddmi_amd.autoencoder import decoder_manifest
+    from ddmi_amd.mlp import mlp_manifest
+    from ddmi_amd.unet import unet_manifest
+    st = lambda tag, man: O.to_state(iw.fill_state(tag, [(k, tuple(s)) for k, s in man]))
+    return (st("afhq.unet", unet_manifest(**AFHQ_UNET)), st("afhq.vae", decoder_manifest(AFHQ_DD, 64)), st("afhq.mlp", mlp_manifest()))
+
+
+@pytest.mark.parametrize("name,T,S,eta", [("ddim", 1000, 10, 0.0), ("anc", 10, 10, 1.0)])
+def test_config1_generate_g2(golden, afhq_states, name, T, S, eta):
+    """BASELINE config 1: AFHQ full-width nets, latent [1,64,16,16], 10 steps, R=64 (si=4), torch.manual_seed(777)."""
+    from helpers import AFHQ_DD, AFHQ_UNET
+    g2 = golden.npz("G2_config1.npz")
+    shape = (1, 64, 16, 16)
+    x_T, steps, _ = reference_draw_order(int(g2["seed"]), shape, T, S, 64, inject=False)
+    assert np.array_equal(x_T.numpy(), g2["x_T"])          # torch's seeded CPU stream is what the fixture was drawn from
+    logit = torch.from_numpy(iw.fill_state("afhq.ddpm", [("mixing_logit", (1, 64, 1, 1))])["mixing_logit"])
+    with torch.no_grad():
+        ref = O.generate(afhq_states[0], AFHQ_UNET, afhq_states[1], AFHQ_DD, afhq_states[2], O.make_schedule(T), logit, x_T,
+                         steps, T, S, eta, 64)
+    assert rel_err(ref["z"], g2[f"{name}.z"]) < 1e-4
+    for i, pl in enumerate(ref["planes"]):
+        a = pl.numpy()
+        assert list(a.shape) == list(g2[f"{name}.plane{i}.shape"])
+        assert rel_err(a[0, :4, :16, :16], g2[f"{name}.plane{i}.slice"]) < 1e-4
+        assert abs(a.astype(np.float64).sum() - float(g2[f"{name}.plane{i}.sum"])) < 1e-4 * float(g2[f"{name}.plane{i}.abssum"])
+    assert rel_err(ref["img"], g2[f"{name}.img"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,T,S,eta", [("ddim_eta0", 1000, 10, 0.0), ("ddim_eta1", 1000, 10, 1.0), ("anc", 10, 10, 1.0)])
+def test_same_seed_draw_order_g3(golden, name, T, S, eta):
+    """The reference's generate() under torch.manual_seed(777) with NOTHING patched and non-zero NoiseInjection weights:
+    pins the draw order x_T -> per-step -> 12 injections (a24)."""
+    g3 = golden.npz("G3_same_seed.npz")
+    cfgs = golden.json("configs.json")
+    shape = (2, 64, 8, 8)
+    x_T, steps, inj = reference_draw_order(int(g3["seed"]), shape, T, S, 32)
+    man = golden.json("manifests.json")["M1n.mlp"]
+    mst = iw.fill_state("M1n.mlp", [(k, tuple(v)) for k, v in man.items()])
+    for k in mst:
+        if k.endswith("noise.weight"):
+            mst[k] = iw.normal("M1n.mlp", k, mst[k].shape, 0.0, 0.1)
+    logit = torch.from_numpy(iw.fill_state("G1.ddpm", [("mixing_logit", (1, 64, 1, 1))])["mixing_logit"])
+    unet_p = state(golden, "U2a.unet")
+    z = O.sample_chain(lambda x, t: O.unet_forward(unet_p, cfgs["TOY_UNET"], x, t), O.make_schedule(T), x_T, steps, T, S, eta, logit)
+    assert rel_err(z, g3[f"{name}.z"]) < 1e-4
+    planes = O.vae_decode(state(golden, "D1.vae"), cfgs["TOY_DD"], z)
+    raw = O.image_mlp(O.to_state(mst), O.generate_coords(32), planes, O.scale_injection(32), noise=inj)
+    assert rel_err(raw, g3[f"{name}.raw"]) < 1e-4
+    assert rel_err(raw.clamp(-1, 1), g3[f"{name}.img"]) < 1e-4
+    wrong = O.image_mlp(O.to_state(mst), O.generate_coords(32), planes, O.scale_injection(32), noise=inj.flip(0))
+    assert rel_err(wrong, g3[f"{name}.raw"]) > 1e-3     # the ORDER of the 12 draws is pinned, not just their presence
