@@ -1,22 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: samples/sec at 256x256, 250-step DDPM + INR decode (BASELINE.json), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload afhq|shapenet|sky]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the hot path over one batch: x_T -> 250 x (UNet + fused DDPM update, ancestral
-p_sample_loop with timesteps=250) -> D2C-VAE decode -> fused plane sampling + coordinate MLP -> clamp, for B samples
-per GPU on random-init (named-seed) AFHQ-architecture weights, bf16 operands / fp32 accumulate, inputs and noise
-generated on the device.  With N GPUs every rank runs independent chains (weak scaling) and the finished images are
-all-gathered over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (child processes,
+ddmi_amd.dist.launch_ranks) - the command form is the same for 1 and 8 GPUs.
+
+A *step* is one pass of the hot path over one batch.  Default workload `afhq` (BASELINE config 2/3): x_T -> 250 x (UNet +
+fused DDPM update, ancestral p_sample_loop with timesteps=250) -> D2C-VAE decode -> fused plane sampling + coordinate
+MLP -> clamp, for B samples per GPU on random-init (named-seed) AFHQ-architecture weights, bf16 operands / fp32
+accumulate, inputs and noise generated on the device.  With N GPUs every rank runs independent chains (weak scaling) and
+the finished images are all-gathered over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+`--workload shapenet` (config 4: 250-step chains on the [192,16,16] tri-plane latent -> Autoencoder3D.decode -> MLP3D on the
+128^3 query grid in one launch -> marching cubes on the device; shapes/sec) and `--workload sky` (config 5: 250-step
+chains on the [64,2048] video latent -> VideoDecoder_light -> MLPVideo over 16x256x256; clips/sec) time the other two
+domains the same way.
 
 Besides the contract fields the line carries
-  roofline     - the dominant kernel (the MFMA implicit-GEMM convolution) timed live with HIP events on its launch
-                 stream during the timed region (every 25th UNet forward), algorithmic FLOPs / time vs 2.5 PFLOP/s
+  roofline     - the dominant kernel timed live with HIP events on its launch stream during the timed region (every 25th
+                 UNet forward), algorithmic FLOPs / time vs 2.5 PFLOP/s; for shapenet the MLP3D launch, for sky the
+                 dominant kernel of the step
   cpu_baseline - the CPU oracle (`oracle/ddmi_oracle.py`, a port of the reference's PyTorch-CPU path) timed on this
-                 box's host cores on a bounded sample: ONE full-size UNet evaluation at B=1 (1 of the 250 that make up
-                 98.8 % of a sample's work), extrapolated to samples/sec.
+                 box's host cores, rank 0 at N = 1 only: SURVEY 8(d) - 3 full-size UNet evaluations + 1 decode + 1 MLP at
+                 B = 1, reported as 1 / (250 t_unet + t_dec + t_mlp) (extrapolated, labelled so), plus BASELINE config 1
+                 (10-step chain on a 16x16 latent + decode + MLP at 64x64) timed in full
+  parity_check - after the timed region: (a) the chain of the LAST sample of the last timed batch re-run alone at B = 1 and
+                 compared with its row of the batch; (b) a full-size 250-step chain at B = 2 run in bf16 AND in fp32 parity
+                 mode from the same Philox seeds: latent relative error and image PSNR - what 250 sequential bf16 steps
+                 do to a sample
+  ddim_1000_250 - the same batch generated with the reference's other 250-NFE sampler (timesteps=1000, S=250, eta=1)
+  nccl_ranks   - size of the group that completed the all-gather
 """
 import argparse
 import json
@@ -39,35 +54,66 @@ NFE = 250
 PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(threads=None):
-    """Times the oracle's UNet on the host (kind 'port'): one evaluation at B=1, full AFHQ size."""
-    import torch
-    from ddmi_amd import initweights as iw
-    from ddmi_amd.unet import unet_manifest
-    from oracle import ddmi_oracle as O
+def host_cores():
     # physical cores: SMT siblings only oversubscribe the fp32 GEMMs (measured: 256 threads are 3x slower than 128
     # on the 2 x 64-core host of the GPU box)
-    cores = threads or max(1, (os.cpu_count() or 2) // 2)
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline_afhq(threads=None):
+    """the oracle (kind 'port') on the host - 3 UNet evaluations + 1 decode + 1 MLP at B = 1, full AFHQ size,
+    extrapolated to a 250-step sample; and BASELINE config 1 (10-step chain on a 16x16 latent, R = 64) timed in full."""
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.autoencoder import decoder_manifest
+    from ddmi_amd.mlp import mlp_manifest
+    from ddmi_amd.unet import unet_manifest
+    from oracle import ddmi_oracle as O
+    cores = threads or host_cores()
     torch.set_num_threads(cores)
-    cfg = AFHQ["unetconfig"]
-    st = O.to_state(iw.fill_state("afhq.unet", unet_manifest(**cfg)))
+    cfg, dd = AFHQ["unetconfig"], AFHQ["ddconfig"]
+    ust = O.to_state(iw.fill_state("afhq.unet", unet_manifest(**cfg)))
+    vst = O.to_state(iw.fill_state("afhq.vae", decoder_manifest(dd, AFHQ["embed_dim"])))
+    mst = O.to_state(iw.fill_state("afhq.mlp", mlp_manifest()))
     x = torch.from_numpy(iw.normal("bench", "x", (1, 64, 64, 64)))
-    t = torch.tensor([125], dtype=torch.long)
     with torch.no_grad():
+        ts = []
+        for t in (249, 125, 0):
+            t0 = time.perf_counter()
+            O.unet_forward(ust, cfg, x, torch.tensor([t], dtype=torch.long))
+            ts.append(time.perf_counter() - t0)
+        t_unet = sum(ts) / len(ts)
         t0 = time.perf_counter()
-        O.unet_forward(st, cfg, x, t)
-        dt = time.perf_counter() - t0
-    return {"value": 1.0 / (NFE * dt), "unit": "samples/sec", "cores": cores, "kind": "port",
-            "sample": f"1 of {NFE} UNet evaluations at B=1, 64x64x64 latent ({dt:.2f} s), x{NFE}; decode+MLP (1.2 % of the work) not included",
-            "unet_eval_s": dt}
+        planes = O.vae_decode(vst, dd, x)
+        t_dec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.image_mlp(mst, O.generate_coords(256), planes, 1.0)
+        t_mlp = time.perf_counter() - t0
+        # config 1 in full: 10-step DDIM (T=1000, eta=0) on [1,64,16,16], decode, MLP at R=64 (si=4)
+        torch.manual_seed(777)
+        shape = (1, 64, 16, 16)
+        xT = torch.randn(shape)
+        draws = [torch.randn(shape) for _ in range(9)]
+        logit = torch.from_numpy(iw.fill_state("afhq.ddpm", [("mixing_logit", (1, 64, 1, 1))])["mixing_logit"])
+        t0 = time.perf_counter()
+        O.generate(ust, cfg, vst, dd, mst, O.make_schedule(1000), logit, xT, draws, 1000, 10, 0.0, 64)
+        t_c1 = time.perf_counter() - t0
+    total = NFE * t_unet + t_dec + t_mlp
+    return {"value": 1.0 / total, "unit": "samples/sec", "cores": cores, "kind": "port",
+            "sample": f"3 UNet evaluations at B=1 on the 64x64x64 latent (mean {t_unet:.2f} s) + 1 decode ({t_dec:.2f} s) + 1 MLP at 256x256 "
+                      f"({t_mlp:.2f} s); value = 1 / ({NFE} t_unet + t_dec + t_mlp), extrapolated",
+            "unet_eval_s": t_unet, "decode_s": t_dec, "mlp_s": t_mlp,
+            "config1_full": {"seconds": t_c1, "samples_per_sec": 1.0 / t_c1,
+                             "what": "BASELINE config 1 in full: 10-step DDIM on [1,64,16,16] + decode + MLP at 64x64, 1 sample"}}
 
 
 def pmc_traffic(live_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied)."""
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied).
+    The newest file wins; a kernel that is not in it reports null rather than a stale number."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))   # r1_..., r2_...: the newest round wins
     if not files or not live_name:
         return None
     m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)>", live_name)
@@ -80,7 +126,7 @@ def pmc_traffic(live_name):
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
-        return None
+        pat = re.compile(re.escape(live_name.split("<")[0]))
     with open(files[-1]) as f:
         table = json.load(f)["kernels"]
     for name, v in table.items():
@@ -89,42 +135,44 @@ def pmc_traffic(live_name):
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="samples per GPU per step")
-    ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seed", type=int, default=777)
-    ap.add_argument("--rng", default="philox", choices=["philox", "torch"],
-                    help="per-chain noise: in-kernel Philox streams (default) or one torch generator per chain")
-    args = ap.parse_args()
+def roofline_of(prof, pick):
+    """`pick(prof) -> kernel key`; achieved = algorithmic FLOPs of the timed launches / their HIP-event time."""
+    dom = pick(prof)
+    if not dom:
+        return None
+    d = prof[dom]
+    ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
+            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_timed": d["launches"],
+            "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
+            "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no
-        # HIP call), the ranks are CHILD processes (never an exec of this one) and their status is ours.
-        from ddmi_amd.dist import launch_ranks
-        sys.exit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
+def psnr(a, b, peak=2.0):
+    import torch
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * float(torch.log10(torch.tensor(peak * peak / mse)))
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+# ======================================================================================================================
+def run_afhq(args, rank, local_rank, world, dev):
     import torch
     from ddmi_amd import _lib
     from ddmi_amd import dist as D
+    from ddmi_amd.ddpm import DDPM
     from ddmi_amd.pipeline import ImagePipeline
-
-    rank, local_rank, world = D.init_process_group()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
-    B = args.batch
-
+    B = args.batch or 512
     ddpmconfig = dict(timesteps=args.nfe, image_size=64, channels=64, clip_denoised=False, mixed_prediction=True,
                       mixed_init=-6, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0)  # S == T -> p_sample_loop
     pipe = ImagePipeline(AFHQ["unetconfig"], AFHQ["ddconfig"], AFHQ["mlpconfig"], ddpmconfig, AFHQ["embed_dim"],
                          test_resolution=256, numerics="bf16", max_batch=B, device=dev)
-    pipe.load_named_seed("afhq").finalize()
+    pipe.load_named_seed("afhq")
+    plans = D.finalize_with_shared_plans(pipe.finalize, rank, world)   # one set of conv plans for every rank
 
     # primer (not a step): two denoiser calls + decode + MLP so lazy one-time setup is out of the timed region
     z0 = torch.randn((B, 64, 64, 64), device=dev)
@@ -132,18 +180,18 @@ def main():
     for _ in range(2):
         pipe.unet(z0, tt)
     pipe.mlp(pipe.coords(), hdbf=pipe.vae.decode(z0), si=1.0)
+    del z0
     torch.cuda.synchronize()
-
-    phase = {"sample": 0.0, "decode_mlp": 0.0, "gather": 0.0}
+    phase = {}
 
     def one_step(step_idx):
         idx = [(step_idx * world + rank) * B + j for j in range(B)]  # disjoint global sample indices
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        img = pipe.generate(idx, base_seed=args.seed, events=ev[1:3], rng=args.rng)
+        img, z = pipe.generate(idx, base_seed=args.seed, events=ev[1:3], rng=args.rng, return_latent=True)
         out = D.all_gather_samples(img, world)
         ev[3].record()
-        phase["_ev"] = ev
+        phase["ev"], phase["idx"], phase["img"], phase["z"] = ev, idx, img, z
         return out
 
     for w in range(args.warmup):
@@ -159,45 +207,342 @@ def main():
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
-    ev = phase.pop("_ev")
+    ev = phase["ev"]
     phase_ms = {"sampling_loop": ev[0].elapsed_time(ev[1]), "decode": ev[1].elapsed_time(ev[2]),
                 "mlp_clamp_gather": ev[2].elapsed_time(ev[3])}
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
     assert out is not None and out.shape == (world * B, 3, 256, 256) and bool(torch.isfinite(out).all())
+    nranks = D.group_size(dev)
+    extra = {}
+    # the fused MLP runs once per step; time it on its own (every launch) for its MFMA figure
+    _lib.profile_enable(1)
+    planes = pipe.vae.decode(phase["z"])
+    pipe.mlp(pipe.coords(), hdbf=planes, si=1.0)
+    torch.cuda.synchronize()
+    p1 = _lib.profile_collect()
+    _lib.profile_enable(0)
+    del planes
+    if "mlp2d_fused" in p1:
+        extra["mlp2d_roofline"] = roofline_of(p1, lambda p: "mlp2d_fused")
+    dec_ms = sum(v["total_ms"] for k, v in p1.items() if k != "mlp2d_fused")
+    dec_fl = sum(v.get("flops", 0.0) for k, v in p1.items() if k != "mlp2d_fused")
+    extra["decoder_kernels"] = {"ms_per_batch": round(dec_ms, 2), "tflops": round(dec_fl / (dec_ms * 1e-3) / 1e12, 1) if dec_ms else None}
 
+    if rank == 0 and not args.no_parity_check:
+        extra["parity_check"] = parity_check_afhq(args, pipe, phase, dev)
+    if not args.no_ddim:   # the reference's other 250-NFE sampler on the same nets: DDIM over T=1000, S=250, eta=1
+        ddim = DDPM(model=pipe.unet, timesteps=1000, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0, channels=64, image_size=64)
+        ddim.mixing_logit = pipe.ddpm.mixing_logit
+        keep, pipe.ddpm = pipe.ddpm, ddim
+        D.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        img = pipe.generate(phase["idx"], base_seed=args.seed, rng=args.rng)
+        D.all_gather_samples(img, world)
+        torch.cuda.synchronize()
+        dt = D.max_over_ranks(time.perf_counter() - t1, dev)
+        pipe.ddpm = keep
+        extra["ddim_1000_250"] = {"samples_per_sec": world * B / dt, "ms_per_step": 1e3 * dt,
+                                  "what": f"timesteps=1000, sampling_timesteps={args.nfe}, eta=1 (ddim_sample), one batch"}
+    if rank != 0:
+        return None
+    conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
+    tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
+    tot_fl = sum(v.get("flops", 0.0) for v in prof.values())
+    line = {
+        "metric": "samples/sec (whole node) at 256x256 image, 250-step DDPM + INR decode",
+        "value": args.steps * world * B / elapsed, "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"AFHQ 256x256, {args.nfe}-step DDPM (p_sample_loop, T={args.nfe}) + D2C-VAE decode + "
+                               "fused HDPE plane sampling/coordinate MLP, random-init named-seed weights",
+                   "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "latent": [64, 64, 64],
+                   "parallelism": f"sample-parallel x{world} (independent chains, all-gather of finished images)",
+                   "noise": {"philox": "per-chain Philox streams drawn in the sampler-step kernel",
+                             "torch": "one torch device generator per chain",
+                             "reference": "torch.manual_seed + CPU randn in the reference's draw order"}[args.rng],
+                   "conv_plans": "shared (rank 0's autotune broadcast)" if world > 1 else (plans or "autotuned at finalize")},
+        "nccl_ranks": nranks,
+        "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None),
+        "unet_step_mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
+        "last_step_phase_ms": {k: round(v, 2) for k, v in phase_ms.items()},
+        "unet_memory_bytes": pipe.unet.memory(),
+    }
+    line.update(extra)
+    if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N = 1 only
+        line["cpu_baseline"] = cpu_baseline_afhq()
+    return line
+
+
+def parity_check_afhq(args, pipe, phase, dev):
+    """(a) the LAST chain of the last timed batch alone at B = 1 vs its row; (b) bf16 vs fp32 over a full-size 250-step
+    chain at B = 2 from the same Philox seeds."""
+    import torch
+    from ddmi_amd.pipeline import ImagePipeline
+    out = {}
+    idx = phase["idx"]
+    row = len(idx) - 1
+    img1, z1 = pipe.generate([idx[row]], base_seed=args.seed, rng="philox", return_latent=True)
+    if args.rng == "philox":
+        out["b1_vs_batch_row"] = {"row": row, "global_index": idx[row], "latent_rel_err": relerr(z1[0], phase["z"][row]),
+                                  "image_rel_err": relerr(img1[0], phase["img"][row]), "image_psnr_db": psnr(img1[0], phase["img"][row]),
+                                  "what": f"sample {idx[row]} ({args.nfe} bf16 steps + decode + MLP) alone at B=1 (heuristic conv plans, "
+                                          "other tiles) vs row of the timed batch (tuned plans); same Philox stream"}
+    ddpmconfig = dict(timesteps=args.nfe, image_size=64, channels=64, clip_denoised=False, mixed_prediction=True,
+                      mixed_init=-6, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0)
+    p32 = ImagePipeline(AFHQ["unetconfig"], AFHQ["ddconfig"], AFHQ["mlpconfig"], ddpmconfig, AFHQ["embed_dim"],
+                        test_resolution=256, numerics="fp32", max_batch=2, device=dev)
+    p32.load_named_seed("afhq").finalize()
+    two = [idx[0], idx[row]]
+    t0 = time.perf_counter()
+    i32, z32 = p32.generate(two, base_seed=args.seed, rng="philox", return_latent=True)
+    torch.cuda.synchronize()
+    t32 = time.perf_counter() - t0
+    i16, z16 = pipe.generate(two, base_seed=args.seed, rng="philox", return_latent=True)
+    # single-step view of the same thing: one UNet evaluation of the fp32 chain's x_T in both modes
+    from ddmi_amd.ddpm import DDPM
+    from ddmi_amd.dist import sample_seed
+    seeds = torch.tensor([sample_seed(args.seed, i) for i in two], dtype=torch.int64, device=dev)
+    xT = DDPM.randn_from_seeds((2, 64, 64, 64), seeds, DDPM.X_T_TAG)
+    tt = torch.full((2,), args.nfe - 1, dtype=torch.int64, device=dev)
+    e32, e16 = p32.unet(xT, tt), pipe.unet(xT, tt)
+    out["bf16_vs_fp32_chain"] = {"batch": 2, "steps": args.nfe, "latent_rel_err": relerr(z16, z32), "image_rel_err": relerr(i16, i32),
+                                 "image_psnr_db": psnr(i16, i32), "single_unet_eval_rel_err": relerr(e16, e32),
+                                 "fp32_parity_mode_samples_per_sec": 2.0 / t32,
+                                 "what": "same Philox seeds; fp32 = DDMI_PARITY_FP32 (the mode the 1e-3 tests run in), bf16 = the timed mode; "
+                                         "random-init weights amplify differences step over step (no trained contraction)"}
+    del p32
+    torch.cuda.empty_cache()
+    return out
+
+
+# ======================================================================================================================
+def run_shapenet(args, rank, local_rank, world, dev):
+    """BASELINE config 4: ShapeNet occupancy - 250-step chains on the [192,16,16] latent, tri-plane decoder, MLP3D on the
+    dense 128^3 query grid (2 097 152 points, one launch), marching cubes on the device; configs/ldm/shapenet.yaml nets."""
+    import torch
+    from ddmi_amd import _lib
+    from ddmi_amd import dist as D
+    from ddmi_amd.config import load_ldm_args
+    from ddmi_amd.occupancy import occupancy_grid_logits
+    from ddmi_amd.pipeline import OccupancyPipeline
+    B = args.batch or 64
+    a = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "shapenet.yaml"))
+    ddpmconfig = dict(a.ddpmconfig, timesteps=args.nfe, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0)
+    pipe = OccupancyPipeline(a.unetconfig, a.ddconfig, a.mlpconfig, ddpmconfig, a.embed_dim, threshold=0.2, resolution0=128,
+                             numerics="bf16", max_batch=B, device=dev)
+    pipe.load_named_seed("shapenet")
+    D.finalize_with_shared_plans(pipe.finalize, rank, world)
+    stats = {}
+
+    def one_step(step_idx):
+        idx = [(step_idx * world + rank) * B + j for j in range(B)]
+        meshes = pipe.generate(idx, base_seed=args.seed)
+        stats["faces"] = sum(len(m.faces) for m in meshes)
+        stats["idx"] = idx
+        counts = torch.tensor([float(len(m.faces)) for m in meshes], device=dev)
+        return D.all_gather_samples(counts, world)   # the meshes stay where the .obj files are written; sizes are gathered
+
+    one_step(0) if args.warmup == 0 else None
+    for w in range(args.warmup):
+        one_step(w)
+    _lib.profile_enable(25)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = one_step(args.warmup + k)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    prof = _lib.profile_collect()
+    nranks = D.group_size(dev)
+    # MLP-only time of the dense 128^3 grid (SURVEY 8d asks for it): every launch timed
+    z = torch.randn((1, *pipe.latent_shape), device=dev)
+    planes = pipe.vae.decode(z)
+    occupancy_grid_logits(pipe.mlp, planes, 128)
+    _lib.profile_enable(1)
+    for _ in range(5):
+        occupancy_grid_logits(pipe.mlp, planes, 128)
+    torch.cuda.synchronize()
+    p1 = _lib.profile_collect()
+    _lib.profile_enable(0)
+    if rank != 0:
+        return None
+    roof = roofline_of(p1, lambda p: "mlp3d_fused" if "mlp3d_fused" in p else None)
+    tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
+    line = {"metric": "shapes/sec (whole node), ShapeNet occupancy: 250-step DDPM + tri-plane decode + 128^3 MLP3D grid + marching cubes",
+            "value": args.steps * world * B / elapsed, "unit": "shapes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"ShapeNet occupancy (configs/ldm/shapenet.yaml nets), {args.nfe}-step DDPM on [192,16,16], Autoencoder3D.decode, "
+                                   "MLP3D on the 1.1-scaled 128^3 grid in one launch, device marching cubes; random-init named-seed weights",
+                       "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "query_points": 128 ** 3,
+                       "parallelism": f"sample-parallel x{world}"},
+            "nccl_ranks": nranks, "roofline": roof,
+            "mlp3d_grid_ms": roof["avg_launch_us"] / 1e3 if roof else None,
+            "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
+            "faces_last_batch": stats.get("faces")}
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_shapenet(a, args.nfe)
+    return line
+
+
+def cpu_baseline_shapenet(a, nfe):
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.occupancy import decoder3d_manifest, mlp3d_manifest
+    from ddmi_amd.unet import unet_manifest
+    from oracle import ddmi_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ucfg = {k: v for k, v in dict(a.unetconfig).items() if k not in ("size1", "size2", "size3")}
+    ust = O.to_state(iw.fill_state("shapenet.unet", unet_manifest(**ucfg)))
+    vst = O.to_state(iw.fill_state("shapenet.vae", decoder3d_manifest(dict(a.ddconfig), a.embed_dim)))
+    mst = O.to_state(iw.fill_state("shapenet.mlp", mlp3d_manifest()))
+    z = torch.from_numpy(iw.normal("bench", "z3", (1, 192, 16, 16)))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for t in (249, 125, 0):
+            O.unet_forward(ust, ucfg, z, torch.tensor([t], dtype=torch.long))
+        t_unet = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        planes = O.vae3d_decode(vst, dict(a.ddconfig), a.embed_dim, z)
+        t_dec = time.perf_counter() - t0
+        pts = O.occupancy_query_points(128)[:200000][None]        # 200 000 of the 2 097 152 grid points (two reference chunks)
+        t0 = time.perf_counter()
+        O.mlp3d(mst, pts, planes)
+        t_mlp = (time.perf_counter() - t0) * (128 ** 3 / 200000.0)
+    total = nfe * t_unet + t_dec + t_mlp
+    return {"value": 1.0 / total, "unit": "shapes/sec", "cores": cores, "kind": "port",
+            "sample": f"3 UNet evaluations at B=1 ({t_unet:.2f} s each) + 1 tri-plane decode ({t_dec:.2f} s) + MLP3D on 200 000 of the 128^3 "
+                      f"points (x10.49 -> {t_mlp:.1f} s); value = 1 / ({nfe} t_unet + t_dec + t_mlp), extrapolated; marching cubes not included",
+            "unet_eval_s": t_unet, "decode_s": t_dec, "mlp3d_grid_s": t_mlp}
+
+
+# ======================================================================================================================
+def run_sky(args, rank, local_rank, world, dev):
+    """BASELINE config 5: SkyTimelapse video 16 x 256^2 - 250-step chains on the [64,2048] tri-plane token latent,
+    VideoDecoder_light, MLPVideo over 16x256x256 points; configs/ldm/skytimelapse.yaml nets."""
+    import torch
+    from ddmi_amd import _lib
+    from ddmi_amd import dist as D
+    from ddmi_amd.config import load_ldm_args
+    from ddmi_amd.pipeline import VideoPipeline
+    B = args.batch or 16
+    a = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "skytimelapse.yaml"))
+    ddpmconfig = dict(a.ddpmconfig, timesteps=args.nfe, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0)
+    pipe = VideoPipeline(a.unetconfig, a.ddconfig, a.mlpconfig, ddpmconfig, a.embed_dim, frames=int(a.data_config.get("frames", 16)),
+                         test_resolution=256, numerics="bf16", max_batch=B, device=dev)
+    pipe.vae.max_batch = 1   # the 73 728-token attention buffers are per sample
+    pipe.load_named_seed("sky")
+    D.finalize_with_shared_plans(pipe.finalize, rank, world)
+
+    def one_step(step_idx):
+        idx = [(step_idx * world + rank) * B + j for j in range(B)]
+        vid = pipe.generate(idx, base_seed=args.seed)
+        return D.all_gather_samples(vid, world)
+
+    if args.warmup == 0:
+        pipe.generate([0], base_seed=args.seed)   # lazy one-time setup out of the timed region
+    for w in range(args.warmup):
+        one_step(w)
+    _lib.profile_enable(25)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for k in range(args.steps):
+        out = one_step(args.warmup + k)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    prof = _lib.profile_collect()
+    _lib.profile_enable(0)
+    assert out.shape == (world * B, 3, 16, 256, 256) and bool(torch.isfinite(out).all())
+    nranks = D.group_size(dev)
+    # decode + MLPVideo of one clip, every launch timed
+    z = torch.randn((1, a.embed_dim, pipe.unet.seq_len), device=dev)
+    _lib.profile_enable(1)
+    pipe.mlp(pipe.coords(), pipe.vae.decode(z))
+    torch.cuda.synchronize()
+    p1 = _lib.profile_collect()
+    _lib.profile_enable(0)
+    if rank != 0:
+        return None
+    tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
+    dom = lambda p: max((k for k in p if p[k].get("flops")), key=lambda k: p[k]["total_ms"], default=None)
+    line = {"metric": "clips/sec (whole node), SkyTimelapse video 16x256x256: 250-step DDPM + spatiotemporal HDPE decode",
+            "value": args.steps * world * B / elapsed, "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"SkyTimelapse (configs/ldm/skytimelapse.yaml nets), {args.nfe}-step DDPM on the [64,2048] tri-plane token latent, "
+                                   "VITAutoencoder.decode (VideoDecoder_light), MLPVideo over 16x256x256; random-init named-seed weights",
+                       "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "parallelism": f"sample-parallel x{world}"},
+            "nccl_ranks": nranks, "roofline": roofline_of(prof, dom),
+            "decode_mlp_one_clip": {"roofline": roofline_of(p1, dom), "kernel_ms": round(sum(v["total_ms"] for v in p1.values()), 2),
+                                    "mlpv_ms": round(p1["mlpv_fused"]["total_ms"], 3) if "mlpv_fused" in p1 else None},
+            "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}}
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_sky(a, args.nfe)
+    return line
+
+
+def cpu_baseline_sky(a, nfe):
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.video import UNetModel_Triplane
+    from oracle import ddmi_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    man = UNetModel_Triplane(**dict(a.unetconfig), numerics="bf16", max_batch=1).manifest()
+    ust = O.to_state(iw.fill_state("sky.unet3", man))
+    x = torch.from_numpy(iw.normal("bench", "zv", (1, 64, 2048)))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for t in (249, 0):
+            O.unet_triplane_forward(ust, dict(a.unetconfig), x, torch.tensor([t], dtype=torch.long))
+        t_unet = (time.perf_counter() - t0) / 2
+    return {"value": 1.0 / (nfe * t_unet), "unit": "clips/sec", "cores": cores, "kind": "port",
+            "sample": f"2 tri-plane UNet evaluations at B=1 ({t_unet:.2f} s each), x{nfe}; the video decoder (13.75 TFLOP, 96.7 % one 73 728-token "
+                      "attention whose score matrix a CPU cannot hold in one piece) and MLPVideo are NOT included: an upper bound",
+            "unet_eval_s": t_unet}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky"])
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 64, sky 16)")
+    ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--seed", type=int, default=777)
+    ap.add_argument("--rng", default="philox", choices=["philox", "torch", "reference"],
+                    help="per-chain noise: in-kernel Philox streams (default), one torch generator per chain, or the reference's seeded CPU draws")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no
+        # HIP call), the ranks are CHILD processes (never an exec of this one) and their status is ours.
+        from ddmi_amd.dist import launch_ranks
+        sys.exit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
+    import torch
+    from ddmi_amd import dist as D
+
+    rank, local_rank, world = D.init_process_group()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    line = {"afhq": run_afhq, "shapenet": run_shapenet, "sky": run_sky}[args.workload](args, rank, local_rank, world, dev)
     if rank == 0:
-        total_samples = args.steps * world * B
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
-        dom = max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None
-        roof = None
-        if dom:
-            d = conv[dom]
-            ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
-                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_timed": d["launches"],
-                    "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
-                    "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
-        tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
-        breakdown = {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
-        line = {
-            "metric": "samples/sec (whole node) at 256x256 image, 250-step DDPM + INR decode",
-            "value": total_samples / elapsed, "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"AFHQ 256x256, {args.nfe}-step DDPM (p_sample_loop, T={args.nfe}) + D2C-VAE decode + "
-                                   "fused HDPE plane sampling/coordinate MLP, random-init named-seed weights",
-                       "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "latent": [64, 64, 64],
-                       "parallelism": f"sample-parallel x{world} (independent chains, all-gather of finished images)",
-                       "noise": "per-chain Philox streams drawn in the sampler-step kernel" if args.rng == "philox"
-                                else "one torch device generator per chain"},
-            "roofline": roof, "kernel_time_share": breakdown,
-            "last_step_phase_ms": {k: round(v, 2) for k, v in phase_ms.items()},
-            "unet_memory_bytes": pipe.unet.memory(),
-        }
-        if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -24,7 +24,8 @@ def env_rank_world() -> Tuple[int, int, int]:
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialises torch.distributed from the torchrun environment (no-op for a single process)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # DDMI_FORCE_GROUP=1: also form the (one-rank) group for WORLD_SIZE=1 - lets a 1-GPU box exercise the RCCL calls
+    if (world > 1 or os.environ.get("DDMI_FORCE_GROUP") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -108,7 +109,7 @@ def barrier() -> None:
 
 def all_gather_samples(local: torch.Tensor, world: int) -> torch.Tensor:
     """[B_local, ...] on every rank -> [world * B_local, ...] in rank-major order (one all-gather per batch)."""
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return local
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())

@@ -15,7 +15,7 @@ dev = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
 local = torch.full((2, 3), float(rank), device=dev)
 full = D.all_gather_samples(local, world)
 rec = {"rank": rank, "world": world, "ranks": D.group_size(dev), "rows": full[:, 0].tolist(),
-       "backend": torch.distributed.get_backend() if world > 1 else None,
+       "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
        "max": D.max_over_ranks(float(rank), dev)}
 
 
@@ -33,5 +33,5 @@ D.finalize_with_shared_plans(fake_finalize, rank, world)
 with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
     json.dump(rec, f)
 D.barrier()
-if world > 1:
+if torch.distributed.is_initialized():
     torch.distributed.destroy_process_group()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs named stages on the GPU box, each under its own timeout, logging to gpurun_out/<tag>_<stage>.log.
+# usage: tools/gpu_stage.sh <tag> stage1 stage2 ...   (stages: see the case below)
+tag=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for st in "$@"; do
+  log=gpurun_out/${tag}_${st}.log
+  case $st in
+    mlptests)  timeout 900 python -m pytest tests/test_gpu_networks.py tests/test_gpu_round2.py -q -k "mlp or pipeline or generate_chain or arbitrary or same_seed or noise" > $log 2>&1 ;;
+    alltests)  timeout 2400 python -m pytest tests -m gpu -q > $log 2>&1 ;;
+    newtests)  timeout 1800 python -m pytest tests/test_gpu_round2.py -q > $log 2>&1 ;;
+    smoke)     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $log 2>&1 ;;
+    mlpbench)  (DDMI_MLP2D_PW=2 timeout 300 python tools/bench_mlp.py; DDMI_MLP2D_PW=1 timeout 300 python tools/bench_mlp.py --which 2d) > $log 2>&1 ;;
+    bench)     timeout 1500 python bench.py --steps 1 --warmup 1 > gpurun_out/${tag}_bench.json 2> $log ;;
+    benchfast) timeout 900 python bench.py --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchfast.json 2> $log ;;
+    benchshape) timeout 900 python bench.py --workload shapenet --steps 1 --warmup 1 > gpurun_out/${tag}_bench_shapenet.json 2> $log ;;
+    benchsky)  timeout 1200 python bench.py --workload sky --steps 1 --warmup 0 > gpurun_out/${tag}_bench_sky.json 2> $log ;;
+    *) echo "unknown stage $st" ;;
+  esac
+  echo "== $st rc=$? =="; tail -n 6 $log
+done
