@@ -64,6 +64,7 @@ struct MlpK {
   float* rgb;
   int B, N;
   int64_t total;  // B*N
+  unsigned long long* ts;   // diagnostics (DDMI_MLP2D_TS): per-workgroup phase timestamps, 64 slots per workgroup
 };
 
 // NoiseInjection term of StyledConv `conv_idx` for global point gp (0 when the launch carries no noise source)
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) mlp2d_kernel(Ml
 // =====================================================================================================================
 #define MV2_P 128
 #define MV2_XP 272
-#define MV2_FP 72
+#define MV2_FP 80   // 160-byte rows: (row * 40 + 4 lg) mod 64 is conflict-free for the b128 lane groups (72 was not)
 
 // element offset of the 1 KiB fragment block (16-row group g, k-step ks) of matrix i; lane l adds 8 l
 __device__ __forceinline__ int mv2_wfrag(int i_off, int KS, int g, int ks) { return i_off + ((g * KS + ks) << 9); }
@@ -400,23 +401,39 @@ template <int NT> struct Mv2Gather {   // one plane's texels in flight: P*8 (poi
   bf16x8 t[ITEMS][4];
   float w[ITEMS][4];
 };
+template <int NT> struct Mv2Points {   // decoded once per workgroup: the three planes are sampled at the same coordinates
+  static constexpr int ITEMS = MV2_P * 8 / NT;
+  float gx[ITEMS], gy[ITEMS];
+  int b[ITEMS];          // sample index, -1 for rows past the end
+};
 
 template <int NT>
-__device__ __forceinline__ void mv2_gather_issue(const MlpK& a, int pl, int64_t tile0, Mv2Gather<NT>& g) {
+__device__ __forceinline__ void mv2_points(const MlpK& a, int64_t tile0, Mv2Points<NT>& q) {
+#pragma unroll
+  for (int j = 0; j < Mv2Points<NT>::ITEMS; ++j) {
+    const int pi = (threadIdx.x + j * NT) >> 3;
+    int64_t gp = tile0 + pi;
+    const bool live = gp < a.total;
+    if (!live) gp = a.total - 1;  // a valid address; the weights are zeroed
+    const int b = (int)(gp / a.N);
+    const int p = (int)(gp - (int64_t)b * a.N);
+    const float2 c = *reinterpret_cast<const float2*>(a.coords + 2 * p);
+    q.gx[j] = c.x; q.gy[j] = c.y;
+    q.b[j] = live ? b : -1 - b;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void mv2_gather_issue(const MlpK& a, int pl, const Mv2Points<NT>& q, Mv2Gather<NT>& g) {
   const int S = a.hw[pl];
   const bf16_t* plane = (const bf16_t*)a.planes[pl];
 #pragma unroll
   for (int j = 0; j < Mv2Gather<NT>::ITEMS; ++j) {
-    const int it = threadIdx.x + j * NT;
-    const int pi = it >> 3, cg = it & 7;
-    int64_t gp = tile0 + pi;
-    const bool live = gp < a.total;
-    if (!live) gp = a.total - 1;  // a valid address; the weights below are zeroed
-    const int b = (int)(gp / a.N);
-    const int p = (int)(gp - (int64_t)b * a.N);
-    const float gx = a.coords[2 * p], gy = a.coords[2 * p + 1];
+    const int cg = (threadIdx.x + j * NT) & 7;
+    const bool live = q.b[j] >= 0;
+    const int b = live ? q.b[j] : -1 - q.b[j];
     // F.grid_sample: unnormalise (align_corners=False), clip to border, bilinear corners
-    float ix = ((gx + 1.f) * S - 1.f) * 0.5f, iy = ((gy + 1.f) * S - 1.f) * 0.5f;
+    float ix = ((q.gx[j] + 1.f) * S - 1.f) * 0.5f, iy = ((q.gy[j] + 1.f) * S - 1.f) * 0.5f;
     ix = fminf(fmaxf(ix, 0.f), (float)(S - 1));
     iy = fminf(fmaxf(iy, 0.f), (float)(S - 1));
     const float x0f = floorf(ix), y0f = floorf(iy);
@@ -424,10 +441,10 @@ __device__ __forceinline__ void mv2_gather_issue(const MlpK& a, int pl, int64_t 
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);
     const bf16_t* base = plane + (int64_t)b * S * S * MLP_F + cg * 8;
-    g.t[j][0] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y0 * S + x0) * MLP_F);
-    g.t[j][1] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y0 * S + x1) * MLP_F);
-    g.t[j][2] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y1 * S + x0) * MLP_F);
-    g.t[j][3] = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y1 * S + x1) * MLP_F);
+    g.t[j][0] = *reinterpret_cast<const bf16x8*>(base + (y0 * S + x0) * MLP_F);
+    g.t[j][1] = *reinterpret_cast<const bf16x8*>(base + (y0 * S + x1) * MLP_F);
+    g.t[j][2] = *reinterpret_cast<const bf16x8*>(base + (y1 * S + x0) * MLP_F);
+    g.t[j][3] = *reinterpret_cast<const bf16x8*>(base + (y1 * S + x1) * MLP_F);
     const float m = live ? 1.f : 0.f;
     g.w[j][0] = wy0 * wx0 * m; g.w[j][1] = wy0 * wx1 * m; g.w[j][2] = wy1 * wx0 * m; g.w[j][3] = wy1 * wx1 * m;
   }
@@ -448,12 +465,13 @@ __device__ __forceinline__ void mv2_gather_commit(const Mv2Gather<NT>& g, bf16_t
   }
 }
 
-// weight fragments of k-step ks of a 256-row matrix for this wave's four 16-row groups
+// weight fragments of k-step ks of a 256-row matrix for this wave's NF 16-row groups
+template <int NF>
 __device__ __forceinline__ void mv2_wload(const bf16_t* __restrict__ Wall, int off, int KS, int cw, int ks, int lane,
-                                          bf16x8 (&dst)[4]) {
+                                          bf16x8 (&dst)[NF]) {
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf)
-    dst[nf] = *reinterpret_cast<const bf16x8*>(Wall + mv2_wfrag(off, KS, 4 * cw + nf, ks) + 8 * lane);
+  for (int nf = 0; nf < NF; ++nf)
+    dst[nf] = *reinterpret_cast<const bf16x8*>(Wall + mv2_wfrag(off, KS, NF * cw + nf, ks) + 8 * lane);
 }
 
 // acc[mf][nf] += W[64 cw + 16 nf + r][k] * IN[prow0 + 16 mf + r][k] over KX channels of X then KF of F.
@@ -461,10 +479,10 @@ __device__ __forceinline__ void mv2_wload(const bf16_t* __restrict__ Wall, int o
 // pass weights (L2 -> registers) and activations (LDS -> registers) are fetched one k-step ahead of their MFMAs - with two
 // waves per SIMD a k-step is ~500 cycles of MFMA issue.  The k loop stays rolled (two steps per trip, static ring
 // slots): fully unrolled, the 116 k-steps of the kernel kept ~100 address registers alive and spilled.
-template <int MF, int KX, int KF>
+template <int MF, int NF, int KX, int KF>
 __device__ __forceinline__ void mv2_pass(const bf16_t* __restrict__ X, const bf16_t* __restrict__ F,
                                          const bf16_t* __restrict__ Wall, int off, int cw, int prow0, int lane,
-                                         bf16x8 (&wq)[2][4], f32x4 (&acc)[MF][4]) {
+                                         bf16x8 (&wq)[2][NF], f32x4 (&acc)[MF][NF]) {
   constexpr int KS = (KX + KF) / 32;
   static_assert(KS % 2 == 0, "two k-steps per trip");
   const int lr = lane & 15, lg = lane >> 4;
@@ -477,32 +495,34 @@ __device__ __forceinline__ void mv2_pass(const bf16_t* __restrict__ X, const bf1
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const bf16x8*>(p + mf * pitch);
   };
-  auto mma = [&](const bf16x8(&w)[4], const bf16x8(&x)[MF]) {
+  auto mma = [&](const bf16x8(&w)[NF], const bf16x8(&x)[MF]) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nf], x[mf], acc[mf][nf], 0, 0, 0);
+      for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nf], x[mf], acc[mf][nf], 0, 0, 0);
   };
   bf16x8 xq[2][MF];
   xload(0, xq[0]);
 #pragma unroll 1
   for (int ks = 0; ks < KS; ks += 2) {
-    mv2_wload(Wall, off, KS, cw, ks + 1, lane, wq[1]);
+    mv2_wload<NF>(Wall, off, KS, cw, ks + 1, lane, wq[1]);
     xload(ks + 1, xq[1]);
     mma(wq[0], xq[0]);
     if (ks + 2 < KS) {
-      mv2_wload(Wall, off, KS, cw, ks + 2, lane, wq[0]);
+      mv2_wload<NF>(Wall, off, KS, cw, ks + 2, lane, wq[0]);
       xload(ks + 2, xq[0]);
     }
     mma(wq[1], xq[1]);
   }
 }
 
-template <int PW, bool NOISE>
-__global__ void __launch_bounds__(256 * PW, 1) mlp2d_v2_kernel(MlpK a) {
-  constexpr int NT = 256 * PW;
-  constexpr int MF = MV2_P / PW / 16;
-  constexpr float SQRT2 = 1.41421356237309515f, RSQRT2 = 0.70710678118654752f;
+// CW = channel slices (waves along the output channels), 8 / CW = point groups; 8 waves either way:
+//   CW = 4: wave tile 64 channels x 64 points  - a weight byte is fetched by two waves (the L1 has to merge them)
+//   CW = 8: wave tile 32 channels x 128 points - every weight byte is fetched once per workgroup; twice the LDS reads
+template <int CW, bool NOISE, bool TS>
+__global__ void __launch_bounds__(512, 1) mlp2d_v2_kernel(MlpK a) {
+  constexpr int NT = 512, PW = 8 / CW;
+  constexpr int MF = MV2_P / PW / 16, NF = 256 / CW / 16, CWC = 256 / CW;   // CWC = channels per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* X0 = (bf16_t*)smem;
   bf16_t* X1 = X0 + MV2_P * MV2_XP;
@@ -510,71 +530,99 @@ __global__ void __launch_bounds__(256 * PW, 1) mlp2d_v2_kernel(MlpK a) {
 
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: weight addresses live in SGPRs
-  const int cw = wave & 3, pw = wave >> 2;
+  const int cw = wave % CW, pw = wave / CW;
   const int prow0 = pw * (MV2_P / PW);
   const int64_t tile0 = (int64_t)blockIdx.x * MV2_P;
   const bf16_t* Wall = (const bf16_t*)a.w;
 
-  f32x4 acc[MF][4];
-  bf16x8 wq[2][4];
+  f32x4 acc[MF][NF];
+  bf16x8 wq[2][NF];
   Mv2Gather<NT> gq;
+  Mv2Points<NT> pts;
+  f32x4 cst[NF];   // this lane's 16 per-channel constants of the coming epilogue (bias / skip constant), fetched under the pass
+  int nts = 0;
+#define MV2_STAMP()                                                                              \
+  if constexpr (TS) {                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) a.ts[blockIdx.x * 64 + nts] = wall_clock64();     \
+    ++nts;                                                                                       \
+  }
   auto zero = [&]() {
 #pragma unroll
     for (int i = 0; i < MF; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   // k-step 0 of the next matrix into the ring (issued before the previous pass's epilogue / barrier)
-  auto wprime = [&](int mat_off, int KS) { mv2_wload(Wall, mat_off, KS, cw, 0, lane, wq[0]); };
-  // StyledConv epilogue: + noise, FusedLeakyReLU.  store = write bf16 rows to Xout; otherwise the value stays in acc
-  auto activate = [&](int conv_idx, bf16_t* Xout) {
-    const float* bias = a.fb + MLP_FB_BIAS(conv_idx);
-    f32x4 b4[4];
+  auto wprime = [&](int mat_off, int KS) { mv2_wload<NF>(Wall, mat_off, KS, cw, 0, lane, wq[0]); };
+  // Paired fragments (mlp2d_pack_fragment_order): accumulator fragments 2p and 2p+1 of a lane hold channels
+  // CWC cw + 32 p + 8 lg + {0..3} and + {4..7} - eight consecutive channels, one 16-byte LDS store per point and pair.
+  // per-channel constants for those: cst[2p], cst[2p+1]
+  auto cload = [&](const float* table) {
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) b4[nf] = *reinterpret_cast<const f32x4*>(bias + 64 * cw + 16 * nf + 4 * lg);
+    for (int pr = 0; pr < NF / 2; ++pr) {
+      cst[2 * pr] = *reinterpret_cast<const f32x4*>(table + CWC * cw + 32 * pr + 8 * lg);
+      cst[2 * pr + 1] = *reinterpret_cast<const f32x4*>(table + CWC * cw + 32 * pr + 8 * lg + 4);
+    }
+  };
+  auto store8 = [&](bf16_t* Xout, int row, int pr, const f32x4& lo, const f32x4& hi) {
+    bf16x8 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q[e] = (bf16_t)lo[e];
+      q[4 + e] = (bf16_t)hi[e];
+    }
+    *reinterpret_cast<bf16x8*>(Xout + row * MV2_XP + CWC * cw + 32 * pr + 8 * lg) = q;
+  };
+  // StyledConv epilogue: + noise, + bias, leaky ReLU as max(t, 0.2 t).  The sqrt2 gain of FusedLeakyReLU and the 1/sqrt2 of
+  // the residual are folded into the matrices and constants on the host (mlp2d_host.hip: lrelu(x) sqrt2 = lrelu(sqrt2 x)).
+  // Xout != null: rows go to LDS; otherwise the activated value stays in acc (conv3: the skip pass accumulates on top).
+  auto activate = [&](int conv_idx, float noise_gain, bf16_t* Xout) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       const int row = prow0 + 16 * mf + lr;
       float nz = 0.f;
-      if constexpr (NOISE) nz = mlp_noise(a, conv_idx, tile0 + row);  // checkpoints with non-zero noise.weight only
+      if constexpr (NOISE) nz = noise_gain * mlp_noise(a, conv_idx, tile0 + row);  // checkpoints with non-zero noise.weight only
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
+      for (int nf = 0; nf < NF; ++nf) {
         f32x4 v = acc[mf][nf];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = NOISE ? v[e] + nz + b4[nf][e] : v[e] + b4[nf][e];
-          v[e] = (t > 0.f ? t : 0.2f * t) * SQRT2;
+          const float t = NOISE ? v[e] + nz + cst[nf][e] : v[e] + cst[nf][e];
+          v[e] = fmaxf(t, 0.2f * t);
         }
         acc[mf][nf] = v;
-        if (Xout != nullptr) {
-          bf16x4 q;
+      }
+      if (Xout != nullptr) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) q[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(Xout + row * MV2_XP + 64 * cw + 16 * nf + 4 * lg) = q;
-        }
+        for (int pr = 0; pr < NF / 2; ++pr) store8(Xout, row, pr, acc[mf][2 * pr], acc[mf][2 * pr + 1]);
       }
     }
   };
-  // block output: x = (acc [+ skip constant] [+ identity skip from Xid]) / sqrt2 -> Xout
-  auto block_store = [&](int skip_const_idx, const bf16_t* Xid, bf16_t* Xout) {
+  // block output: x = acc + skip constant (cst) [+ identity skip x_in / sqrt2] -> Xout
+  auto block_store = [&](bool add_const, const bf16_t* Xid, bf16_t* Xout) {
+    constexpr float RSQRT2 = 0.70710678118654752f;
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      const int n = 64 * cw + 16 * nf + 4 * lg;
-      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (skip_const_idx >= 0) sc = *reinterpret_cast<const f32x4*>(a.fb + MLP_FB_SKIP(skip_const_idx) + n);
+    for (int mf = 0; mf < MF; ++mf) {
+      const int row = prow0 + 16 * mf + lr;
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const int row = prow0 + 16 * mf + lr;
-        f32x4 v = acc[mf][nf];
-        if (Xid != nullptr) {
-          const bf16x4 xi = *reinterpret_cast<const bf16x4*>(Xid + row * MV2_XP + n);
+      for (int pr = 0; pr < NF / 2; ++pr) {
+        f32x4 lo = acc[mf][2 * pr], hi = acc[mf][2 * pr + 1];
+        if (add_const) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)xi[e];
+          for (int e = 0; e < 4; ++e) {
+            lo[e] += cst[2 * pr][e];
+            hi[e] += cst[2 * pr + 1][e];
+          }
         }
-        bf16x4 q;
+        if (Xid != nullptr) {
+          const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Xid + row * MV2_XP + CWC * cw + 32 * pr + 8 * lg);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q[e] = (bf16_t)((v[e] + sc[e]) * RSQRT2);
-        *reinterpret_cast<bf16x4*>(Xout + row * MV2_XP + n) = q;
+          for (int e = 0; e < 4; ++e) {
+            lo[e] += RSQRT2 * (float)xi[e];
+            hi[e] += RSQRT2 * (float)xi[4 + e];
+          }
+        }
+        store8(Xout, row, pr, lo, hi);
       }
     }
   };
@@ -585,37 +633,55 @@ __global__ void __launch_bounds__(256 * PW, 1) mlp2d_v2_kernel(MlpK a) {
   //      matrix whose first k-steps are primed before the last barrier.
 #define MV2_BLOCK(IN, TMP, KX, KF, m1, ms, m2, m3, c0, skip_idx, next_plane, next_off, next_KS)                        \
   {                                                                                                                   \
+    constexpr float SQRT2 = 1.41421356237309515f;                                                                     \
     zero();                                                                                                           \
-    mv2_pass<MF, KX, KF>(IN, F, Wall, mlp_w_off(m1), cw, prow0, lane, wq, acc);                                       \
+    cload(a.fb + MLP_FB_BIAS(c0));                                                                                    \
+    mv2_pass<MF, NF, KX, KF>(IN, F, Wall, mlp_w_off(m1), cw, prow0, lane, wq, acc);                                       \
+    MV2_STAMP();                                                                                                      \
     wprime(mlp_w_off(m2), 8);                                                                                         \
-    activate((c0), TMP);                                                                                              \
+    activate((c0), SQRT2, TMP);                                                                                       \
     __syncthreads();                                                                                                  \
+    MV2_STAMP();                                                                                                      \
     zero();                                                                                                           \
-    mv2_pass<MF, 256, 0>(TMP, F, Wall, mlp_w_off(m2), cw, prow0, lane, wq, acc);                                      \
+    cload(a.fb + MLP_FB_BIAS((c0) + 1));                                                                              \
+    mv2_pass<MF, NF, 256, 0>(TMP, F, Wall, mlp_w_off(m2), cw, prow0, lane, wq, acc);                                      \
+    MV2_STAMP();                                                                                                      \
     wprime(mlp_w_off(m3), 8);                                                                                         \
     __syncthreads(); /* every wave has read TMP: conv2 writes it in place */                                          \
-    activate((c0) + 1, TMP);                                                                                          \
-    if ((next_plane) >= 0) mv2_gather_issue<NT>(a, (next_plane), tile0, gq);                                          \
+    activate((c0) + 1, SQRT2, TMP);                                                                                   \
+    if ((next_plane) >= 0) mv2_gather_issue<NT>(a, (next_plane), pts, gq);                                            \
     __syncthreads();                                                                                                  \
+    MV2_STAMP();                                                                                                      \
     zero();                                                                                                           \
-    mv2_pass<MF, 256, 0>(TMP, F, Wall, mlp_w_off(m3), cw, prow0, lane, wq, acc);                                      \
+    cload(a.fb + MLP_FB_BIAS((c0) + 2));                                                                              \
+    mv2_pass<MF, NF, 256, 0>(TMP, F, Wall, mlp_w_off(m3), cw, prow0, lane, wq, acc);                                      \
+    MV2_STAMP();                                                                                                      \
     if ((ms) >= 0) wprime(mlp_w_off((ms) >= 0 ? (ms) : 0), ((KX) + (KF)) / 32);                                       \
-    activate((c0) + 2, nullptr);                                                                                      \
+    activate((c0) + 2, 1.f, nullptr);                                                                                 \
     __syncthreads(); /* every wave has read TMP: the block output goes there */                                       \
-    if ((ms) >= 0) mv2_pass<MF, KX, KF>(IN, F, Wall, mlp_w_off((ms) >= 0 ? (ms) : 0), cw, prow0, lane, wq, acc);      \
+    MV2_STAMP();                                                                                                      \
+    if ((ms) >= 0) {                                                                                                  \
+      cload(a.fb + MLP_FB_SKIP((skip_idx) >= 0 ? (skip_idx) : 0));                                                    \
+      mv2_pass<MF, NF, KX, KF>(IN, F, Wall, mlp_w_off((ms) >= 0 ? (ms) : 0), cw, prow0, lane, wq, acc);                   \
+    }                                                                                                                 \
+    MV2_STAMP();                                                                                                      \
     if ((next_KS) > 0) wprime((next_off), (next_KS));                                                                 \
-    block_store((skip_idx), (ms) >= 0 ? nullptr : IN, TMP);                                                           \
+    block_store((ms) >= 0, (ms) >= 0 ? nullptr : IN, TMP);                                                            \
     if ((next_plane) >= 0) {                                                                                          \
       __syncthreads(); /* every wave is done with the current features */                                             \
       mv2_gather_commit<NT>(gq, F);                                                                                   \
     }                                                                                                                 \
     __syncthreads();                                                                                                  \
+    MV2_STAMP();                                                                                                      \
   }
 
-  mv2_gather_issue<NT>(a, 0, tile0, gq);
+  MV2_STAMP();
+  mv2_points<NT>(a, tile0, pts);
+  mv2_gather_issue<NT>(a, 0, pts, gq);
   wprime(mlp_w_off(0), 2);
   mv2_gather_commit<NT>(gq, F);
   __syncthreads();
+  MV2_STAMP();
   //          IN  TMP  KX  KF  m1  ms  m2  m3  c0 skip next_plane  next matrix
   MV2_BLOCK(X1, X0, 0, 64, 0, 1, 2, 3, 0, 0, 1, mlp_w_off(4), 10);     // block 1: input f0            -> X0
   MV2_BLOCK(X0, X1, 256, 64, 4, 5, 6, 7, 3, 1, 2, mlp_w_off(8), 10);   // block 2: input [x1 | f1]     -> X1
@@ -624,7 +690,7 @@ __global__ void __launch_bounds__(256 * PW, 1) mlp2d_v2_kernel(MlpK a) {
 #undef MV2_BLOCK
   // ================= ToRGB: 256 -> 3 (rows padded to 16), 16-point fragments split over the waves ======================
   {
-    constexpr int MFT = (MV2_P / 16) / (4 * PW);
+    constexpr int MFT = (MV2_P / 16) / 8;
     f32x4 r[MFT];
 #pragma unroll
     for (int i = 0; i < MFT; ++i) r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -652,29 +718,100 @@ __global__ void __launch_bounds__(256 * PW, 1) mlp2d_v2_kernel(MlpK a) {
       }
     }
   }
+  MV2_STAMP();
+#undef MV2_STAMP
 }
 
-// host side of the fragment order: row-major [rows][K] fp32 -> [rows/16][K/32][64 lanes][8]
+// host side of the bf16 kernel's weight image: row-major [rows][K] fp32 -> [rows/16][K/32][64 lanes][8] (fragment order),
+// with the rows of the 256-row matrices PAIRED: row 4q + e of 16-row group 4c + 2p + h is channel 64c + 32p + 8q + 4h + e,
+// so a lane's accumulators of groups 2p and 2p+1 are eight consecutive channels.
 void mlp2d_pack_fragment_order(const float* src, float* dst) {
   for (int i = 0; i < 16; ++i) {
     const int K = mlp_w_k(i), R = mlp_w_rows(i), KS = K / 32, off = mlp_w_off(i);
     for (int g = 0; g < R / 16; ++g)
       for (int ks = 0; ks < KS; ++ks)
-        for (int l = 0; l < 64; ++l)
-          for (int e = 0; e < 8; ++e)
-            dst[off + (((g * KS + ks) * 64 + l) << 3) + e] = src[off + (16 * g + (l & 15)) * K + 32 * ks + 8 * (l >> 4) + e];
+        for (int l = 0; l < 64; ++l) {
+          const int r = l & 15;
+          int row = 16 * g + r;
+          if (R == 256) {
+            const int c = g >> 2, pr = (g >> 1) & 1, h = g & 1, q = r >> 2, e = r & 3;
+            row = 64 * c + 32 * pr + 8 * q + 4 * h + e;
+          }
+          for (int e = 0; e < 8; ++e) dst[off + (((g * KS + ks) * 64 + l) << 3) + e] = src[off + row * K + 32 * ks + 8 * (l >> 4) + e];
+        }
   }
 }
 
-template <int PW, bool NOISE> static int launch_mlp2d_v2(const MlpK& k, hipStream_t s) {
+// FusedLeakyReLU's sqrt2 gain and the residual's 1/sqrt2, folded into the bf16 kernel's matrices and constants
+// (lrelu is positively homogeneous: lrelu(x + b) sqrt2 = lrelu(sqrt2 x + sqrt2 b)):
+//   conv1, conv2 of a block : W, bias scaled by sqrt2            -> epilogue max(t, 0.2 t)
+//   conv3                   : untouched, (lrelu(.) sqrt2 + skip + c) / sqrt2 = lrelu(.) + (skip + c) / sqrt2
+//   skip matrices, constants: scaled by 1 / sqrt2                 (block 4's identity skip: x / sqrt2 in the kernel)
+void mlp2d_fold_gains(float* W, float* fb) {
+  const double S2 = 1.41421356237309504880, R2 = 0.70710678118654752440;
+  const int conv12[8] = {0, 2, 4, 6, 8, 10, 12, 13};   // matrix indices of conv1 / conv2 per block
+  const int conv12_bias[8] = {0, 1, 3, 4, 6, 7, 9, 10};
+  for (int j = 0; j < 8; ++j) {
+    const int i = conv12[j];
+    float* w = W + mlp_w_off(i);
+    for (int n = 0; n < 256 * mlp_w_k(i); ++n) w[n] = (float)(w[n] * S2);
+    float* b = fb + MLP_FB_BIAS(conv12_bias[j]);
+    for (int n = 0; n < 256; ++n) b[n] = (float)(b[n] * S2);
+  }
+  const int skip[3] = {1, 5, 9};
+  for (int k = 0; k < 3; ++k) {
+    float* w = W + mlp_w_off(skip[k]);
+    for (int n = 0; n < 256 * mlp_w_k(skip[k]); ++n) w[n] = (float)(w[n] * R2);
+    float* c = fb + MLP_FB_SKIP(k);
+    for (int n = 0; n < 256; ++n) c[n] = (float)(c[n] * R2);
+  }
+}
+
+template <int CW, bool NOISE, bool TS = false> static int launch_mlp2d_v2(const MlpK& k, hipStream_t s) {
   const size_t lds = (size_t)(2 * MV2_P * MV2_XP + MV2_P * MV2_FP) * sizeof(bf16_t);
   static bool set = false;
   if (!set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2d_v2_kernel<PW, NOISE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2d_v2_kernel<CW, NOISE, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     set = true;
   }
-  hipLaunchKernelGGL((mlp2d_v2_kernel<PW, NOISE>), dim3((unsigned)cdiv64(k.total, MV2_P)), dim3(256 * PW), lds, s, k);
+  hipLaunchKernelGGL((mlp2d_v2_kernel<CW, NOISE, TS>), dim3((unsigned)cdiv64(k.total, MV2_P)), dim3(512), lds, s, k);
   return DDMI_OK;
+}
+
+// DDMI_MLP2D_TS=1: the third launch of the process is run once more with per-workgroup phase stamps (wall_clock64,
+// 100 MHz) and the mean duration of every phase over workgroups 512..1023 (steady state) is printed
+static void mlp2d_v2_timeline(MlpK k, hipStream_t s) {
+  const int nwg = (int)std::min<int64_t>(1024, cdiv64(k.total, MV2_P));
+  if (nwg < 1024) return;
+  unsigned long long* dts = nullptr;
+  if (hipMalloc((void**)&dts, (size_t)1024 * 64 * 8) != hipSuccess) return;
+  (void)hipMemsetAsync(dts, 0, (size_t)1024 * 64 * 8, s);
+  k.ts = dts;
+  if (getenv("DDMI_MLP2D_CW") && atoi(getenv("DDMI_MLP2D_CW")) == 8) (void)launch_mlp2d_v2<8, false, true>(k, s);
+  else (void)launch_mlp2d_v2<4, false, true>(k, s);
+  (void)hipStreamSynchronize(s);
+  std::vector<unsigned long long> h((size_t)1024 * 64);
+  (void)hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(dts);
+  static const char* names[8] = {"conv1 pass", "act+barrier", "conv2 pass", "barrier+act+gather issue+barrier", "conv3 pass",
+                                 "act+barrier", "skip pass", "store+commit+barriers"};
+  fprintf(stderr, "mlp2d_v2 timeline (mean over workgroups 512..1023, us):\n");
+  auto mean = [&](int i) {
+    double acc = 0;
+    for (int w = 512; w < 1024; ++w) acc += (double)(h[(size_t)w * 64 + i + 1] - h[(size_t)w * 64 + i]);
+    return acc / 512 * 0.01;
+  };
+  fprintf(stderr, "  first gather                          %7.2f\n", mean(0));
+  double tot = mean(0), pass = 0;
+  for (int b = 0; b < 4; ++b)
+    for (int j = 0; j < 8; ++j) {
+      double v = mean(1 + 8 * b + j);
+      tot += v;
+      if (j == 0 || j == 2 || j == 4 || j == 6) pass += v;
+      fprintf(stderr, "  block %d %-32s %7.2f\n", b + 1, names[j], v);
+    }
+  fprintf(stderr, "  torgb                                 %7.2f\n  total %.2f us, GEMM passes %.2f us (%.0f %%); at the bf16 MFMA peak a tile's 244 MFLOP take %.2f us\n",
+          mean(33), tot + mean(33), pass, 100 * pass / (tot + mean(33)), 128 * 2.0 * 954112.0 / (2.5e15 / 256) * 1e6);
 }
 
 int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s) {
@@ -690,13 +827,17 @@ int launch_mlp2d(const Mlp2dArgs& a, int dt, hipStream_t s) {
   for (int i = 0; i < 3; ++i) plane_bytes += (double)a.B * a.plane_hw[i] * a.plane_hw[i] * 64 * dt_size(dt);
   PROF_SCOPE("mlp2d_fused", 2.0 * 954112.0 * (double)k.total, plane_bytes + 12.0 * (double)k.total, s);
   if (dt == DT_BF16) {  // weights in fragment order (mlp2d_pack_fragment_order)
-    static const int pw = [] { const char* e = getenv("DDMI_MLP2D_PW"); return e ? atoi(e) : 2; }();
+    // measured (B = 32, R = 256): CW = 8 1033 TFLOP/s, CW = 4 986 - the default fetches every weight byte once per workgroup
+    static const int cw = [] { const char* e = getenv("DDMI_MLP2D_CW"); return e ? atoi(e) : 8; }();
     const bool nz = k.noise != nullptr || k.seeds != nullptr;
     int rc;
-    if (nz) rc = launch_mlp2d_v2<2, true>(k, s);
-    else if (pw == 1) rc = launch_mlp2d_v2<1, false>(k, s);
-    else rc = launch_mlp2d_v2<2, false>(k, s);
+    if (nz) rc = launch_mlp2d_v2<8, true>(k, s);
+    else if (cw == 4) rc = launch_mlp2d_v2<4, false>(k, s);
+    else rc = launch_mlp2d_v2<8, false>(k, s);
     DDMI_TRY(rc);
+    static const bool want_ts = getenv("DDMI_MLP2D_TS") != nullptr;
+    static int n_launch = 0;
+    if (want_ts && !nz && ++n_launch == 3) mlp2d_v2_timeline(k, s);
   } else {
     using L = MlpL<float>;
     size_t lds = (size_t)(2 * L::P * L::XP + L::P * L::FP) * sizeof(float);

@@ -140,6 +140,8 @@ size_t mlp2d_weight_elems();
 size_t mlp2d_fb_elems();
 // bf16 handles keep their folded weights in MFMA fragment order: row-major [rows][K] -> [rows/16][K/32][64 lanes][8]
 void mlp2d_pack_fragment_order(const float* src_row_major, float* dst);
+// ... and the activation gains folded into matrices / constants (k_mlp2d.hip); applied BEFORE the fragment packing
+void mlp2d_fold_gains(float* W_row_major, float* fb);
 
 // ---- fused tri-plane sampling + occupancy MLP (MLP3D) -----------------------------------------------------
 struct Mlp3dArgs {

@@ -175,6 +175,7 @@ static int fold_for_si(Mlp2d& m, float si, hipStream_t s) {
     for (int c = 0; c < 3; ++c) fb[15 * 256 + c] = rb.data[c];
   }
   if (m.dt == DT_BF16) {  // the bf16 kernel streams MFMA fragments: [16-row group][k step][lane][8]
+    mlp2d_fold_gains(W.data(), fb.data());
     std::vector<float> Wf(W.size());
     mlp2d_pack_fragment_order(W.data(), Wf.data());
     W.swap(Wf);

@@ -45,7 +45,7 @@ if __name__ == "__main__":
         mlp.load_state_dict(named_state("afhq.mlp", mlp.manifest()))
         planes = [torch.randn((B, 64, p, p), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for p in (64, 128, 256)]
         coords = generation_coords(256)
-        timed(f"mlp2d B={B} R=256 (PW={os.environ.get('DDMI_MLP2D_PW', '2')})", lambda: mlp(coords, hdbf=planes, si=1.0), args.iters, "mlp2d_fused")
+        timed(f"mlp2d B={B} R=256", lambda: mlp(coords, hdbf=planes, si=1.0), args.iters, "mlp2d_fused")
     if "3d" in which:
         from ddmi_amd.occupancy import MLP3D, occupancy_grid_logits
         m3 = MLP3D(numerics="bf16")

@@ -11,7 +11,11 @@ for st in "$@"; do
     alltests)  timeout 2400 python -m pytest tests -m gpu -q > $log 2>&1 ;;
     newtests)  timeout 1800 python -m pytest tests/test_gpu_round2.py -q > $log 2>&1 ;;
     smoke)     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $log 2>&1 ;;
-    mlpbench)  (DDMI_MLP2D_PW=2 timeout 300 python tools/bench_mlp.py; DDMI_MLP2D_PW=1 timeout 300 python tools/bench_mlp.py --which 2d) > $log 2>&1 ;;
+    mlpbench)  timeout 300 python tools/bench_mlp.py > $log 2>&1 ;;
+    mlptests8) DDMI_MLP2D_CW=8 timeout 900 python -m pytest tests/test_gpu_networks.py tests/test_gpu_round2.py -q -k "mlp or pipeline or arbitrary or noise" > $log 2>&1 ;;
+    mlpbench8) DDMI_MLP2D_CW=8 timeout 300 python tools/bench_mlp.py --which 2d > $log 2>&1 ;;
+    mlpts8)    DDMI_MLP2D_CW=8 DDMI_MLP2D_TS=1 timeout 300 python tools/bench_mlp.py --which 2d > $log 2>&1 ;;
+    mlpts)     DDMI_MLP2D_TS=1 timeout 300 python tools/bench_mlp.py --which 2d > $log 2>&1 ;;
     bench)     timeout 1500 python bench.py --steps 1 --warmup 1 > gpurun_out/${tag}_bench.json 2> $log ;;
     benchfast) timeout 900 python bench.py --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchfast.json 2> $log ;;
     benchshape) timeout 900 python bench.py --workload shapenet --steps 1 --warmup 1 > gpurun_out/${tag}_bench_shapenet.json 2> $log ;;
