@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include "mlp_common.h"
+#include "mlp_fc2.h"
 
 // packed weight matrices (row-major [N][K], storage dtype), in execution order
 //  0 r1.fc_0 [64][64]   1 r1.fc_1 [256][64]   2 r1.shortcut [256][64]
@@ -264,6 +265,223 @@ __global__ void __launch_bounds__(256, 1) mlp3d_kernel(Mlp3dK a) {
   }
 }
 
+// =====================================================================================================================
+// bf16 perf kernel, second generation (mlp_fc2.h): 128 points per workgroup, 8 waves x (32 channels x 128 points),
+// fragment-ordered weights fetched once per workgroup, raw activations in two LDS buffers, relu applied on the fragment.
+// Measured on the 128^3 grid: first generation 6.6 ms (0.40 PFLOP/s).
+// =====================================================================================================================
+#define M3V2_P 128
+#define M3V2_FP 80   // feature row pitch (160 B): conflict-free for the b128 lane groups
+
+// raw features of scale `sc` (sum over the three planes of bilinear samples) -> F[P][FP]
+__device__ __forceinline__ void m3v2_gather(const Mlp3dK& a, int sc, int64_t tile0, bf16_t* F) {
+  const int S = a.hw[sc];
+#pragma unroll   // both items of a thread: 24 texel loads in flight (the accumulators are dead at a block boundary)
+  for (int rnd = 0; rnd < M3V2_P * 8 / 512; ++rnd) {
+    const int it = threadIdx.x + 512 * rnd;
+    const int pi = it >> 3, cg = it & 7;
+    const int64_t gp = tile0 + pi;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (gp < a.total) {
+      const int b = (int)(gp / a.N);
+      const float* pt = a.pts + gp * 3;
+      const float c3[3] = {pt[0], pt[1], pt[2]};
+      // plane j: xy -> axes (0,1), yz -> (1,2), xz -> (0,2)   (general_utils.py:79-84)
+      const int ax0[3] = {0, 1, 0}, ax1[3] = {1, 2, 2};
+      bf16x8 t[3][4];
+      float w[3][4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {   // all twelve texel loads of the point in flight before the first blend
+        const float ix = m3_texcoord(c3[ax0[j]], S), iy = m3_texcoord(c3[ax1[j]], S);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);
+        const bf16_t* base = (const bf16_t*)a.planes[j * 3 + sc] + (int64_t)b * S * S * 64 + cg * 8;
+        t[j][0] = *reinterpret_cast<const bf16x8*>(base + (y0 * S + x0) * 64);
+        t[j][1] = *reinterpret_cast<const bf16x8*>(base + (y0 * S + x1) * 64);
+        t[j][2] = *reinterpret_cast<const bf16x8*>(base + (y1 * S + x0) * 64);
+        t[j][3] = *reinterpret_cast<const bf16x8*>(base + (y1 * S + x1) * 64);
+        w[j][0] = wy0 * wx0; w[j][1] = wy0 * wx1; w[j][2] = wy1 * wx0; w[j][3] = wy1 * wx1;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)   // the first generation's (and the fp32 kernel's) operation order
+          v[e] += (float)t[j][0][e] * w[j][0] + (float)t[j][1][e] * w[j][1] + (float)t[j][2][e] * w[j][2] + (float)t[j][3][e] * w[j][3];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(F + pi * M3V2_FP + cg * 8) = o;
+  }
+}
+
+__global__ void __launch_bounds__(512, 1) mlp3d_v2_kernel(Mlp3dK a) {
+  constexpr int P = M3V2_P, MF = P / 16, NF = 2, FP = M3V2_FP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* X0 = (bf16_t*)smem;
+  bf16_t* X1 = X0 + P * FC2_XP;
+  bf16_t* F = X1 + P * FC2_XP;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g0 = 2 * wave, ch0 = 32 * wave + 8 * lg;   // this lane's eight channels: ch0 .. ch0 + 7
+  const int64_t tile0 = (int64_t)blockIdx.x * P;
+  const bf16_t* W = (const bf16_t*)a.w;
+  const float* fb = a.fb;
+
+  f32x4 acc[MF][NF], cst[NF];
+  bf16x8 wq[2][NF];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto wprime = [&](int off, int KS) { fc2_wload<NF>(W, off, KS, g0, 0, lane, wq[0]); };
+  auto cload = [&](const float* table) {
+    cst[0] = *reinterpret_cast<const f32x4*>(table + ch0);
+    cst[1] = *reinterpret_cast<const f32x4*>(table + ch0 + 4);
+  };
+  auto store8 = [&](bf16_t* Xout, int row, const f32x4& lo, const f32x4& hi) {
+    bf16x8 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q[e] = (bf16_t)lo[e];
+      q[4 + e] = (bf16_t)hi[e];
+    }
+    *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0) = q;
+  };
+  // hidden activation: relu(acc + bias) -> Xout (rectified: fc_1 reads it as is)
+  auto store_hidden = [&](bf16_t* Xout) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] = fmaxf(acc[mf][0][e] + cst[0][e], 0.f);
+        hi[e] = fmaxf(acc[mf][1][e] + cst[1][e], 0.f);
+      }
+      store8(Xout, 16 * mf + lr, lo, hi);
+    }
+  };
+  // block output: x = acc (fc_1 + shortcut) + bias [+ identity x_in] -> Xout, raw
+  auto store_block = [&](const bf16_t* Xid, bf16_t* Xout) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int row = 16 * mf + lr;
+      f32x4 lo = acc[mf][0], hi = acc[mf][1];
+      if (Xid != nullptr) {
+        const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Xid + row * FC2_XP + ch0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] += (float)xi[e];
+          hi[e] += (float)xi[4 + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] += cst[0][e];
+        hi[e] += cst[1][e];
+      }
+      store8(Xout, row, lo, hi);
+    }
+  };
+
+  // ================= block 1: x1 = net_p(p) + RB(64 -> 256)(f0), hidden width 64 (waves 0, 1) ======================
+  wprime(m3_off(0), 2);
+  m3v2_gather(a, 0, tile0, F);
+  __syncthreads();
+  if (wave < 2) {
+    zero();
+    cload(fb + M3_B_R1FC0);
+    fc2_pass<MF, NF, 0, 64, FP, true>(X1, F, W, m3_off(0), g0, lane, wq, acc);     // fc_0(relu(f0)): 64 -> 64
+    store_hidden(X1);
+  }
+  wprime(m3_off(1), 2);
+  __syncthreads();
+  zero();
+  fc2_pass<MF, NF, 64, 0, FP, false>(X1, F, W, m3_off(1), g0, lane, wq, acc);        // fc_1(relu(net)): 64 -> 256
+  wprime(m3_off(2), 2);
+  cload(fb + M3_B(0));
+  fc2_pass<MF, NF, 0, 64, FP, false>(X0, F, W, m3_off(2), g0, lane, wq, acc);        // + shortcut(f0), bias-free
+  wprime(m3_off(3), 10);
+  {  // + net_p(coords): Linear(3 -> 256) on the fp32 coordinates (mlp.py:103)
+    float wp[8][3], bp[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(fb + M3_WP + (ch0 + c) * 4);
+      wp[c][0] = w4[0]; wp[c][1] = w4[1]; wp[c][2] = w4[2];
+      bp[c] = fb[M3_BP + ch0 + c];
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t gp = tile0 + 16 * mf + lr;
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (gp < a.total) { px = a.pts[gp * 3]; py = a.pts[gp * 3 + 1]; pz = a.pts[gp * 3 + 2]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[mf][0][e] += wp[e][0] * px + wp[e][1] * py + wp[e][2] * pz + bp[e];
+        acc[mf][1][e] += wp[4 + e][0] * px + wp[4 + e][1] * py + wp[4 + e][2] * pz + bp[4 + e];
+      }
+    }
+  }
+  store_block(nullptr, X0);
+  __syncthreads();   // every wave is done with f0 and the hidden tile
+  m3v2_gather(a, 1, tile0, F);
+  __syncthreads();
+
+  // ---- blocks 2-4.  IN = raw block input, TMP = the other buffer (hidden, then the block output).
+#define M3V2_BLOCK(IN, TMP, KF, m_fc0, m_fc1, m_sc, b_fc0, b_fc1, next_scale, next_off, next_KS)                      \
+  {                                                                                                                   \
+    zero();                                                                                                           \
+    cload(fb + M3_B(b_fc0));                                                                                          \
+    fc2_pass<MF, NF, 256, KF, FP, true>(IN, F, W, m3_off(m_fc0), g0, lane, wq, acc);      /* fc_0(relu([x | f])) */   \
+    wprime(m3_off(m_fc1), 8);                                                                                         \
+    store_hidden(TMP);                                                                                                \
+    __syncthreads();                                                                                                  \
+    zero();                                                                                                           \
+    cload(fb + M3_B(b_fc1));                                                                                          \
+    fc2_pass<MF, NF, 256, 0, FP, false>(TMP, F, W, m3_off(m_fc1), g0, lane, wq, acc);     /* fc_1(relu(net)) */       \
+    if ((m_sc) >= 0) wprime(m3_off((m_sc) >= 0 ? (m_sc) : 0), (256 + (KF)) / 32);                                     \
+    __syncthreads(); /* every wave has read the hidden tile: the block output goes there */                           \
+    if ((m_sc) >= 0)                                                                                                  \
+      fc2_pass<MF, NF, 256, KF, FP, false>(IN, F, W, m3_off((m_sc) >= 0 ? (m_sc) : 0), g0, lane, wq, acc);            \
+    if ((next_KS) > 0) wprime((next_off), (next_KS));                                                                 \
+    store_block((m_sc) >= 0 ? nullptr : IN, TMP);                                                                     \
+    __syncthreads();                                                                                                  \
+    if ((next_scale) >= 0) {                                                                                          \
+      m3v2_gather(a, (next_scale), tile0, F);                                                                         \
+      __syncthreads();                                                                                                \
+    }                                                                                                                 \
+  }
+  M3V2_BLOCK(X0, X1, 64, 3, 4, 5, 1, 2, 2, m3_off(6), 10);     // block 2: [x1 | f1] -> X1
+  M3V2_BLOCK(X1, X0, 64, 6, 7, 8, 3, 4, -1, m3_off(9), 8);     // block 3: [x2 | f2] -> X0
+  M3V2_BLOCK(X0, X1, 0, 9, 10, -1, 5, 6, -1, 0, 0);            // block 4: identity shortcut -> X1
+#undef M3V2_BLOCK
+  // ================= net_out: 256 -> 1 (rows padded to 16): one 16-point fragment per wave ===========================
+  {
+    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(W + fc2_wfrag(m3_off(11), 8, 0, ks) + 8 * lane);
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(X1 + (16 * wave + lr) * FC2_XP + ks * 32 + 8 * lg);
+      r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, r, 0, 0, 0);
+    }
+    if (lg == 0) {
+      const int64_t gp = tile0 + 16 * wave + lr;
+      if (gp < a.total) a.logits[gp] = r[0] + fb[M3_BOUT];
+    }
+  }
+}
+
+// host: the bf16 kernel's weight image (fragment order, paired rows) from the row-major pack
+void mlp3d_pack_fragment_order(const float* src, float* dst) {
+  for (int i = 0; i < 12; ++i) fc2_pack_matrix(src + m3_off(i), dst + m3_off(i), m3_rows(i), m3_k(i));
+}
+
 int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s) {
   Mlp3dK k{};
   for (int i = 0; i < 9; ++i) k.planes[i] = a.planes[i];
@@ -273,15 +491,14 @@ int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s) {
   double plane_bytes = 0;
   for (int i = 0; i < 3; ++i) plane_bytes += 3.0 * a.B * a.plane_hw[i] * a.plane_hw[i] * 64 * dt_size(dt);
   PROF_SCOPE("mlp3d_fused", 2.0 * 627712.0 * (double)k.total, plane_bytes + 16.0 * (double)k.total, s);
-  if (dt == DT_BF16) {
-    using L = M3L<bf16_t>;
-    size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(bf16_t);
+  if (dt == DT_BF16) {  // weights in fragment order (mlp3d_pack_fragment_order)
+    const size_t lds = (size_t)(2 * M3V2_P * FC2_XP + M3V2_P * M3V2_FP) * sizeof(bf16_t);
     static bool set = false;
     if (!set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set = true;
     }
-    hipLaunchKernelGGL(mlp3d_kernel<bf16_t>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+    hipLaunchKernelGGL(mlp3d_v2_kernel, dim3((unsigned)cdiv64(k.total, M3V2_P)), dim3(512), lds, s, k);
   } else {
     using L = M3L<float>;
     size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(float);

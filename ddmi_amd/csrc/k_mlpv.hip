@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include "mlp_common.h"
+#include "mlp_fc2.h"
 
 // packed weight matrices (row-major [N][K], storage dtype), in execution order
 //  0 r1.fc_0 [192][192]  1 r1.fc_1 [256][192]  2 r1.shortcut [256][192]
@@ -251,6 +252,202 @@ __global__ void __launch_bounds__(256, 1) mlpv_kernel(MlpVK a) {
   }
 }
 
+// =====================================================================================================================
+// bf16 perf kernel, second generation (mlp_fc2.h): 96 points per workgroup (two [96][272] activation buffers + the
+// [96][208] feature tile = 141 KB of LDS), 8 waves x (32 channels x 96 points), fragment-ordered weights fetched once per
+// workgroup, relu applied on the fragment.  First generation: 4.8 ms per 16x256x256 clip (0.37 PFLOP/s).
+// =====================================================================================================================
+#define MVV2_P 96
+#define MVV2_FP 208   // 416-byte feature rows: (row * 104 + 4 lg) mod 64 conflict-free for the b128 lane groups
+
+// raw features of scale `sc`: [xy(h,w) | yt(t,h) | xt(t,w)] bilinear samples -> F[P][FP]
+__device__ __forceinline__ void mvv2_gather(const MlpVK& a, int sc, int64_t tile0, bf16_t* F) {
+  const int HW = a.H * a.W, THW = a.T * HW;
+#pragma unroll   // a thread's 4-5 items: up to 20 texel loads in flight
+  for (int rnd = 0; rnd < (MVV2_P * 24 + 511) / 512; ++rnd) {
+    const int it = threadIdx.x + 512 * rnd;
+    if (it >= MVV2_P * 24) break;
+    const int pi = it / 24, cg = it - pi * 24;
+    const int j = cg >> 3, cgi = cg & 7;
+    const int64_t gp = tile0 + pi;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)0.f;
+    if (gp < a.total) {
+      const int b = (int)(gp / THW);
+      const int idx = (int)(gp - (int64_t)b * THW);
+      const int t = idx / HW, r = idx - t * HW, h = r / a.W, w = r - h * a.W;
+      // grid channel 0 -> grid_sample's x (plane width), channel 1 -> y (plane height)   (general_utils.py:27-52, 134-138)
+      float gx, gy;
+      int Hp;
+      const int Wp = a.pw[sc];
+      if (j == 0) { gx = a.cxy[h * a.W + w]; gy = a.cxy[HW + h * a.W + w]; Hp = Wp; }
+      else if (j == 1) { gx = a.cyt[t * a.H + h]; gy = a.cyt[a.T * a.H + t * a.H + h]; Hp = a.frames; }
+      else { gx = a.cxt[t * a.W + w]; gy = a.cxt[a.T * a.W + t * a.W + w]; Hp = a.frames; }
+      const float ix = fminf(fmaxf((gx + 1.0f) * 0.5f * (float)(Wp - 1), 0.f), (float)(Wp - 1));
+      const float iy = fminf(fmaxf((gy + 1.0f) * 0.5f * (float)(Hp - 1), 0.f), (float)(Hp - 1));
+      const float x0f = floorf(ix), y0f = floorf(iy);
+      const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const int x1 = min(x0 + 1, Wp - 1), y1 = min(y0 + 1, Hp - 1);
+      const bf16_t* base = (const bf16_t*)a.planes[j * 3 + sc] + (int64_t)b * Hp * Wp * 64 + cgi * 8;
+      const bf16x8 t00 = *reinterpret_cast<const bf16x8*>(base + (y0 * Wp + x0) * 64), t01 = *reinterpret_cast<const bf16x8*>(base + (y0 * Wp + x1) * 64);
+      const bf16x8 t10 = *reinterpret_cast<const bf16x8*>(base + (y1 * Wp + x0) * 64), t11 = *reinterpret_cast<const bf16x8*>(base + (y1 * Wp + x1) * 64);
+      const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)t00[e] * w00 + (float)t01[e] * w01 + (float)t10[e] * w10 + (float)t11[e] * w11);
+    }
+    *reinterpret_cast<bf16x8*>(F + pi * MVV2_FP + cg * 8) = o;
+  }
+}
+
+__global__ void __launch_bounds__(512, 1) mlpv_v2_kernel(MlpVK a) {
+  constexpr int P = MVV2_P, MF = P / 16, NF = 2, FP = MVV2_FP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* X0 = (bf16_t*)smem;
+  bf16_t* X1 = X0 + P * FC2_XP;
+  bf16_t* F = X1 + P * FC2_XP;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g0 = 2 * wave, ch0 = 32 * wave + 8 * lg;   // this lane's eight channels: ch0 .. ch0 + 7
+  const int64_t tile0 = (int64_t)blockIdx.x * P;
+  const bf16_t* W = (const bf16_t*)a.w;
+  const float* fb = a.fb;
+
+  f32x4 acc[MF][NF], cst[NF];
+  bf16x8 wq[2][NF];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto wprime = [&](int off, int KS) { fc2_wload<NF>(W, off, KS, g0, 0, lane, wq[0]); };
+  auto cload = [&](const float* table) {
+    cst[0] = *reinterpret_cast<const f32x4*>(table + ch0);
+    cst[1] = *reinterpret_cast<const f32x4*>(table + ch0 + 4);
+  };
+  auto store8 = [&](bf16_t* Xout, int row, const f32x4& lo, const f32x4& hi) {
+    bf16x8 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q[e] = (bf16_t)lo[e];
+      q[4 + e] = (bf16_t)hi[e];
+    }
+    *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0) = q;
+  };
+  auto store_hidden = [&](bf16_t* Xout) {   // relu(acc + bias) -> Xout (rectified: fc_1 reads it as is)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] = fmaxf(acc[mf][0][e] + cst[0][e], 0.f);
+        hi[e] = fmaxf(acc[mf][1][e] + cst[1][e], 0.f);
+      }
+      store8(Xout, 16 * mf + lr, lo, hi);
+    }
+  };
+  // block output: x = acc (fc_1 + shortcut) + bias [+ identity x_in] -> Xout; slope 1 = raw, 0.2 = leaky_relu for net_out
+  auto store_block = [&](const bf16_t* Xid, bf16_t* Xout, float slope) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int row = 16 * mf + lr;
+      f32x4 lo = acc[mf][0], hi = acc[mf][1];
+      if (Xid != nullptr) {
+        const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Xid + row * FC2_XP + ch0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] += (float)xi[e];
+          hi[e] += (float)xi[4 + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] += cst[0][e];
+        hi[e] += cst[1][e];
+        lo[e] = lo[e] > 0.f ? lo[e] : lo[e] * slope;
+        hi[e] = hi[e] > 0.f ? hi[e] : hi[e] * slope;
+      }
+      store8(Xout, row, lo, hi);
+    }
+  };
+
+  // ================= block 1: x1 = RB(192 -> 256)(f0), hidden width 192 (waves 0..5) ===============================
+  wprime(mv_off(0), 6);
+  mvv2_gather(a, 0, tile0, F);
+  __syncthreads();
+  if (wave < 6) {
+    zero();
+    cload(fb + MV_B_R1FC0);
+    fc2_pass<MF, NF, 0, 192, FP, true>(X1, F, W, mv_off(0), g0, lane, wq, acc);    // fc_0(relu(f0)): 192 -> 192
+    store_hidden(X1);
+  }
+  wprime(mv_off(1), 6);
+  __syncthreads();
+  zero();
+  fc2_pass<MF, NF, 192, 0, FP, false>(X1, F, W, mv_off(1), g0, lane, wq, acc);       // fc_1(relu(net)): 192 -> 256
+  wprime(mv_off(2), 6);
+  cload(fb + MV_B(0));
+  fc2_pass<MF, NF, 0, 192, FP, false>(X0, F, W, mv_off(2), g0, lane, wq, acc);       // + shortcut(f0), bias-free
+  wprime(mv_off(3), 14);
+  store_block(nullptr, X0, 1.f);
+  __syncthreads();   // every wave is done with f0 and the hidden tile
+  mvv2_gather(a, 1, tile0, F);
+  __syncthreads();
+
+#define MVV2_BLOCK(IN, TMP, KF, m_fc0, m_fc1, m_sc, b_fc0, b_fc1, next_scale, next_off, next_KS, slope)               \
+  {                                                                                                                   \
+    zero();                                                                                                           \
+    cload(fb + MV_B(b_fc0));                                                                                          \
+    fc2_pass<MF, NF, 256, KF, FP, true>(IN, F, W, mv_off(m_fc0), g0, lane, wq, acc);      /* fc_0(relu([x | f])) */   \
+    wprime(mv_off(m_fc1), 8);                                                                                         \
+    store_hidden(TMP);                                                                                                \
+    __syncthreads();                                                                                                  \
+    zero();                                                                                                           \
+    cload(fb + MV_B(b_fc1));                                                                                          \
+    fc2_pass<MF, NF, 256, 0, FP, false>(TMP, F, W, mv_off(m_fc1), g0, lane, wq, acc);     /* fc_1(relu(net)) */       \
+    if ((m_sc) >= 0) wprime(mv_off((m_sc) >= 0 ? (m_sc) : 0), (256 + (KF)) / 32);                                     \
+    __syncthreads(); /* every wave has read the hidden tile: the block output goes there */                           \
+    if ((m_sc) >= 0)                                                                                                  \
+      fc2_pass<MF, NF, 256, KF, FP, false>(IN, F, W, mv_off((m_sc) >= 0 ? (m_sc) : 0), g0, lane, wq, acc);            \
+    if ((next_KS) > 0) wprime((next_off), (next_KS));                                                                 \
+    store_block((m_sc) >= 0 ? nullptr : IN, TMP, (slope));                                                            \
+    __syncthreads();                                                                                                  \
+    if ((next_scale) >= 0) {                                                                                          \
+      mvv2_gather(a, (next_scale), tile0, F);                                                                         \
+      __syncthreads();                                                                                                \
+    }                                                                                                                 \
+  }
+  MVV2_BLOCK(X0, X1, 192, 3, 4, 5, 1, 2, 2, mv_off(6), 14, 1.f);     // block 2: [x1 | f1] -> X1
+  MVV2_BLOCK(X1, X0, 192, 6, 7, 8, 3, 4, -1, mv_off(9), 8, 1.f);     // block 3: [x2 | f2] -> X0
+  MVV2_BLOCK(X0, X1, 0, 9, 10, -1, 5, 6, -1, 0, 0, 0.2f);            // block 4: identity; leaky_relu(x, 0.2) for net_out (mlp.py:153)
+#undef MVV2_BLOCK
+  // ================= net_out: 256 -> 3 (rows padded to 16): one 16-point fragment per wave (waves 0..5) =============
+  if (wave < MF) {
+    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(W + fc2_wfrag(mv_off(11), 8, 0, ks) + 8 * lane);
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(X1 + (16 * wave + lr) * FC2_XP + ks * 32 + 8 * lg);
+      r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, r, 0, 0, 0);
+    }
+    if (lg == 0) {  // lanes 0..15 hold output channels 0..3 of their point
+      const int64_t THW = (int64_t)a.T * a.H * a.W;
+      const int64_t gp = tile0 + 16 * wave + lr;
+      if (gp < a.total) {
+        const int64_t b = gp / THW, idx = gp - b * THW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.out[(b * 3 + c) * THW + idx] = r[c] + fb[MV_BOUT + c];
+      }
+    }
+  }
+}
+
+void mlpv_pack_fragment_order(const float* src, float* dst) {
+  for (int i = 0; i < 12; ++i) fc2_pack_matrix(src + mv_off(i), dst + mv_off(i), mv_rows(i), mv_k(i));
+}
+
 int launch_mlpv(const MlpVArgs& a, int dt, hipStream_t s) {
   MlpVK k{};
   for (int i = 0; i < 9; ++i) k.planes[i] = a.planes[i];
@@ -264,15 +461,14 @@ int launch_mlpv(const MlpVArgs& a, int dt, hipStream_t s) {
   for (int i = 0; i < 3; ++i)
     plane_bytes += (double)a.B * ((double)a.plane_hw[i] * a.plane_hw[i] + 2.0 * a.frames * a.plane_hw[i]) * 64 * dt_size(dt);
   PROF_SCOPE("mlpv_fused", 2.0 * 857088.0 * (double)k.total, plane_bytes + 12.0 * (double)k.total, s);
-  if (dt == DT_BF16) {
-    using L = MVL<bf16_t>;
-    size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(bf16_t);
+  if (dt == DT_BF16) {  // weights in fragment order (mlpv_pack_fragment_order)
+    const size_t lds = (size_t)(2 * MVV2_P * FC2_XP + MVV2_P * MVV2_FP) * sizeof(bf16_t);
     static bool set = false;
     if (!set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlpv_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlpv_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set = true;
     }
-    hipLaunchKernelGGL(mlpv_kernel<bf16_t>, dim3((unsigned)cdiv64(k.total, L::P)), dim3(256), lds, s, k);
+    hipLaunchKernelGGL(mlpv_v2_kernel, dim3((unsigned)cdiv64(k.total, MVV2_P)), dim3(512), lds, s, k);
   } else {
     using L = MVL<float>;
     size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(float);

@@ -156,6 +156,7 @@ struct Mlp3dArgs {
 int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s);
 size_t mlp3d_weight_elems();
 size_t mlp3d_fb_elems();
+void mlp3d_pack_fragment_order(const float* src_row_major, float* dst);   // bf16 handles (k_mlp3d.hip, mlp_fc2.h)
 
 // ---- fused tri-plane sampling + video MLP (MLPVideo) -------------------------------------------------------
 struct MlpVArgs {
@@ -171,3 +172,4 @@ struct MlpVArgs {
 int launch_mlpv(const MlpVArgs& a, int dt, hipStream_t s);
 size_t mlpv_weight_elems();
 size_t mlpv_fb_elems();
+void mlpv_pack_fragment_order(const float* src_row_major, float* dst);    // bf16 handles (k_mlpv.hip, mlp_fc2.h)

@@ -59,6 +59,11 @@ int mlp3d_finalize(Mlp3d& m) {
   std::memcpy(fb.data() + BP, bp->data.data(), 256 * sizeof(float));
   fb[BOUT] = bo->data[0];
 
+  if (m.dt == DT_BF16) {  // the bf16 kernel streams MFMA fragments
+    std::vector<float> Wf(W.size());
+    mlp3d_pack_fragment_order(W.data(), Wf.data());
+    W.swap(Wf);
+  }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, W.size() * dt_size(m.dt)));
   m.dev_allocs.push_back(p);

@@ -49,6 +49,11 @@ int mlpv_finalize(MlpV& m) {
     DDMI_TRY(get(b.key, b.n, &t));
     std::memcpy(fb.data() + b.off, t->data.data(), (size_t)b.n * sizeof(float));
   }
+  if (m.dt == DT_BF16) {  // the bf16 kernel streams MFMA fragments
+    std::vector<float> Wf(W.size());
+    mlpv_pack_fragment_order(W.data(), Wf.data());
+    W.swap(Wf);
+  }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, W.size() * dt_size(m.dt)));
   m.dev_allocs.push_back(p);
