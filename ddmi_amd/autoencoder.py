@@ -70,7 +70,7 @@ def decoder_manifest(ddconfig, embed_dim) -> List[Tuple[str, Tuple[int, ...]]]:
 
 
 class Autoencoder:
-    def __init__(self, ddconfig, embed_dim, image_key="image", numerics="bf16", max_batch=8):
+    def __init__(self, ddconfig, embed_dim, image_key="image", numerics="bf16", max_batch=8, latent_size=None):
         self.ddconfig = {k: (list(v) if isinstance(v, (list, tuple)) or type(v).__name__ == "ListConfig" else v)
                          for k, v in dict(ddconfig).items()}
         if self.ddconfig.get("attn_type", "vanilla") != "vanilla":
@@ -78,6 +78,9 @@ class Autoencoder:
         self.embed_dim = int(embed_dim)
         self.numerics = _lib.numerics_code(numerics)
         self.max_batch = int(max_batch)
+        # the reference decoder is fully convolutional; the native handle plans its arena for one latent size: by default
+        # resolution / 2^(levels-1) (autoencoder_unet.py:745-747), or the size the sampler produces (config 1: 16x16)
+        self.latent_size = int(latent_size) if latent_size else self.ddconfig["resolution"] // 2 ** (len(self.ddconfig["ch_mult"]) - 1)
         self._state: Dict[str, np.ndarray] = {}
         self._handle = None
         self.plane_hw: List[int] = []
@@ -141,7 +144,7 @@ class Autoencoder:
         cfg.n_hdbf = len(hr)
         for i, a in enumerate(hr):
             cfg.hdbf_resolutions[i] = int(a)
-        cfg.latent_size = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
+        cfg.latent_size = self.latent_size
         cfg.max_batch, cfg.numerics = self.max_batch, self.numerics
         h = C.c_void_p()
         _lib.check(L.ddmi_decoder2d_create(C.byref(cfg), C.byref(h)))
@@ -162,6 +165,8 @@ class Autoencoder:
     def decode(self, z, reference_layout: bool = False):
         import torch
         assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 4
+        if z.shape[2] != self.latent_size or z.shape[3] != self.latent_size:
+            raise ValueError(f"this decoder handle was planned for {self.latent_size}x{self.latent_size} latents, got {tuple(z.shape[2:])}")
         self.finalize(z.device.index or 0)
         z = z.contiguous()
         B, oc = z.shape[0], self.ddconfig["out_ch"]

@@ -443,12 +443,15 @@ int decoder2d_finalize(Decoder2d& d) {
   const ddmi_decoder2d_cfg& c = d.cfg;
   DDMI_REQUIRE(c.n_mult >= 1 && c.n_mult <= 8, "bad ch_mult");
   const int nres = c.n_mult;
+  // `curr` is the NOMINAL resolution of a level (what attn_resolutions / hdbf_resolutions are matched against,
+  // autoencoder_unet.py:745-747, 790-829); the tensors have the size of the latent that is actually fed (the decoder is
+  // fully convolutional: BASELINE config 1 decodes a 16x16 latent with the 256-anchored AFHQ decoder)
   int curr = c.resolution >> (nres - 1);
-  DDMI_REQUIRE(c.latent_size == curr, "latent_size must equal resolution / 2^(len(ch_mult)-1)");
+  DDMI_REQUIRE(c.latent_size >= 1 && c.latent_size <= 4096, "bad latent_size");
   Op in;
   in.kind = OP_NCHW_IN;
   in.ext = 0;
-  in.out = n.new_tensor(c.embed_dim, curr, curr);
+  in.out = n.new_tensor(c.embed_dim, c.latent_size, c.latent_size);
   n.ops.push_back(in);
   int cpq, cin_;
   DDMI_TRY(n.make_conv("post_quant_conv.weight", "post_quant_conv.bias", &cpq));

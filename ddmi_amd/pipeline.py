@@ -48,12 +48,15 @@ class ImagePipeline:
         self.device = device
         self.numerics = numerics
         self.max_batch = int(max_batch)
-        self.unet = UNetModel(**dict(unetconfig), numerics=numerics, max_batch=max_batch)
-        self.vae = Autoencoder(ddconfig, embed_dim, numerics=numerics, max_batch=max_batch)
+        self.latent_size = int(ddpmconfig.get("image_size", unetconfig["image_size"]))
+        # the reference's UNet is fully convolutional and never reads `image_size` in forward; the native handle plans its
+        # arena for one resolution, so it is built for the latent the sampler will feed it (ddpmconfig.image_size) - e.g.
+        # BASELINE config 1 runs the AFHQ nets (image_size 64) on a 16x16 latent
+        self.unet = UNetModel(**dict(unetconfig, image_size=self.latent_size), numerics=numerics, max_batch=max_batch)
+        self.vae = Autoencoder(ddconfig, embed_dim, numerics=numerics, max_batch=max_batch, latent_size=self.latent_size)
         self.mlp = MLP(**dict(mlpconfig), numerics=numerics)
         self.ddpm = DDPM(model=self.unet, **dict(ddpmconfig))
         self.embed_dim = int(embed_dim)
-        self.latent_size = int(ddpmconfig.get("image_size", unetconfig["image_size"]))
         self.test_resolution = int(test_resolution)
         self._coords = None
 

@@ -213,6 +213,9 @@ class UNetModel:
         import torch
         assert context is None and y is None, "unconditional sampling only (ddpm.py:304-308)"
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
+            raise ValueError(f"this UNetModel handle was planned for {self.image_size}x{self.image_size} inputs, got "
+                             f"{tuple(x.shape[2:])}: construct it with image_size = the latent size")
         self.finalize(x.device.index or 0)
         x = x.contiguous()
         t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
