@@ -128,6 +128,24 @@ SYMBOLS = {
     "ddmi_mcubes_count": (_I, [C.POINTER(McubesGrid), _VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _VP]),
     "ddmi_mcubes_emit": (_I, [C.POINTER(McubesGrid), _VP, _VP, _VP, _I, C.c_double, _VP]),
     "ddmi_image_to_u8": (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
+    # training (include/ddmi_hip.h "Training")
+    "ddmi_train_create": (_I, [_I, C.POINTER(_VP)]),
+    "ddmi_train_destroy": (_I, [_VP]),
+    "ddmi_train_to_nhwc": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    "ddmi_train_to_nchw": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    "ddmi_train_conv_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP, _VP] + [_I] * 8 + [_VP]),
+    "ddmi_train_conv_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP] + [_I] * 8 + [_VP]),
+    "ddmi_train_gn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _VP]),
+    "ddmi_train_gn_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_attn_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_attn_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_linear_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_linear_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_timestep_embedding": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
+    "ddmi_train_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _I, C.c_int64, _VP]),
+    "ddmi_train_eps_loss": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "ddmi_train_adamw": (_I, [_VP, _VP, _VP, _VP, C.c_int64, _F, _F, _F, _F, _F, _I, _F, _VP]),
+    "ddmi_train_ema": (_I, [_VP, _VP, C.c_int64, _F, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -181,6 +181,8 @@ static int gn_splits(int B, int HW) {
   return std::max(1, std::min(std::min(want, HW / 16), GN_MAXSPLIT));
 }
 
+int gn_nsplit(int B, int HW) { return gn_splits(B, HW); }
+
 int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg, int nseg,
                     const void* x2, int C1) {
   DDMI_REQUIRE(nseg >= 1 && nseg <= 3 && seg >= 0 && seg < nseg, "groupnorm: bad segment index");

@@ -1,0 +1,576 @@
+// Kernels of the LDM training step (tools/ldm/image.py:136-178, diffusion/ddpm.py:383-454): what the
+// backward pass needs beyond the forward kernels.  First slice: every op is correct in both numerics modes and MFMA-backed
+// where the FLOPs are (both convolution gradients run on the forward implicit-GEMM kernels of k_conv.hip); the HBM-bound
+// helpers and the attention / GroupNorm gradients are plain kernels, not yet tuned against their rooflines.
+//
+//   conv  y = conv(up?(x), W) + b + emb[b] + res
+//     dgrad : dX = conv(dY', W^T flipped) - the forward kernel on re-packed weights [Cin][k*k flipped][Cout];
+//             stride 2: dY' = dY with zeros inserted (the gradient of a strided gather), nearest-x2 input: 2x2 sum-pool
+//     wgrad : dW[co][tap, ci] = sum_p dY[p][co] X_col[p][tap, ci] = the forward kernel as a plain GEMM over the pixel
+//             axis (dY^T and the transposed im2col image are both pixel-contiguous), split-K in fp32 slabs
+//     dbias / demb : per-(sample, channel) sums of dY
+//   GroupNorm(32)+SiLU, QKVAttentionLegacy, the small time-embedding linears: reference formulas, fp32 math
+//   q_sample, mixed-prediction MSE loss + its gradient, AdamW
+#include "kernels.h"
+#include "prof.h"
+
+#define TR_GROUPS 32
+
+template <typename T> __device__ __forceinline__ float tr_ld(const T* p) { return to_f32(*p); }
+template <typename T> __device__ __forceinline__ void tr_st(T* p, float v) { *p = from_f32<T>(v); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// convolution gradients: layout helpers
+// ---------------------------------------------------------------------------------------------------------------------
+// master fp32 [Co][Ci][k][k] -> packed forward-kernel layout [Ci][k*k][Co] of the TRANSPOSED, spatially flipped filter
+template <typename T>
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int k) {
+  const int kk = k * k;
+  const int64_t n = (int64_t)Co * Ci * kk;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Co);
+    const int tp = (int)((i / Co) % kk);
+    const int ci = (int)(i / ((int64_t)Co * kk));
+    const int kh = k - 1 - tp / k, kw = k - 1 - tp % k;
+    out[i] = from_f32<T>(w[(((int64_t)co * Ci + ci) * k + kh) * k + kw]);
+  }
+}
+
+// u[b][2i][2j][c] = dy[b][i][j][c], 0 elsewhere  (u is [B][2Ho][2Wo][C])
+template <typename T>
+__global__ void zero_insert2x_kernel(const T* __restrict__ dy, T* __restrict__ u, int B, int Ho, int Wo, int C) {
+  const int64_t n = (int64_t)B * 4 * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int w = (int)(pix % (2 * Wo)), h = (int)((pix / (2 * Wo)) % (2 * Ho));
+    const int b = (int)(pix / ((int64_t)4 * Ho * Wo));
+    float v = 0.f;
+    if (!(h & 1) && !(w & 1)) v = tr_ld(dy + (((int64_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c);
+    tr_st(u + i, v);
+  }
+}
+
+// dx[b][i][j][c] = sum of the 2x2 block of up[b][2i..2i+1][2j..2j+1][c]  (gradient of nearest x2)
+template <typename T>
+__global__ void sumpool2x_kernel(const T* __restrict__ up, T* __restrict__ dx, int B, int H, int W, int C) {
+  const int64_t n = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const int b = (int)(pix / ((int64_t)H * W));
+    const T* p = up + (((int64_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
+    const float v = tr_ld(p) + tr_ld(p + C) + tr_ld(p + (int64_t)2 * W * C) + tr_ld(p + (int64_t)2 * W * C + C);
+    tr_st(dx + i, v);
+  }
+}
+
+// transposed im2col: out[(tap * Ci + ci)][p] = xin[b][oh*stride - pad + kh][ow*stride - pad + kw][ci], xin = nearest-x2(x)
+// when ups; p = (b*Ho + oh)*Wo + ow; zero outside the image.  Tiles of 32 pixels x 32 channels go through LDS so both the
+// reads (channel-contiguous) and the writes (pixel-contiguous) are coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_t_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int Ci,
+                                                      int Ho, int Wo, int k, int stride, int pad, int ups) {
+  __shared__ float tile[32][33];
+  const int64_t P = (int64_t)B * Ho * Wo;
+  const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int Hin = ups ? 2 * H : H, Win = ups ? 2 * W : W;
+  for (int r = ty; r < 32; r += 8) {   // r = pixel within the tile, tx = channel
+    const int64_t p = p0 + r;
+    float v = 0.f;
+    if (p < P && c0 + tx < Ci) {
+      const int ow = (int)(p % Wo), oh = (int)((p / Wo) % Ho);
+      const int b = (int)(p / ((int64_t)Ho * Wo));
+      int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+      if (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) {
+        if (ups) { ih >>= 1; iw >>= 1; }
+        v = tr_ld(x + (((int64_t)b * H + ih) * W + iw) * Ci + c0 + tx);
+      }
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {   // r = channel within the tile, tx = pixel
+    const int64_t p = p0 + tx;
+    if (p < P && c0 + r < Ci) tr_st(out + ((int64_t)tap * Ci + c0 + r) * P + p, tile[tx][r]);
+  }
+}
+
+// dw[co][ci][kh][kw] = G[tap * Ci + ci][co]   (G = the fp32 output of the pixel-axis GEMM, [taps * Ci][Co])
+__global__ void wgrad_finish_kernel(const float* __restrict__ G, float* __restrict__ dw, int Co, int Ci, int kk) {
+  const int64_t n = (int64_t)Co * Ci * kk;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % kk);
+    const int ci = (int)((i / kk) % Ci);
+    const int co = (int)(i / ((int64_t)kk * Ci));
+    dw[i] = G[((int64_t)tap * Ci + ci) * Co + co];
+  }
+}
+
+// out[b][c] = sum over HW of dy[b][hw][c]   (grid (ceil(C/64), B), block 256 = 64 channels x 4 pixel lanes)
+template <typename T>
+__global__ void __launch_bounds__(256) sum_hw_kernel(const T* __restrict__ dy, float* __restrict__ out, int HW, int C) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (int p = lane; p < HW; p += 4) acc += tr_ld(dy + ((int64_t)b * HW + p) * C + c);
+  red[lane][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (lane == 0 && c < C) out[(int64_t)b * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[c] = sum_b in[b][c]
+__global__ void sum_b_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += in[(int64_t)b * C + c];
+  out[c] = acc;
+}
+
+static inline int tr_blocks(int64_t n) { return (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16); }
+
+int launch_pack_dgrad_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s) {
+  const int64_t n = (int64_t)Co * Ci * k * k;
+  if (dt == DT_F32) hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, w, (float*)out, Co, Ci, k);
+  else hipLaunchKernelGGL(pack_dgrad_weight_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, k);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo, int C, hipStream_t s) {
+  const int64_t n = (int64_t)B * 4 * Ho * Wo * C;
+  if (dt == DT_F32) hipLaunchKernelGGL(zero_insert2x_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)dy, (float*)u, B, Ho, Wo, C);
+  else hipLaunchKernelGGL(zero_insert2x_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)u, B, Ho, Wo, C);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_sumpool2x(const void* up, void* dx, int dt, int B, int H, int W, int C, hipStream_t s) {
+  const int64_t n = (int64_t)B * H * W * C;
+  if (dt == DT_F32) hipLaunchKernelGGL(sumpool2x_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)up, (float*)dx, B, H, W, C);
+  else hipLaunchKernelGGL(sumpool2x_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, (const bf16_t*)up, (bf16_t*)dx, B, H, W, C);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int Ci, int Ho, int Wo, int k, int stride, int pad, int ups,
+                    hipStream_t s) {
+  const int64_t P = (int64_t)B * Ho * Wo;
+  dim3 g((unsigned)cdiv64(P, 32), (unsigned)cdiv(Ci, 32), (unsigned)(k * k));
+  if (dt == DT_F32) hipLaunchKernelGGL(im2col_t_kernel<float>, g, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
+  else hipLaunchKernelGGL(im2col_t_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(tr_blocks((int64_t)Co * Ci * kk)), dim3(256), 0, s, G, dw, Co, Ci, kk);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_sum_hw(const void* dy, float* out, int dt, int B, int HW, int C, hipStream_t s) {
+  dim3 g((unsigned)cdiv(C, 64), (unsigned)B);
+  if (dt == DT_F32) hipLaunchKernelGGL(sum_hw_kernel<float>, g, dim3(256), 0, s, (const float*)dy, out, HW, C);
+  else hipLaunchKernelGGL(sum_hw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)dy, out, HW, C);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s) {
+  hipLaunchKernelGGL(sum_b_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, in, out, B, C);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm(32) [+ SiLU] backward.  mr = saved [B][32][2] (mean, rstd) of the forward.
+//   x^ = (x - mean) rstd ; z = gamma x^ + beta ; y = silu?(z)
+//   dz = dy silu'(z) ; dgamma = sum dz x^ ; dbeta = sum dz ; dx^ = dz gamma
+//   dx = rstd (dx^ - mean_g(dx^) - x^ mean_g(dx^ x^))
+// pass 1, grid (32, B): a thread owns ONE channel of the group for a fixed set of pixels -> per-channel and per-group sums
+// reduced through LDS in a fixed order (no atomics: deterministic)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tr_dsilu(float z) {
+  const float sg = 1.0f / (1.0f + expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mr,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ ab, float* __restrict__ dgp, float* __restrict__ dbp,
+                                                           int HW, int C, int silu) {
+  extern __shared__ float red[];   // [4][256]: dgamma, dbeta, A, Bs partials per thread
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / TR_GROUPS;
+  const int L = 256 / cpg;                      // pixel lanes
+  const int cc = threadIdx.x % cpg, lane = threadIdx.x / cpg;
+  const int c = g * cpg + cc;
+  const float mean = mr[((int64_t)b * TR_GROUPS + g) * 2], rstd = mr[((int64_t)b * TR_GROUPS + g) * 2 + 1];
+  float sdg = 0.f, sdb = 0.f, sA = 0.f, sB = 0.f;
+  if (lane < L) {
+    const float ga = gamma[c], be = beta[c];
+    for (int p = lane; p < HW; p += L) {
+      const int64_t o = ((int64_t)b * HW + p) * C + c;
+      const float xh = (tr_ld(x + o) - mean) * rstd;
+      float dz = tr_ld(dy + o);
+      if (silu) dz *= tr_dsilu(ga * xh + be);
+      sdg += dz * xh;
+      sdb += dz;
+      const float dxh = dz * ga;
+      sA += dxh;
+      sB += dxh * xh;
+    }
+  }
+  red[threadIdx.x] = sdg; red[256 + threadIdx.x] = sdb; red[512 + threadIdx.x] = sA; red[768 + threadIdx.x] = sB;
+  __syncthreads();
+  if (threadIdx.x < cpg) {   // per-channel sums over the pixel lanes
+    float a = 0.f, d = 0.f;
+    for (int l = 0; l < L; ++l) { a += red[l * cpg + threadIdx.x]; d += red[256 + l * cpg + threadIdx.x]; }
+    dgp[(int64_t)b * C + g * cpg + threadIdx.x] = a;
+    dbp[(int64_t)b * C + g * cpg + threadIdx.x] = d;
+  }
+  if (threadIdx.x == 0) {
+    double a = 0.0, d = 0.0;
+    for (int t = 0; t < L * cpg; ++t) { a += red[512 + t]; d += red[768 + t]; }
+    const double n = (double)HW * cpg;
+    ab[((int64_t)b * TR_GROUPS + g) * 2] = (float)(a / n);
+    ab[((int64_t)b * TR_GROUPS + g) * 2 + 1] = (float)(d / n);
+  }
+}
+
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mr,
+                                    const float* __restrict__ ab, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    T* __restrict__ dx, int64_t n, int HW, int C, int silu) {
+  const int cpg = C / TR_GROUPS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    const int g = c / cpg;
+    const float mean = mr[((int64_t)b * TR_GROUPS + g) * 2], rstd = mr[((int64_t)b * TR_GROUPS + g) * 2 + 1];
+    const float mA = ab[((int64_t)b * TR_GROUPS + g) * 2], mB = ab[((int64_t)b * TR_GROUPS + g) * 2 + 1];
+    const float ga = gamma[c];
+    const float xh = (tr_ld(x + i) - mean) * rstd;
+    float dz = tr_ld(dy + i);
+    if (silu) dz *= tr_dsilu(ga * xh + beta[c]);
+    tr_st(dx + i, rstd * (dz * ga - mA - xh * mB));
+  }
+}
+
+int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
+                       float* dgamma, float* dbeta, float* scratch /* [B*32*2 + 2*B*C] */, int dt, int B, int HW, int C, int silu,
+                       hipStream_t s) {
+  DDMI_REQUIRE(C % TR_GROUPS == 0 && C / TR_GROUPS <= 256, "gn_backward: C must be a multiple of 32 with at most 256 channels per group");
+  float* ab = scratch;
+  float* dgp = ab + (size_t)B * TR_GROUPS * 2;
+  float* dbp = dgp + (size_t)B * C;
+  dim3 g(TR_GROUPS, B);
+  const size_t lds = 4 * 256 * sizeof(float);
+  const int64_t n = (int64_t)B * HW * C;
+  if (dt == DT_F32) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, g, dim3(256), lds, s, (const float*)x, (const float*)dy, meanrstd, gamma, beta, ab, dgp, dbp, HW, C, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)x, (const float*)dy, meanrstd, ab, gamma, beta,
+                       (float*)dx, n, HW, C, silu);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, g, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, gamma, beta, ab, dgp, dbp, HW, C, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, ab, gamma, beta,
+                       (bf16_t*)dx, n, HW, C, silu);
+  }
+  HIP_TRY(hipGetLastError());
+  DDMI_TRY(launch_sum_b(dgp, dgamma, B, C, s));
+  DDMI_TRY(launch_sum_b(dbp, dbeta, B, C, s));
+  return DDMI_OK;
+}
+
+// saved statistics of the forward: (mean, rstd) per (sample, group) from the partial sums launch_gn_stats wrote
+__global__ void gn_meanrstd_kernel(const double* __restrict__ part, float* __restrict__ mr, int nsplit, int maxsplit, double cnt, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= TR_GROUPS) return;
+  const double* p = part + (int64_t)b * maxsplit * (TR_GROUPS * 2) + g * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nsplit; ++i) { s1 += p[(int64_t)i * (TR_GROUPS * 2)]; s2 += p[(int64_t)i * (TR_GROUPS * 2) + 1]; }
+  const double m = s1 / cnt;
+  double var = s2 / cnt - m * m;
+  if (var < 0) var = 0;
+  mr[((int64_t)b * TR_GROUPS + g) * 2] = (float)m;
+  mr[((int64_t)b * TR_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+int launch_gn_meanrstd(const double* part, float* mr, int B, int HW, int C, float eps, int nsplit, hipStream_t s) {
+  hipLaunchKernelGGL(gn_meanrstd_kernel, dim3(B), dim3(64), 0, s, part, mr, nsplit, 64, (double)HW * (C / TR_GROUPS), eps);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// QKVAttentionLegacy backward (openaimodel.py:397-426): per (sample, head), logits s_ij = (q_i . k_j) / sqrt(d),
+// p = softmax_j(s), o_i = sum_j p_ij v_j.
+//   D_i = dO_i . O_i ; dP_ij = dO_i . v_j ; dS_ij = p_ij (dP_ij - D_i)
+//   dQ_i = sum_j dS_ij k_j / sqrt(d) ; dK_j = sum_i dS_ij q_i / sqrt(d) ; dV_j = sum_i p_ij dO_i
+// Rows of qkv: [q(d) | k(d) | v(d)] per head (the legacy per-head interleave).  One thread per query row (dq kernel) /
+// key row (dkv kernel); the other side's rows are read wave-uniformly.  fp32 math; probabilities are recomputed from the
+// row log-sum-exp.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ void __launch_bounds__(128) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ dout,
+                                                         T* __restrict__ dqkv, float* __restrict__ lse, float* __restrict__ dsum,
+                                                         int Tn, int heads) {
+  const int b = blockIdx.z, h = blockIdx.y, i = blockIdx.x * 128 + threadIdx.x;
+  const int ld = heads * 3 * D, ldo = heads * D;
+  const float scale = rsqrtf((float)D);
+  const T* base = qkv + (int64_t)b * Tn * ld + h * 3 * D;
+  const bool live = i < Tn;
+  const int ii = live ? i : Tn - 1;
+  float q[D], go[D], dq[D];
+  float dsm = 0.f;
+#pragma unroll
+  for (int e = 0; e < D; ++e) {
+    q[e] = tr_ld(base + (int64_t)ii * ld + e) * scale;
+    go[e] = tr_ld(dout + ((int64_t)b * Tn + ii) * ldo + h * D + e);
+    dsm += go[e] * tr_ld(o + ((int64_t)b * Tn + ii) * ldo + h * D + e);
+    dq[e] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < Tn; ++j) {   // online log-sum-exp
+    const T* kr = base + (int64_t)j * ld + D;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < D; ++e) s += q[e] * tr_ld(kr + e);
+    const float mn = fmaxf(m, s);
+    l = l * expf(m - mn) + expf(s - mn);
+    m = mn;
+  }
+  const float L = m + logf(l);
+  for (int j = 0; j < Tn; ++j) {
+    const T* kr = base + (int64_t)j * ld + D;
+    const T* vr = kr + D;
+    float s = 0.f, dp = 0.f;
+    float kk[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) {
+      kk[e] = tr_ld(kr + e);
+      s += q[e] * kk[e];
+      dp += go[e] * tr_ld(vr + e);
+    }
+    const float ds = expf(s - L) * (dp - dsm) * scale;
+#pragma unroll
+    for (int e = 0; e < D; ++e) dq[e] += ds * kk[e];
+  }
+  if (live) {
+    lse[((int64_t)b * heads + h) * Tn + i] = L;
+    dsum[((int64_t)b * heads + h) * Tn + i] = dsm;
+    T* dst = dqkv + ((int64_t)b * Tn + i) * ld + h * 3 * D;
+#pragma unroll
+    for (int e = 0; e < D; ++e) tr_st(dst + e, dq[e]);
+  }
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(128) attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
+                                                          const float* __restrict__ lse, const float* __restrict__ dsum, int Tn, int heads) {
+  const int b = blockIdx.z, h = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
+  const int ld = heads * 3 * D, ldo = heads * D;
+  const float scale = rsqrtf((float)D);
+  const T* base = qkv + (int64_t)b * Tn * ld + h * 3 * D;
+  const bool live = j < Tn;
+  const int jj = live ? j : Tn - 1;
+  float k[D], v[D], dk[D], dv[D];
+#pragma unroll
+  for (int e = 0; e < D; ++e) {
+    k[e] = tr_ld(base + (int64_t)jj * ld + D + e);
+    v[e] = tr_ld(base + (int64_t)jj * ld + 2 * D + e);
+    dk[e] = dv[e] = 0.f;
+  }
+  const float* Lr = lse + ((int64_t)b * heads + h) * Tn;
+  const float* Dr = dsum + ((int64_t)b * heads + h) * Tn;
+  for (int i = 0; i < Tn; ++i) {
+    const T* qr = base + (int64_t)i * ld;
+    const T* gr = dout + ((int64_t)b * Tn + i) * ldo + h * D;
+    float s = 0.f, dp = 0.f, qq[D], go[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) {
+      qq[e] = tr_ld(qr + e);
+      go[e] = tr_ld(gr + e);
+      s += qq[e] * k[e];
+      dp += go[e] * v[e];
+    }
+    const float p = expf(s * scale - Lr[i]);
+    const float ds = p * (dp - Dr[i]) * scale;
+#pragma unroll
+    for (int e = 0; e < D; ++e) {
+      dv[e] += p * go[e];
+      dk[e] += ds * qq[e];
+    }
+  }
+  if (live) {
+    T* dst = dqkv + ((int64_t)b * Tn + j) * ld + h * 3 * D;
+#pragma unroll
+    for (int e = 0; e < D; ++e) {
+      tr_st(dst + D + e, dk[e]);
+      tr_st(dst + 2 * D + e, dv[e]);
+    }
+  }
+}
+
+int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch /* 2*B*heads*T */,
+                                     int dt, int B, int T, int heads, int d, hipStream_t s) {
+  DDMI_REQUIRE(d == 32, "attention backward: head dim 32 (num_head_channels of every DDMI config)");
+  float* lse = scratch;
+  float* dsum = scratch + (size_t)B * heads * T;
+  dim3 g((unsigned)cdiv(T, 128), (unsigned)heads, (unsigned)B);
+  PROF_SCOPE("attention_legacy_bwd", 2.0 * 5.0 * B * heads * (double)T * T * d, 0, s);
+  if (dt == DT_F32) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<float, 32>), g, dim3(128), 0, s, (const float*)qkv, (const float*)out, (const float*)dout, (float*)dqkv, lse, dsum, T, heads);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 32>), g, dim3(128), 0, s, (const float*)qkv, (const float*)dout, (float*)dqkv, lse, dsum, T, heads);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, 32>), g, dim3(128), 0, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, T, heads);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16_t, 32>), g, dim3(128), 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, T, heads);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small fp32 linears of the time-embedding path: y = act(x) W^T + b, act = SiLU when silu_in (launch_linear_small forward)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
+                                     float* __restrict__ dx, int B, int K, int N, int silu_in) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (k >= K) return;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc += dy[(int64_t)b * N + n] * W[(int64_t)n * K + k];
+  if (silu_in) acc *= tr_dsilu(x[(int64_t)b * K + k]);
+  dx[(int64_t)b * K + k] = acc;
+}
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
+                                     float* __restrict__ db, int B, int K, int N, int silu_in) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (k >= K) return;
+  float acc = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float a = x[(int64_t)b * K + k];
+    if (silu_in) a = a / (1.0f + expf(-a));
+    const float g = dy[(int64_t)b * N + n];
+    acc += g * a;
+    sb += g;
+  }
+  dW[(int64_t)n * K + k] = acc;
+  if (k == 0 && db) db[n] = sb;
+}
+int launch_linear_small_backward(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K, int N,
+                                 int silu_in, hipStream_t s) {
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(K, 128), B), dim3(128), 0, s, x, W, dy, dx, B, K, N, silu_in);
+  hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(K, 128), N), dim3(128), 0, s, x, dy, dW, db, B, K, N, silu_in);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DDPM training arithmetic (ddpm.py:383-386, 409-447) and the optimizer
+// ---------------------------------------------------------------------------------------------------------------------
+// x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) noise, per-sample coefficients  (q_sample)
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ a,
+                                const float* __restrict__ sg, float* __restrict__ out, int64_t per, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    out[i] = a[b] * x0[i] + sg[b] * noise[i];
+  }
+}
+int launch_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* out, int B, int64_t per,
+                    hipStream_t s) {
+  const int64_t n = (int64_t)B * per;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, x0, noise, sqrt_ac, sqrt_1mac, out, per, n);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// eps^ = (1 - c) sqrt(1-abar_t) x_t + c model_out, c = sigmoid(logit[ch]) (get_mixed_prediction, ddpm.py:469-477);
+// loss = mean((eps^ - noise)^2) (mse over [1,2,3] then over the batch: equal sizes -> the global mean, ddpm.py:436-439);
+// d_model_out = c g, d_logit[ch] = sum g (model_out - m) c (1 - c), g = 2 (eps^ - noise) / N.
+// grid (C, B): one block per (sample, channel) plane; partials are summed in a fixed order by eps_loss_finish_kernel.
+__global__ void __launch_bounds__(256) eps_loss_kernel(const float* __restrict__ mo, const float* __restrict__ xt, const float* __restrict__ noise,
+                                                      const float* __restrict__ sg, const float* __restrict__ logit, float* __restrict__ dmo,
+                                                      float* __restrict__ part /* [B][C][2] */, int C, int HW, float inv_n) {
+  __shared__ float r1[256], r2[256];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float coef = logit ? 1.0f / (1.0f + expf(-logit[c])) : 1.0f;
+  const float s1 = sg[b];
+  const int64_t base = ((int64_t)b * C + c) * HW;
+  float sl = 0.f, sd = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const float m = s1 * xt[base + p], o = mo[base + p];
+    const float e = logit ? (1.0f - coef) * m + coef * o : o;
+    const float df = e - noise[base + p];
+    sl += df * df;
+    const float g = 2.0f * df * inv_n;
+    dmo[base + p] = coef * g;
+    sd += g * (o - m) * coef * (1.0f - coef);
+  }
+  r1[threadIdx.x] = sl; r2[threadIdx.x] = sd;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) { r1[threadIdx.x] += r1[threadIdx.x + st]; r2[threadIdx.x] += r2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[((int64_t)b * C + c) * 2] = r1[0]; part[((int64_t)b * C + c) * 2 + 1] = r2[0]; }
+}
+__global__ void eps_loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss, float* __restrict__ dlogit, int B, int C,
+                                       float inv_n) {
+  const int c = threadIdx.x;
+  __shared__ double tot[1024];
+  double l = 0.0;
+  float d = 0.f;
+  if (c < C)
+    for (int b = 0; b < B; ++b) { l += part[((int64_t)b * C + c) * 2]; d += part[((int64_t)b * C + c) * 2 + 1]; }
+  tot[c] = l;
+  if (c < C && dlogit) dlogit[c] = d;
+  __syncthreads();
+  if (c == 0) {
+    double s = 0.0;
+    for (int i = 0; i < C; ++i) s += tot[i];
+    *loss = (float)(s * inv_n);
+  }
+}
+int launch_eps_loss(const float* model_out, const float* x_t, const float* noise, const float* sqrt_1mac, const float* logit, float* loss,
+                    float* d_model_out, float* d_logit, float* scratch /* 2*B*C */, int B, int C, int HW, hipStream_t s) {
+  DDMI_REQUIRE(C <= 1024, "eps_loss: at most 1024 channels");
+  const float inv_n = (float)(1.0 / ((double)B * C * HW));
+  hipLaunchKernelGGL(eps_loss_kernel, dim3(C, B), dim3(256), 0, s, model_out, x_t, noise, sqrt_1mac, logit, d_model_out, scratch, C, HW, inv_n);
+  hipLaunchKernelGGL(eps_loss_finish_kernel, dim3(1), dim3(1024), 0, s, scratch, loss, d_logit, B, C, inv_n);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// torch.optim.AdamW (decoupled weight decay, bias-corrected moments), one pass over a flat fp32 parameter slab
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                 float grad_scale, hipStream_t s) {
+  DDMI_REQUIRE(step >= 1, "adamw: step counts from 1");
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), grad_scale);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// ema_pytorch's update (tools/ldm/image.py:64, 174): ema = ema * decay + param * (1 - decay)  (torch.lerp form)
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n, float decay) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    ema[i] = ema[i] + (p[i] - ema[i]) * (1.0f - decay);
+}
+int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s) {
+  hipLaunchKernelGGL(ema_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, ema, p, n, decay);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

@@ -173,3 +173,28 @@ int launch_mlpv(const MlpVArgs& a, int dt, hipStream_t s);
 size_t mlpv_weight_elems();
 size_t mlpv_fb_elems();
 void mlpv_pack_fragment_order(const float* src_row_major, float* dst);    // bf16 handles (k_mlpv.hip, mlp_fc2.h)
+
+// ---- LDM training step (k_train.hip): what the backward pass needs beyond the forward kernels -------------------------
+int launch_pack_dgrad_weight(const float* w_oihw, void* out, int dt, int Co, int Ci, int k, hipStream_t s);   // -> [Ci][k*k flipped][Co]
+int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo, int C, hipStream_t s);
+int launch_sumpool2x(const void* up, void* dx, int dt, int B, int H, int W, int C, hipStream_t s);
+int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int Ci, int Ho, int Wo, int k, int stride, int pad, int ups,
+                    hipStream_t s);   // out [(tap * Ci + ci)][B * Ho * Wo]
+int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, hipStream_t s);
+int launch_sum_hw(const void* dy, float* out, int dt, int B, int HW, int C, hipStream_t s);   // out [B][C]
+int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s);
+int launch_gn_meanrstd(const double* part, float* mr, int B, int HW, int C, float eps, int nsplit, hipStream_t s);
+int gn_nsplit(int B, int HW);   // the split count launch_gn_stats uses (k_groupnorm.hip)
+int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
+                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s);
+int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch, int dt, int B,
+                                     int T, int heads, int d, hipStream_t s);
+int launch_linear_small_backward(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K, int N,
+                                 int silu_in, hipStream_t s);
+int launch_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* out, int B, int64_t per,
+                    hipStream_t s);
+int launch_eps_loss(const float* model_out, const float* x_t, const float* noise, const float* sqrt_1mac, const float* logit, float* loss,
+                    float* d_model_out, float* d_logit, float* scratch, int B, int C, int HW, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                 float grad_scale, hipStream_t s);
+int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s);

@@ -1,0 +1,251 @@
+// C ABI of the LDM training step (include/ddmi_hip.h, "Training"): stateless ops on caller-owned NHWC tensors in the
+// handle's storage dtype + fp32 master parameters, composed from the forward kernels and k_train.hip.  The handle only owns
+// a scratch arena (grown on demand: the first call of a larger shape synchronises the stream once).
+#include <cmath>
+#include <vector>
+#include "kernels.h"
+#include "prof.h"
+
+struct ddmi_train {
+  int dt = DT_F32;
+  unsigned char* ws = nullptr;
+  size_t ws_bytes = 0;
+};
+
+namespace {
+struct Carve {   // sequential carving of the scratch arena, 256-byte aligned
+  ddmi_train* h;
+  size_t off = 0;
+  void* take(size_t bytes) {
+    void* p = h->ws + off;
+    off += (bytes + 255) & ~(size_t)255;
+    return p;
+  }
+};
+int reserve(ddmi_train* h, size_t bytes, hipStream_t s) {
+  bytes += 4096;
+  if (bytes <= h->ws_bytes) return DDMI_OK;
+  HIP_TRY(hipStreamSynchronize(s));   // nothing in flight may still use the old arena
+  if (h->ws) (void)hipFree(h->ws);
+  h->ws = nullptr;
+  h->ws_bytes = 0;
+  size_t want = bytes + bytes / 4;
+  HIP_TRY(hipMalloc((void**)&h->ws, want));
+  h->ws_bytes = want;
+  return DDMI_OK;
+}
+size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" {
+
+int ddmi_train_create(int numerics, ddmi_train** out) {
+  DDMI_REQUIRE(out, "train_create: null argument");
+  DDMI_REQUIRE(numerics == DDMI_PARITY_FP32 || numerics == DDMI_PERF_BF16, "train_create: bad numerics");
+  ddmi_train* h = new (std::nothrow) ddmi_train();
+  if (!h) return ddmi_fail(DDMI_ERR_HIP, "out of memory");
+  h->dt = numerics == DDMI_PARITY_FP32 ? DT_F32 : DT_BF16;
+  *out = h;
+  return DDMI_OK;
+}
+int ddmi_train_destroy(ddmi_train* h) {
+  if (h) {
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+  }
+  return DDMI_OK;
+}
+
+int ddmi_train_to_nhwc(ddmi_train* h, const float* x_nchw, void* y_nhwc, int B, int C, int HW, void* stream) {
+  DDMI_REQUIRE(h && x_nchw && y_nhwc, "train_to_nhwc: null argument");
+  return launch_nchw_to_nhwc(x_nchw, y_nhwc, h->dt, B, C, HW, (hipStream_t)stream);
+}
+int ddmi_train_to_nchw(ddmi_train* h, const void* x_nhwc, float* y_nchw, int B, int C, int HW, void* stream) {
+  DDMI_REQUIRE(h && x_nhwc && y_nchw, "train_to_nchw: null argument");
+  return launch_nhwc_to_nchw(x_nhwc, h->dt, y_nchw, B, C, HW, (hipStream_t)stream);
+}
+
+static void conv_geometry(int H, int W, int k, int stride, int ups, int* Ho, int* Wo) {
+  const int hin = ups ? 2 * H : H, win = ups ? 2 * W : W, pad = k / 2;
+  *Ho = (hin + 2 * pad - k) / stride + 1;
+  *Wo = (win + 2 * pad - k) / stride + 1;
+}
+
+int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const float* bias, const float* emb, int emb_stride,
+                        const void* res, void* y, int B, int H, int W, int Cin, int Cout, int k, int stride, int ups, void* stream) {
+  DDMI_REQUIRE(h && x && w && y && (k == 1 || k == 3) && (stride == 1 || stride == 2), "train_conv_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int dt = h->dt;
+  int Ho, Wo;
+  conv_geometry(H, W, k, stride, ups, &Ho, &Wo);
+  ConvArgs a{};
+  a.x = x; a.bias = bias; a.emb = emb; a.emb_stride = emb_stride; a.res = res; a.y = y;
+  a.B = B; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout;
+  a.KH = a.KW = k; a.stride = stride; a.pad = k / 2; a.ups = ups ? 1 : 0; a.out_scale = 1.f;
+  a.splitk = conv_pick_splitk(a, dt);
+  const size_t wbytes = al((size_t)Cout * Cin * k * k * dt_size(dt));
+  const size_t sk = a.splitk > 1 ? al((size_t)a.splitk * B * Ho * Wo * Cout * sizeof(float)) : 0;
+  DDMI_TRY(reserve(h, wbytes + sk, s));
+  Carve c{h};
+  void* wp = c.take(wbytes);
+  DDMI_TRY(launch_pack_conv_weight(w, wp, dt, Cout, Cin, k, k, s));
+  a.w = wp;
+  if (a.splitk > 1) a.splitk_ws = (float*)c.take(sk);
+  return launch_conv(a, dt, s);
+}
+
+int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void* dy, void* dx, float* dw, float* dbias,
+                        float* demb, int B, int H, int W, int Cin, int Cout, int k, int stride, int ups, void* stream) {
+  DDMI_REQUIRE(h && x && w && dy && dw && (k == 1 || k == 3) && (stride == 1 || stride == 2), "train_conv_bwd: bad arguments");
+  DDMI_REQUIRE(!(stride == 2 && (ups || k != 3)), "train_conv_bwd: stride 2 is the 3x3 Downsample convolution");
+  hipStream_t s = (hipStream_t)stream;
+  const int dt = h->dt;
+  const size_t es = dt_size(dt);
+  int Ho, Wo;
+  conv_geometry(H, W, k, stride, ups, &Ho, &Wo);
+  const int64_t P = (int64_t)B * Ho * Wo;
+  const int kk = k * k, N = kk * Cin;
+  DDMI_REQUIRE(P % (dt == DT_F32 ? 4 : 8) == 0, "train_conv_bwd: B*Ho*Wo must be a multiple of the 16-byte vector");
+  DDMI_REQUIRE((double)N * P * es < 3.9e9, "train_conv_bwd: im2col image exceeds 4 GB - lower the batch");
+  // ---- scratch plan (the two phases reuse the arena) --------------------------------------------------------
+  const int Hg = ups ? 2 * H : (stride == 2 ? 2 * Ho : H), Wg = ups ? 2 * W : (stride == 2 ? 2 * Wo : W);   // dgrad conv grid
+  ConvArgs d{};   // dgrad: a stride-1 convolution of dY' with the transposed, flipped filter
+  d.B = B; d.Hin = Hg; d.Win = Wg; d.Cin = Cout; d.Hout = Hg; d.Wout = Wg; d.Cout = Cin;
+  d.KH = d.KW = k; d.stride = 1; d.pad = k / 2; d.ups = 0; d.out_scale = 1.f;
+  d.splitk = dx ? conv_pick_splitk(d, dt) : 1;
+  ConvArgs g{};   // wgrad: G[n][co] = sum_p Bm[n][p] A[co][p] as a 1x1 "convolution" over rows of A
+  g.B = 1; g.Hin = 1; g.Win = Cout; g.Cin = (int)P; g.Hout = 1; g.Wout = Cout; g.Cout = N;
+  g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.ups = 0; g.out_scale = 1.f;
+  g.splitk = conv_pick_splitk(g, dt);
+  const size_t dgrad_bytes = dx ? al((size_t)Cout * Cin * kk * es) + (stride == 2 ? al((size_t)B * Hg * Wg * Cout * es) : 0) +
+                                      (ups ? al((size_t)B * Hg * Wg * Cin * es) : 0) +
+                                      (d.splitk > 1 ? al((size_t)d.splitk * B * Hg * Wg * Cin * sizeof(float)) : 0)
+                                : 0;
+  const size_t wgrad_bytes = al((size_t)Cout * P * es) + al((size_t)N * P * es) + al((size_t)N * Cout * sizeof(float)) +
+                             (g.splitk > 1 ? al((size_t)g.splitk * Cout * N * sizeof(float)) : 0);
+  const size_t red_bytes = al((size_t)B * Cout * sizeof(float));
+  DDMI_TRY(reserve(h, std::max(dgrad_bytes, wgrad_bytes) + red_bytes, s));
+  // ---- bias / embedding gradients ---------------------------------------------------------------------------
+  if (dbias || demb) {
+    Carve c{h};
+    float* per = demb ? demb : (float*)c.take(red_bytes);
+    DDMI_TRY(launch_sum_hw(dy, per, dt, B, Ho * Wo, Cout, s));
+    if (dbias) DDMI_TRY(launch_sum_b(per, dbias, B, Cout, s));
+  }
+  // ---- dgrad ------------------------------------------------------------------------------------------------
+  if (dx) {
+    Carve c{h};
+    c.take(red_bytes);
+    void* wp = c.take((size_t)Cout * Cin * kk * es);
+    DDMI_TRY(launch_pack_dgrad_weight(w, wp, dt, Cout, Cin, k, s));
+    const void* src = dy;
+    if (stride == 2) {
+      void* u = c.take((size_t)B * Hg * Wg * Cout * es);
+      DDMI_TRY(launch_zero_insert2x(dy, u, dt, B, Ho, Wo, Cout, s));
+      src = u;
+    }
+    void* dst = ups ? c.take((size_t)B * Hg * Wg * Cin * es) : dx;
+    d.x = src; d.w = wp; d.y = dst;
+    if (d.splitk > 1) d.splitk_ws = (float*)c.take((size_t)d.splitk * B * Hg * Wg * Cin * sizeof(float));
+    DDMI_TRY(launch_conv(d, dt, s));
+    if (ups) DDMI_TRY(launch_sumpool2x(dst, dx, dt, B, H, W, Cin, s));
+  }
+  // ---- wgrad ------------------------------------------------------------------------------------------------
+  {
+    Carve c{h};
+    c.take(red_bytes);
+    void* A = c.take((size_t)Cout * P * es);
+    void* Bm = c.take((size_t)N * P * es);
+    float* G = (float*)c.take((size_t)N * Cout * sizeof(float));
+    DDMI_TRY(launch_transpose_2d(dy, A, dt, 1, (int)P, Cout, s));                       // A[co][p] = dY[p][co]
+    DDMI_TRY(launch_im2col_t(x, Bm, dt, B, H, W, Cin, Ho, Wo, k, stride, k / 2, ups ? 1 : 0, s));
+    g.x = A; g.w = Bm; g.y_nchw = G;
+    if (g.splitk > 1) g.splitk_ws = (float*)c.take((size_t)g.splitk * Cout * N * sizeof(float));
+    DDMI_TRY(launch_conv(g, dt, s));
+    DDMI_TRY(launch_wgrad_finish(G, dw, Cout, Cin, kk, s));
+  }
+  return DDMI_OK;
+}
+
+int ddmi_train_gn_fwd(ddmi_train* h, const void* x, const float* gamma, const float* beta, void* y, float* meanrstd, int B, int HW,
+                      int C, float eps, int silu, void* stream) {
+  DDMI_REQUIRE(h && x && gamma && beta && y && meanrstd, "train_gn_fwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, GN_STATS_DOUBLES(B) * sizeof(double), s));
+  double* st = (double*)h->ws;
+  DDMI_TRY(launch_gn_stats(x, h->dt, st, B, HW, C, s));
+  DDMI_TRY(launch_gn_apply(x, y, h->dt, st, gamma, beta, eps, silu, B, HW, C, s));
+  return launch_gn_meanrstd(st, meanrstd, B, HW, C, eps, gn_nsplit(B, HW), s);
+}
+int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
+                      void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream) {
+  DDMI_REQUIRE(h && x && gamma && beta && meanrstd && dy && dx && dgamma && dbeta, "train_gn_bwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, ((size_t)B * 64 + (size_t)2 * B * C) * sizeof(float), s));
+  return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s);
+}
+
+int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream) {
+  DDMI_REQUIRE(h && qkv && out, "train_attn_fwd: null argument");
+  return launch_attention_legacy(qkv, out, h->dt, B, T, heads, d, (hipStream_t)stream);
+}
+int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
+                        void* stream) {
+  DDMI_REQUIRE(h && qkv && out && dout && dqkv, "train_attn_bwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, (size_t)2 * B * heads * T * sizeof(float), s));
+  return launch_attention_legacy_backward(qkv, out, dout, dqkv, (float*)h->ws, h->dt, B, T, heads, d, s);
+}
+
+int ddmi_train_linear_fwd(ddmi_train* h, const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in,
+                          void* stream) {
+  DDMI_REQUIRE(h && x && W && y, "train_linear_fwd: null argument");
+  return launch_linear_small(x, K, W, b, y, N, B, K, N, silu_in, (hipStream_t)stream);
+}
+int ddmi_train_linear_bwd(ddmi_train* h, const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K,
+                          int N, int silu_in, void* stream) {
+  DDMI_REQUIRE(h && x && W && dy && dW, "train_linear_bwd: null argument");
+  return launch_linear_small_backward(x, W, dy, dx, dW, db, B, K, N, silu_in, (hipStream_t)stream);
+}
+
+int ddmi_train_timestep_embedding(ddmi_train* h, const int64_t* t, float* out, int B, int dim, void* stream) {
+  DDMI_REQUIRE(h && t && out && dim % 2 == 0, "train_timestep_embedding: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int half = dim / 2;
+  std::vector<float> fr(half);
+  const float neg_log = (float)(-std::log(10000.0));
+  for (int i = 0; i < half; ++i) {   // fp32 product, then fp32 division, as torch evaluates util.py:161-163
+    volatile float a = neg_log * (float)i;
+    volatile float q = a / (float)half;
+    fr[i] = std::exp((float)q);
+  }
+  DDMI_TRY(reserve(h, half * sizeof(float), s));
+  HIP_TRY(hipMemcpyAsync(h->ws, fr.data(), half * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // `fr` leaves scope; tiny, once per step
+  return launch_timestep_embedding(t, (const float*)h->ws, out, B, dim, s);
+}
+
+int ddmi_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* x_t, int B,
+                        int64_t per_sample, void* stream) {
+  DDMI_REQUIRE(x0 && noise && sqrt_ac && sqrt_1mac && x_t && B > 0 && per_sample > 0, "train_q_sample: bad arguments");
+  return launch_q_sample(x0, noise, sqrt_ac, sqrt_1mac, x_t, B, per_sample, (hipStream_t)stream);
+}
+int ddmi_train_eps_loss(ddmi_train* h, const float* model_out, const float* x_t, const float* noise, const float* sqrt_1mac,
+                        const float* mixing_logit, float* loss, float* d_model_out, float* d_logit, int B, int C, int HW, void* stream) {
+  DDMI_REQUIRE(h && model_out && x_t && noise && sqrt_1mac && loss && d_model_out, "train_eps_loss: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, (size_t)2 * B * C * sizeof(float), s));
+  return launch_eps_loss(model_out, x_t, noise, sqrt_1mac, mixing_logit, loss, d_model_out, d_logit, (float*)h->ws, B, C, HW, s);
+}
+int ddmi_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  DDMI_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0, "train_adamw: bad arguments");
+  return launch_adamw(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
+}
+
+int ddmi_train_ema(float* ema, const float* param, int64_t n, float decay, void* stream) {
+  DDMI_REQUIRE(ema && param && n > 0, "train_ema: bad arguments");
+  return launch_ema(ema, param, n, decay, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+"""LDM training step - host side: the inner step of `LDMTrainer.train` (tools/ldm/image.py:136-178):
+
+    z -> DDPM.forward(z): t ~ randint, p_losses (diffusion/ddpm.py:409-454) -> backward -> [all-reduce] -> AdamW -> EMA
+
+Every FLOP runs in libddmi_hip (include/ddmi_hip.h "Training": forward / backward ops for convolution, GroupNorm32+SiLU,
+QKVAttentionLegacy, the time-embedding linears, q_sample, the mixed-prediction MSE loss, AdamW, EMA).  torch is the tape:
+`torch.autograd.Function` records which op produced which tensor and replays the ops' backward entry points in reverse;
+`torch.nn.Module` / `Parameter` hold the fp32 master weights under the reference's state-dict names (so `state_dict()` is
+what `LDMTrainer.save` writes, tools/ldm/image.py:104-119), as views into ONE flat slab - the gradient slab is what RCCL
+all-reduces (accelerate's DDP in the reference, tools/ldm/image.py:96) and what the fused AdamW kernel reads.
+Activations are NHWC tensors in the storage dtype of the numerics mode (fp32 parity / bf16 perf).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ddpm import make_beta_schedule
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class TrainContext:
+    """One `ddmi_train` handle (scratch arena) per device and numerics mode."""
+
+    def __init__(self, numerics="bf16", device="cuda:0"):
+        self.numerics = _lib.numerics_code(numerics)
+        self.dtype = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+        self.device = torch.device(device)
+        _lib.init_device(self.device.index or 0)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ddmi_train_create(self.numerics, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().ddmi_train_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _stream():
+    return _lib.stream_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ops: forward and backward are entry points of the C ABI; autograd only sequences them
+# ---------------------------------------------------------------------------------------------------------------------
+class ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tc, x):   # x [B,C,H,W] fp32 -> [B,H,W,C] storage dtype
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, H, W, Cc), dtype=tc.dtype, device=x.device)
+        _lib.check(_lib.lib().ddmi_train_to_nhwc(tc.h, x.contiguous().data_ptr(), y.data_ptr(), B, Cc, H * W, _stream()))
+        ctx.tc = tc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc = dy.shape
+        dx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.lib().ddmi_train_to_nchw(ctx.tc.h, dy.contiguous().data_ptr(), dx.data_ptr(), B, Cc, H * W, _stream()))
+        return None, dx
+
+
+class ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tc, x):   # [B,H,W,C] storage dtype -> [B,C,H,W] fp32
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ddmi_train_to_nchw(tc.h, x.contiguous().data_ptr(), y.data_ptr(), B, Cc, H * W, _stream()))
+        ctx.tc = tc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cc, H, W = dy.shape
+        dx = torch.empty((B, H, W, Cc), dtype=ctx.tc.dtype, device=dy.device)
+        _lib.check(_lib.lib().ddmi_train_to_nhwc(ctx.tc.h, dy.contiguous().data_ptr(), dx.data_ptr(), B, Cc, H * W, _stream()))
+        return None, dx
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv(nearest_x2?(x), w) + bias + emb[:, :, None, None] + res (ddmi_train_conv_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, tc, x, w, bias, emb, res, stride, ups):
+        x = x.contiguous()
+        B, H, W, Cin = x.shape
+        Cout, k = w.shape[0], (w.shape[2] if w.dim() == 4 else 1)
+        hin, win, pad = (2 * H if ups else H), (2 * W if ups else W), k // 2
+        Ho, Wo = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        y = torch.empty((B, Ho, Wo, Cout), dtype=tc.dtype, device=x.device)
+        emb_c = emb.contiguous() if emb is not None else None
+        res_c = res.contiguous() if res is not None else None
+        _lib.check(_lib.lib().ddmi_train_conv_fwd(tc.h, x.data_ptr(), w.data_ptr(), _p(bias), _p(emb_c), Cout if emb_c is not None else 0,
+                                                  _p(res_c), y.data_ptr(), B, H, W, Cin, Cout, k, stride, int(ups), _stream()))
+        ctx.save_for_backward(x, w)
+        ctx.tc, ctx.meta = tc, (B, H, W, Cin, Cout, k, stride, int(ups), bias is not None, emb is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, Cin, Cout, k, stride, ups, has_b, has_e, has_r = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        dw = torch.empty_like(w)
+        db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_b else None
+        de = torch.empty((B, Cout), dtype=torch.float32, device=x.device) if has_e else None
+        _lib.check(_lib.lib().ddmi_train_conv_bwd(ctx.tc.h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), dw.data_ptr(), _p(db), _p(de),
+                                                  B, H, W, Cin, Cout, k, stride, ups, _stream()))
+        return None, dx, dw, db, de, (dy if has_r else None), None, None
+
+
+class GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tc, x, gamma, beta, eps, silu):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        mr = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ddmi_train_gn_fwd(tc.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mr.data_ptr(), B, H * W,
+                                                Cc, float(eps), int(silu), _stream()))
+        ctx.save_for_backward(x, gamma, beta, mr)
+        ctx.tc, ctx.silu = tc, int(silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mr = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        _lib.check(_lib.lib().ddmi_train_gn_bwd(ctx.tc.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mr.data_ptr(), dy.data_ptr(),
+                                                dx.data_ptr(), dg.data_ptr(), db.data_ptr(), B, H * W, Cc, ctx.silu, _stream()))
+        return None, dx, dg, db, None, None
+
+
+class AttentionLegacyFn(torch.autograd.Function):
+    """QKVAttentionLegacy on qkv [B,H,W,heads*3*d] -> [B,H,W,heads*d]."""
+
+    @staticmethod
+    def forward(ctx, tc, qkv, heads):
+        qkv = qkv.contiguous()
+        B, H, W, C3 = qkv.shape
+        d = C3 // (3 * heads)
+        out = torch.empty((B, H, W, heads * d), dtype=tc.dtype, device=qkv.device)
+        _lib.check(_lib.lib().ddmi_train_attn_fwd(tc.h, qkv.data_ptr(), out.data_ptr(), B, H * W, heads, d, _stream()))
+        ctx.save_for_backward(qkv, out)
+        ctx.tc, ctx.heads = tc, heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out = ctx.saved_tensors
+        B, H, W, C3 = qkv.shape
+        d = C3 // (3 * ctx.heads)
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib.lib().ddmi_train_attn_bwd(ctx.tc.h, qkv.data_ptr(), out.data_ptr(), dout.contiguous().data_ptr(), dqkv.data_ptr(), B,
+                                                  H * W, ctx.heads, d, _stream()))
+        return None, dqkv, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x) W^T + b on fp32 [B,K]; act = SiLU when silu_in (time_embed, ResBlock.emb_layers)."""
+
+    @staticmethod
+    def forward(ctx, tc, x, W, b, silu_in):
+        x = x.contiguous()
+        B, K = x.shape
+        N = W.shape[0]
+        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ddmi_train_linear_fwd(tc.h, x.data_ptr(), W.data_ptr(), _p(b), y.data_ptr(), B, K, N, int(silu_in), _stream()))
+        ctx.save_for_backward(x, W)
+        ctx.tc, ctx.silu_in, ctx.has_b = tc, int(silu_in), b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        B, K = x.shape
+        N = W.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        dW = torch.empty_like(W)
+        db = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.has_b else None
+        _lib.check(_lib.lib().ddmi_train_linear_bwd(ctx.tc.h, x.data_ptr(), W.data_ptr(), dy.data_ptr(), _p(dx), dW.data_ptr(), _p(db), B, K, N,
+                                                    ctx.silu_in, _stream()))
+        return None, dx, dW, db, None
+
+
+class EpsLossFn(torch.autograd.Function):
+    """p_losses (ddpm.py:409-447): mixed prediction + MSE against the noise; gradients come out of the same kernel."""
+
+    @staticmethod
+    def forward(ctx, tc, model_out, x_t, noise, sqrt_1mac, logit):
+        B, Cc, H, W = model_out.shape
+        loss = torch.empty((), dtype=torch.float32, device=model_out.device)
+        dmo = torch.empty_like(model_out)
+        dlogit = torch.empty((Cc,), dtype=torch.float32, device=model_out.device) if logit is not None else None
+        lg = logit.reshape(-1).contiguous() if logit is not None else None
+        _lib.check(_lib.lib().ddmi_train_eps_loss(tc.h, model_out.contiguous().data_ptr(), x_t.data_ptr(), noise.data_ptr(), sqrt_1mac.data_ptr(),
+                                                  _p(lg), loss.data_ptr(), dmo.data_ptr(), _p(dlogit), B, Cc, H * W, _stream()))
+        ctx.save_for_backward(dmo, dlogit if dlogit is not None else torch.empty(0))
+        ctx.logit_shape = tuple(logit.shape) if logit is not None else None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dmo, dlogit = ctx.saved_tensors
+        return None, dmo * g, None, None, None, (dlogit.reshape(ctx.logit_shape) * g if ctx.logit_shape else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UNetModel as a tree of parameter holders with the reference's state-dict names (openaimodel.py:463-793)
+# ---------------------------------------------------------------------------------------------------------------------
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, dims=2):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty((cout, cin, k, k) if dims == 2 else (cout, cin, k)))
+        self.bias = nn.Parameter(torch.empty((cout,)))
+
+    def w4(self):
+        return self.weight if self.weight.dim() == 4 else self.weight.unsqueeze(-1)
+
+    def run(self, tc, x, emb=None, res=None, stride=1, ups=False):
+        return ConvFn.apply(tc, x, self.w4(), self.bias, emb, res, stride, ups)
+
+
+class _Norm(nn.Module):   # GroupNorm32(32, C)
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty((c,)))
+        self.bias = nn.Parameter(torch.empty((c,)))
+
+    def run(self, tc, x, silu):
+        return GroupNormFn.apply(tc, x, self.weight, self.bias, 1e-5, silu)
+
+
+class _Linear(nn.Module):
+    def __init__(self, k, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty((n, k)))
+        self.bias = nn.Parameter(torch.empty((n,)))
+
+    def run(self, tc, x, silu_in):
+        return LinearFn.apply(tc, x, self.weight, self.bias, silu_in)
+
+
+def _seq(*mods):
+    """nn.Sequential whose parameterless slots (SiLU, Dropout, Identity) keep the reference's numeric keys."""
+    return nn.Sequential(*[m if m is not None else nn.Identity() for m in mods])
+
+
+class ResBlock(nn.Module):
+    def __init__(self, cin, emb_ch, cout):
+        super().__init__()
+        self.in_layers = _seq(_Norm(cin), None, _Conv(cin, cout, 3))
+        self.emb_layers = _seq(None, _Linear(emb_ch, cout))
+        self.out_layers = _seq(_Norm(cout), None, None, _Conv(cout, cout, 3))
+        self.skip_connection = _Conv(cin, cout, 1) if cin != cout else nn.Identity()
+
+    def run(self, tc, x, emb):
+        h = self.in_layers[0].run(tc, x, silu=True)
+        h = self.in_layers[2].run(tc, h, emb=self.emb_layers[1].run(tc, emb, silu_in=True))   # h + emb_out[..., None, None]
+        h = self.out_layers[0].run(tc, h, silu=True)
+        skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection.run(tc, x)
+        return self.out_layers[3].run(tc, h, res=skip)                                          # skip_connection(x) + h
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, ch, head_ch):
+        super().__init__()
+        self.heads = ch // head_ch
+        self.norm = _Norm(ch)
+        self.qkv = _Conv(ch, 3 * ch, 1, dims=1)
+        self.proj_out = _Conv(ch, ch, 1, dims=1)
+
+    def run(self, tc, x, emb=None):
+        qkv = self.qkv.run(tc, self.norm.run(tc, x, silu=False))
+        a = AttentionLegacyFn.apply(tc, qkv, self.heads)
+        return self.proj_out.run(tc, a, res=x)
+
+
+class Downsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.op = _Conv(ch, ch, 3)
+
+    def run(self, tc, x, emb=None):
+        return self.op.run(tc, x, stride=2)
+
+
+class Upsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = _Conv(ch, ch, 3)
+
+    def run(self, tc, x, emb=None):
+        return self.conv.run(tc, x, ups=True)
+
+
+class _InConv(nn.Module):
+    pass
+
+
+class TrainUNetModel(nn.Module):
+    """The training-path UNetModel: same constructor kwargs and state-dict keys as the reference (openaimodel.py:493-743)
+    for the variant the DDMI configs build (2-D, legacy attention, conv_resample)."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 channel_mult=(1, 2, 4, 8), num_head_channels=32, numerics="bf16", device="cuda:0", **ignored):
+        super().__init__()
+        mc, E = model_channels, 4 * model_channels
+        self.model_channels, self.in_channels, self.out_channels = mc, in_channels, out_channels
+        self._numerics, self._device, self._tc = numerics, device, None   # the native handle is created on first use
+        self.time_embed = _seq(_Linear(mc, E), None, _Linear(E, E))
+        self.input_blocks = nn.ModuleList([nn.Sequential(_Conv(in_channels, mc, 3))])
+        chans, ch, ds = [mc], mc, 1
+        attn = set(int(a) for a in attention_resolutions)
+        mult = list(channel_mult)
+        for level, m in enumerate(mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, E, m * mc)]
+                ch = m * mc
+                if ds in attn:
+                    layers.append(AttentionBlock(ch, num_head_channels))
+                self.input_blocks.append(nn.Sequential(*layers))
+                chans.append(ch)
+            if level != len(mult) - 1:
+                self.input_blocks.append(nn.Sequential(Downsample(ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = nn.Sequential(ResBlock(ch, E, ch), AttentionBlock(ch, num_head_channels), ResBlock(ch, E, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, m in list(enumerate(mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + chans.pop(), E, mc * m)]
+                ch = mc * m
+                if ds in attn:
+                    layers.append(AttentionBlock(ch, num_head_channels))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch))
+                    ds //= 2
+                self.output_blocks.append(nn.Sequential(*layers))
+        self.out = _seq(_Norm(ch), None, _Conv(mc, out_channels, 3))
+        self.to(device)
+
+    @property
+    def tc(self) -> TrainContext:
+        if self._tc is None:
+            self._tc = TrainContext(self._numerics, self._device)
+        return self._tc
+
+    @staticmethod
+    def _run_block(tc, block, h, emb):
+        for layer in block:
+            h = layer.run(tc, h, emb) if not isinstance(layer, _Conv) else layer.run(tc, h)
+        return h
+
+    def forward(self, x, timesteps, context=None, **kw):
+        """x [B,C,H,W] fp32, timesteps [B] int64 -> eps [B,C,H,W] fp32 (openaimodel.py:761-793)."""
+        tc = self.tc
+        B = x.shape[0]
+        temb = torch.empty((B, self.model_channels), dtype=torch.float32, device=x.device)
+        t64 = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        _lib.check(_lib.lib().ddmi_train_timestep_embedding(tc.h, t64.data_ptr(), temb.data_ptr(), B, self.model_channels, _stream()))
+        emb = self.time_embed[2].run(tc, self.time_embed[0].run(tc, temb, silu_in=False), silu_in=True)
+        h = ToNHWC.apply(tc, x)
+        hs = []
+        for block in self.input_blocks:
+            h = self._run_block(tc, block, h, emb)
+            hs.append(h)
+        h = self._run_block(tc, self.middle_block, h, emb)
+        for block in self.output_blocks:
+            h = torch.cat([h, hs.pop()], dim=-1)        # th.cat([h, hs.pop()], dim=1) in NHWC
+            h = self._run_block(tc, block, h, emb)
+        h = self.out[2].run(tc, self.out[0].run(tc, h, silu=True))
+        return ToNCHW.apply(tc, h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the training step
+# ---------------------------------------------------------------------------------------------------------------------
+class FlatParams:
+    """All parameters of a module as views into one fp32 slab (+ a gradient slab of the same layout, + AdamW moments)."""
+
+    def __init__(self, params: Sequence[nn.Parameter], device):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        self.data = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.data[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.data[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                off += k
+        self.n = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class LDMTrainStep:
+    """`DDPM.forward` + backward + optimizer step of the reference's LDM trainer on one GPU of a data-parallel job.
+
+    diffusion = (TrainUNetModel, mixing_logit); schedule from the `ddpmconfig` block; AdamW(lr, weight_decay 0) as
+    tools/ldm/image.py:62; gradients are summed over ranks with one all-reduce of the flat slab and scaled by
+    1 / (world_size * gradient_accumulate_every) inside the fused AdamW kernel."""
+
+    def __init__(self, unetconfig, ddpmconfig, numerics="bf16", lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
+                 gradient_accumulate_every=1, ema_decay=0.9999, ema_update_every=10, device="cuda:0"):
+        cfg = dict(ddpmconfig)
+        self.device = torch.device(device)
+        self.model = TrainUNetModel(**dict(unetconfig), numerics=numerics, device=device)
+        self.channels = int(cfg.get("channels", unetconfig["in_channels"]))
+        self.num_timesteps = int(cfg.get("timesteps", 1000))
+        betas_np = make_beta_schedule(cfg.get("beta_schedule", "linear"), self.num_timesteps, cfg.get("linear_start", 0.0015),
+                                      cfg.get("linear_end", 0.0195), cfg.get("cosine_s", 8e-3))
+        ac = np.cumprod(1.0 - betas_np, axis=0)
+        self.sqrt_ac = torch.from_numpy(np.sqrt(ac).astype(np.float32)).to(self.device)
+        self.sqrt_1mac = torch.from_numpy(np.sqrt(1.0 - ac).astype(np.float32)).to(self.device)
+        self.mixed_prediction = bool(cfg.get("mixed_prediction", True))
+        self.mixing_logit = nn.Parameter(torch.full((1, self.channels, 1, 1), float(cfg.get("mixed_init", -6)), device=self.device)) \
+            if self.mixed_prediction else None
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        self.accum = int(gradient_accumulate_every)
+        self.ema_decay, self.ema_every = float(ema_decay), int(ema_update_every)
+        self.flat: Optional[FlatParams] = None
+        self.ema: Optional[torch.Tensor] = None
+        self.opt_step = 0
+        self.micro = 0
+
+    # ---- parameters ----------------------------------------------------------------------------------------------------
+    def named_parameters(self):
+        """The reference's `diffusion_process.state_dict()` naming: 'model.*' + 'mixing_logit' (tools/ldm/image.py:79)."""
+        for k, p in self.model.named_parameters():
+            yield "model." + k, p
+        if self.mixing_logit is not None:
+            yield "mixing_logit", self.mixing_logit
+
+    def load_state_dict(self, state, strict=True):
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}")
+        with torch.no_grad():
+            for k, v in state.items():
+                if k in own:
+                    t = torch.as_tensor(np.asarray(v) if not hasattr(v, "detach") else v).to(self.device, torch.float32)
+                    own[k].data.copy_(t.reshape(own[k].shape))
+        return self
+
+    def state_dict(self):
+        return {k: p.detach().clone() for k, p in self.named_parameters()}
+
+    def finalize(self):
+        """Lays the parameters out in one slab (after load_state_dict) and snapshots the EMA copy."""
+        self.flat = FlatParams([p for _, p in self.named_parameters()], self.device)
+        self.ema = self.flat.data.clone()
+        return self
+
+    # ---- one micro-step -------------------------------------------------------------------------------------------------
+    def loss_and_backward(self, z0, t=None, noise=None):
+        """p_losses on a latent batch z0 [B,C,H,W] fp32 and the backward pass; gradients ACCUMULATE in the flat slab."""
+        if self.flat is None:
+            self.finalize()
+        z0 = z0.to(self.device, torch.float32).contiguous()
+        B = z0.shape[0]
+        if t is None:
+            t = torch.randint(0, self.num_timesteps, (B,), device=self.device)      # ddpm.py:452
+        t = t.to(self.device, torch.int64)
+        if noise is None:
+            noise = torch.randn_like(z0)                                                 # ddpm.py:410
+        noise = noise.to(self.device, torch.float32).contiguous()
+        a, s = self.sqrt_ac[t].contiguous(), self.sqrt_1mac[t].contiguous()
+        x_t = torch.empty_like(z0)
+        _lib.check(_lib.lib().ddmi_train_q_sample(z0.data_ptr(), noise.data_ptr(), a.data_ptr(), s.data_ptr(), x_t.data_ptr(), B,
+                                                  z0[0].numel(), _stream()))
+        model_out = self.model(x_t, t)
+        loss = EpsLossFn.apply(self.model.tc, model_out, x_t, noise, s, self.mixing_logit)
+        loss.backward()
+        self.micro += 1
+        return loss.detach()
+
+    def optimizer_step(self, world_size: int = 1):
+        """All-reduce (sum) of the gradient slab over the ranks, fused AdamW, EMA every `ema_update_every` steps."""
+        import torch.distributed as dist
+        if world_size > 1 and dist.is_initialized():
+            dist.all_reduce(self.flat.grad)            # one bucket: the whole slab (2.08 GB for the AFHQ UNet)
+        self.opt_step += 1
+        f = self.flat
+        _lib.check(_lib.lib().ddmi_train_adamw(f.data.data_ptr(), f.grad.data_ptr(), f.exp_avg.data_ptr(), f.exp_avg_sq.data_ptr(), f.n,
+                                               self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
+                                               1.0 / (world_size * self.accum), _stream()))
+        f.zero_grad()
+        self.micro = 0
+        if self.opt_step % self.ema_every == 0:
+            _lib.check(_lib.lib().ddmi_train_ema(self.ema.data_ptr(), f.data.data_ptr(), f.n, self.ema_decay, _stream()))
+
+    def train_step(self, z0, t=None, noise=None, world_size: int = 1):
+        """The body of the reference's loop for one batch (tools/ldm/image.py:158-175)."""
+        loss = self.loss_and_backward(z0, t, noise)
+        if self.micro % self.accum == 0:
+            self.optimizer_step(world_size)
+        return loss

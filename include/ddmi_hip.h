@@ -314,6 +314,60 @@ int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* 
 /* timestep_embedding (util.py:150-170): t [B] int64 -> [B, dim] */
 int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Training: the pieces of LDMTrainer.train's inner step (tools/ldm/image.py:136-178) =
+ * DDPM.forward -> p_losses (diffusion/ddpm.py:409-454) -> backward -> AdamW (tools/ldm/image.py:62, 171-172), as stateless
+ * ops.  Activations are caller-owned NHWC tensors in the handle's storage dtype (fp32 for DDMI_PARITY_FP32, bf16 for
+ * DDMI_PERF_BF16); parameters and their gradients are fp32 in the reference's own layouts (the state-dict tensors), so the
+ * host can all-reduce the gradients with RCCL (accelerate's DDP wrapper in the reference, tools/ldm/image.py:96) and keep
+ * the optimizer state.  The host side (ddmi_amd/train.py) sequences them with an autograd tape; every FLOP runs here.
+ * The handle owns only a scratch arena (grown on demand; a growth synchronises the stream once).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct ddmi_train ddmi_train;
+int ddmi_train_create(int numerics, ddmi_train** out);
+int ddmi_train_destroy(ddmi_train* h);
+/* layout seams: fp32 NCHW <-> NHWC in the storage dtype */
+int ddmi_train_to_nhwc(ddmi_train* h, const float* x_nchw, void* y_nhwc, int B, int C, int HW, void* stream);
+int ddmi_train_to_nchw(ddmi_train* h, const void* x_nhwc, float* y_nchw, int B, int C, int HW, void* stream);
+/* y = conv_kxk(nearest_x2?(x), w) + bias + emb[b] + res: nn.Conv2d / Conv1d(k=1) of openaimodel.py (ResBlock :164-276 with the
+ * time-embedding addend, Downsample stride 2 :135-161, Upsample :92-120).  x [B,H,W,Cin]; w fp32 [Cout,Cin,k,k];
+ * bias [Cout] / emb [B,emb_stride] fp32 / res [B,Ho,Wo,Cout] nullable. */
+int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const float* bias, const float* emb, int emb_stride,
+                        const void* res, void* y, int B, int H, int W, int Cin, int Cout, int k, int stride, int ups, void* stream);
+/* gradients of the above for dy [B,Ho,Wo,Cout]: dx [B,H,W,Cin] (nullable), dw fp32 [Cout,Cin,k,k], dbias [Cout] (nullable),
+ * demb [B,Cout] fp32 (nullable; = the per-sample channel sums of dy).  d(res) = dy is the caller's. */
+int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void* dy, void* dx, float* dw, float* dbias, float* demb,
+                        int B, int H, int W, int Cin, int Cout, int k, int stride, int ups, void* stream);
+/* GroupNorm32 (+ SiLU) util.py:198-215; meanrstd [B,32,2] fp32 is saved for the backward */
+int ddmi_train_gn_fwd(ddmi_train* h, const void* x, const float* gamma, const float* beta, void* y, float* meanrstd, int B, int HW,
+                      int C, float eps, int silu, void* stream);
+int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
+                      void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream);
+/* QKVAttentionLegacy openaimodel.py:397-426: qkv [B,T,heads*3*d] (per-head [q|k|v]), out [B,T,heads*d]; backward d = 32 */
+int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream);
+int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
+                        void* stream);
+/* y = act(x) W^T + b (fp32 [B,K] -> [B,N]; act = SiLU when silu_in): time_embed and the ResBlock emb_layers */
+int ddmi_train_linear_fwd(ddmi_train* h, const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in,
+                          void* stream);
+int ddmi_train_linear_bwd(ddmi_train* h, const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K,
+                          int N, int silu_in, void* stream);
+int ddmi_train_timestep_embedding(ddmi_train* h, const int64_t* t, float* out, int B, int dim, void* stream);   /* util.py:150-170 */
+/* q_sample ddpm.py:383-386 with per-sample coefficients sqrt(abar_t), sqrt(1 - abar_t) [B] */
+int ddmi_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* x_t, int B,
+                        int64_t per_sample, void* stream);
+/* p_losses ddpm.py:409-447 for parameterization 'eps', loss_type 'l2', l_simple_weight 1, original_elbo_weight 0:
+ * loss = mean((mix(model_out) - noise)^2) with the mixed prediction of :469-477; also d loss / d model_out [B,C,HW] fp32 NCHW
+ * and d loss / d mixing_logit [C] (mixing_logit nullable = no mixing) */
+int ddmi_train_eps_loss(ddmi_train* h, const float* model_out, const float* x_t, const float* noise, const float* sqrt_1mac,
+                        const float* mixing_logit, float* loss, float* d_model_out, float* d_logit, int B, int C, int HW, void* stream);
+/* torch.optim.AdamW over a flat fp32 slab; grad is multiplied by grad_scale first (1 / world_size after a sum all-reduce,
+ * 1 / gradient_accumulate_every) */
+int ddmi_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* ema_pytorch's parameter average (tools/ldm/image.py:64, 174): ema += (param - ema) * (1 - decay) */
+int ddmi_train_ema(float* ema, const float* param, int64_t n, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

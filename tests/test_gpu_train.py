@@ -1,0 +1,208 @@
+"""SURVEY 8(f) rank 4 - the LDM training step on the GPU (include/ddmi_hip.h "Training", ddmi_amd/train.py):
+  * every backward op against torch's CPU autograd on the same fp32 inputs (the floating-point reference of these kernels);
+  * one whole step - p_losses, backward, AdamW - against fixture T1 captured from the REAL reference
+    (oracle/gen_golden_train.py: loss, gradients, updated parameters on the toy UNet), parity mode < 1e-3;
+  * the bf16 mode against the same fixture at bf16 tolerances (loss, gradient direction)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ddmi_amd import _lib
+from ddmi_amd import initweights as iw
+from ddmi_amd import train as T
+from helpers import TOL_BF16, TOL_FP32, named_state, rel_err
+from oracle import ddmi_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(x, tc):   # [B,C,H,W] fp32 cpu -> NHWC storage tensor on the device (leaf)
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype).requires_grad_(True)
+
+
+def nchw(y):
+    return y.detach().float().permute(0, 3, 1, 2).cpu()
+
+
+def g(tag, key, shape, std=1.0):
+    return torch.from_numpy(iw.normal(tag, key, shape, 0.0, std))
+
+
+@pytest.mark.parametrize("numerics,tol", [("fp32", 2e-5), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("k,stride,ups,cin,cout,hw", [(3, 1, 0, 32, 64, 8), (1, 1, 0, 64, 96, 8), (3, 2, 0, 32, 32, 8), (3, 1, 1, 32, 32, 4),
+                                                     (3, 1, 0, 224, 224, 16)])
+def test_conv_forward_backward_vs_torch(numerics, tol, k, stride, ups, cin, cout, hw):
+    tc = T.TrainContext(numerics, DEV)
+    B = 2
+    x, w, b = g("tc", "x", (B, cin, hw, hw)), g("tc", "w", (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k)), g("tc", "b", (cout,), 0.1)
+    emb = g("tc", "emb", (B, cout), 0.3)
+    xr, wr, br, er = (t.clone().requires_grad_(True) for t in (x, w, b, emb))
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr
+    yr = F.conv2d(xin, wr, br, stride=stride, padding=k // 2) + er[:, :, None, None]
+    res = g("tc", "res", tuple(yr.shape), 0.5)
+    rr = res.clone().requires_grad_(True)
+    yr = yr + rr
+    dy = g("tc", "dy", tuple(yr.shape))
+    yr.backward(dy)
+    xd, rd = nhwc(x, tc), nhwc(res, tc)
+    wd, bd, ed = (t.clone().to(DEV).requires_grad_(True) for t in (w, b, emb))
+    y = T.ConvFn.apply(tc, xd, wd, bd, ed, rd, stride, bool(ups))
+    assert rel_err(nchw(y), yr.detach()) < tol
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype))
+    assert rel_err(nchw(xd.grad), xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    assert rel_err(bd.grad, br.grad) < tol
+    assert rel_err(ed.grad, er.grad) < tol
+    assert rel_err(nchw(rd.grad), rr.grad) < (1e-6 if numerics == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("numerics,tol", [("fp32", 2e-5), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("silu", [True, False])
+@pytest.mark.parametrize("C,hw", [(64, 8), (224, 16), (2688, 4)])
+def test_groupnorm_backward_vs_torch(numerics, tol, silu, C, hw):
+    tc = T.TrainContext(numerics, DEV)
+    B = 2
+    x, ga, be = g("tg", "x", (B, C, hw, hw)) * 1.7 + 0.3, g("tg", "g", (C,), 0.1) + 1.0, g("tg", "b", (C,), 0.1)
+    if numerics == "bf16":
+        x = x.to(torch.bfloat16).float()     # the same stored values on both sides
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, ga, be))
+    yr = F.group_norm(xr, 32, gr, br, 1e-5)
+    if silu:
+        yr = F.silu(yr)
+    dy = g("tg", "dy", (B, C, hw, hw))
+    if numerics == "bf16":
+        dy = dy.to(torch.bfloat16).float()
+    yr.backward(dy)
+    xd = nhwc(x, tc)
+    gd, bd = ga.clone().to(DEV).requires_grad_(True), be.clone().to(DEV).requires_grad_(True)
+    y = T.GroupNormFn.apply(tc, xd, gd, bd, 1e-5, silu)
+    assert rel_err(nchw(y), yr.detach()) < tol
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype))
+    assert rel_err(nchw(xd.grad), xr.grad) < tol
+    assert rel_err(gd.grad, gr.grad) < tol
+    assert rel_err(bd.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("numerics,tol", [("fp32", 2e-5), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("heads,Tside", [(2, 8), (14, 16)])
+def test_attention_legacy_backward_vs_torch(numerics, tol, heads, Tside):
+    tc = T.TrainContext(numerics, DEV)
+    B, d = 2, 32
+    qkv = g("ta", "qkv", (B, heads * 3 * d, Tside, Tside))
+    if numerics == "bf16":
+        qkv = qkv.to(torch.bfloat16).float()
+    qr = qkv.clone().requires_grad_(True)
+    out_r = O.qkv_attention_legacy(qr.reshape(B, heads * 3 * d, Tside * Tside), heads)      # [B, heads*d, T]
+    dout = g("ta", "dout", tuple(out_r.shape))
+    if numerics == "bf16":
+        dout = dout.to(torch.bfloat16).float()
+    out_r.backward(dout)
+    qd = nhwc(qkv, tc)
+    out = T.AttentionLegacyFn.apply(tc, qd, heads)
+    assert rel_err(nchw(out).reshape(B, heads * d, -1), out_r.detach()) < tol
+    out.backward(dout.reshape(B, heads * d, Tside, Tside).permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype))
+    assert rel_err(nchw(qd.grad).reshape(B, heads * 3 * d, -1), qr.grad) < tol
+
+
+def test_linear_loss_adamw_qsample_vs_torch():
+    tc = T.TrainContext("fp32", DEV)
+    B, K, N = 3, 96, 160
+    for silu_in in (False, True):
+        x, W, b = g("tl", "x", (B, K)), g("tl", "W", (N, K), 0.1), g("tl", "b", (N,), 0.1)
+        xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+        yr = F.linear(F.silu(xr) if silu_in else xr, Wr, br)
+        dy = g("tl", "dy", (B, N))
+        yr.backward(dy)
+        xd, Wd, bd = (t.clone().to(DEV).requires_grad_(True) for t in (x, W, b))
+        y = T.LinearFn.apply(tc, xd, Wd, bd, silu_in)
+        assert rel_err(y, yr.detach()) < 1e-5
+        y.backward(dy.to(DEV))
+        assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+    # q_sample + mixed-prediction loss: the oracle's schedule and mixing (ddpm.py:383-386, 469-477)
+    B, Cc, H = 2, 8, 6
+    sched = O.make_schedule(1000)
+    t = torch.tensor([3, 900])
+    x0, nz, mo = g("tq", "x0", (B, Cc, H, H)), g("tq", "nz", (B, Cc, H, H)), g("tq", "mo", (B, Cc, H, H))
+    logit = g("tq", "logit", (1, Cc, 1, 1), 1.5)
+    a = torch.from_numpy(sched["sqrt_alphas_cumprod"])[t]
+    s = torch.from_numpy(sched["sqrt_one_minus_alphas_cumprod"])[t]
+    xt_ref = a.view(-1, 1, 1, 1) * x0 + s.view(-1, 1, 1, 1) * nz
+    xt = torch.empty_like(x0, device=DEV)
+    ad, sd = a.to(DEV).contiguous(), s.to(DEV).contiguous()
+    x0d, nzd = x0.to(DEV), nz.to(DEV)
+    _lib.check(_lib.lib().ddmi_train_q_sample(x0d.data_ptr(), nzd.data_ptr(), ad.data_ptr(), sd.data_ptr(), xt.data_ptr(), B, Cc * H * H,
+                                              _lib.stream_ptr()))
+    assert rel_err(xt, xt_ref) < 1e-6
+    mor, lr_ = mo.clone().requires_grad_(True), logit.clone().requires_grad_(True)
+    coef = torch.sigmoid(lr_)
+    eps = (1 - coef) * (s.view(-1, 1, 1, 1) * xt_ref) + coef * mor
+    loss_r = F.mse_loss(nz, eps, reduction="none").mean(dim=[1, 2, 3]).mean()
+    loss_r.backward()
+    mod, ld = mo.clone().to(DEV).requires_grad_(True), logit.clone().to(DEV).requires_grad_(True)
+    loss = T.EpsLossFn.apply(tc, mod, xt, nzd, sd, ld)
+    loss.backward()
+    assert abs(float(loss) - float(loss_r)) < 1e-6 * abs(float(loss_r))
+    assert rel_err(mod.grad, mor.grad) < 1e-5 and rel_err(ld.grad, lr_.grad) < 1e-5
+    # AdamW: three steps against torch.optim.AdamW
+    p0, grads = g("to", "p", (1000,)), [g("to", f"g{i}", (1000,)) for i in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.01)
+    pd, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for i, gr in enumerate(grads):
+        pr.grad = gr.clone()
+        opt.step()
+        gd = (gr * 4).to(DEV)   # grad_scale 0.25 undoes it: the all-reduce / accumulation factor
+        _lib.check(_lib.lib().ddmi_train_adamw(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 1000, 1e-3, 0.9, 0.999, 1e-8, 0.01, i + 1,
+                                               0.25, _lib.stream_ptr()))
+    assert rel_err(pd, pr.detach()) < 1e-6
+
+
+def _toy_trainer(golden, numerics):
+    cfg = golden.json("configs.json")["TOY_UNET"]
+    tr = T.LDMTrainStep(cfg, dict(timesteps=1000, channels=64), numerics=numerics, lr=1e-4, weight_decay=0.0, device=DEV)
+    st = {"model." + k: v for k, v in named_state("T1.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+    st["mixing_logit"] = iw.normal("T1", "mixing_logit", (1, 64, 1, 1), 0.0, 0.5)
+    tr.load_state_dict(st).finalize()
+    return tr
+
+
+def test_training_step_matches_reference_fixture_t1(golden):
+    """p_losses -> backward -> AdamW on the toy UNet == the real reference (oracle/gen_golden_train.py), parity mode."""
+    t1 = golden.npz("T1_train_step.npz")
+    tr = _toy_trainer(golden, "fp32")
+    x0, nz = g("T1", "x_start", (2, 64, 8, 8)), g("T1", "noise", (2, 64, 8, 8))
+    loss = tr.loss_and_backward(x0, torch.from_numpy(t1["t"]), nz)
+    assert abs(float(loss) - float(t1["loss"])) < TOL_FP32 * float(t1["loss"])
+    grads = {k: p.grad for k, p in tr.named_parameters()}
+    for k in [k[5:] for k in t1 if k.startswith("grad.")]:
+        assert rel_err(grads[k], t1["grad." + k]) < TOL_FP32, k
+    for k, s_ref, l2_ref in zip(t1["all_keys"], t1["all_sum"], t1["all_l2"]):     # every one of the 129 gradients
+        gk = grads[str(k)].double()
+        assert abs(float(gk.pow(2).sum().sqrt()) - l2_ref) < TOL_FP32 * l2_ref + 1e-9, k
+        assert abs(float(gk.sum()) - s_ref) < TOL_FP32 * l2_ref * np.sqrt(gk.numel()) + 1e-9, k
+    tr.optimizer_step()
+    params = dict(tr.named_parameters())
+    for k in [k[6:] for k in t1 if k.startswith("adamw.")]:
+        assert rel_err(params[k], t1["adamw." + k]) < 1e-5, k
+    assert float(tr.flat.grad.abs().max()) == 0.0      # zero_grad after the step
+
+
+def test_training_step_bf16_tracks_the_fixture(golden):
+    t1 = golden.npz("T1_train_step.npz")
+    tr = _toy_trainer(golden, "bf16")
+    x0, nz = g("T1", "x_start", (2, 64, 8, 8)), g("T1", "noise", (2, 64, 8, 8))
+    loss = tr.loss_and_backward(x0, torch.from_numpy(t1["t"]), nz)
+    assert abs(float(loss) - float(t1["loss"])) < TOL_BF16 * float(t1["loss"])
+    grads = {k: p.grad for k, p in tr.named_parameters()}
+    for k in [k[5:] for k in t1 if k.startswith("grad.")]:
+        a, b = grads[k].double().flatten().cpu(), torch.from_numpy(t1["grad." + k]).double().flatten()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.98, (k, cos)
+    # a few steps reduce the loss on a fixed batch (the optimizer really descends)
+    l0 = float(loss)
+    tr.optimizer_step()
+    for _ in range(5):
+        l1 = float(tr.train_step(x0, torch.from_numpy(t1["t"]), nz))
+    assert l1 < l0

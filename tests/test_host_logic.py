@@ -200,3 +200,19 @@ def test_shipped_configs_parse_like_the_reference_schema():
     # convocc get_generator's inputs (conv_onet/config.py:117-128): shapenet_3plane.yaml over default.yaml
     assert entry.generator_settings(a.data_config) == {"threshold": 0.2, "resolution0": 256, "upsampling_steps": 0, "padding": 0.1}
     assert a.unetconfig.in_channels == 3 * a.embed_dim and a.ddpmconfig.domain == "occupancy"
+
+
+def test_training_unet_has_the_reference_state_dict_layout(golden):
+    """ddmi_amd.train.TrainUNetModel: parameter names and shapes of the reference UNetModel.state_dict() (what LDMTrainer.save
+    writes, tools/ldm/image.py:104-119), for the toy and the full AFHQ configuration (built on the meta device: no memory)."""
+    import torch
+    from ddmi_amd.train import TrainUNetModel
+    from ddmi_amd.unet import unet_manifest
+    from helpers import AFHQ_UNET
+    toy = golden.json("configs.json")["TOY_UNET"]
+    for cfg in (toy, AFHQ_UNET):
+        with torch.device("meta"):
+            m = TrainUNetModel(**cfg, device="meta")
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        want = {k: tuple(s) for k, s in unet_manifest(**cfg)}
+        assert got == want
