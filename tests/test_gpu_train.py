@@ -103,7 +103,7 @@ def test_attention_legacy_backward_vs_torch(numerics, tol, heads, Tside):
     out = T.AttentionLegacyFn.apply(tc, qd, heads)
     assert rel_err(nchw(out).reshape(B, heads * d, -1), out_r.detach()) < tol
     out.backward(dout.reshape(B, heads * d, Tside, Tside).permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype))
-    assert rel_err(nchw(qd.grad).reshape(B, heads * 3 * d, -1), qr.grad) < tol
+    assert rel_err(nchw(qd.grad), qr.grad) < tol
 
 
 def test_linear_loss_adamw_qsample_vs_torch():
@@ -176,16 +176,36 @@ def test_training_step_matches_reference_fixture_t1(golden):
     loss = tr.loss_and_backward(x0, torch.from_numpy(t1["t"]), nz)
     assert abs(float(loss) - float(t1["loss"])) < TOL_FP32 * float(t1["loss"])
     grads = {k: p.grad for k, p in tr.named_parameters()}
+    # gradients that are analytically ZERO come back as fp32 rounding noise on both sides (the toy UNet's 32-channel blocks
+    # have ONE channel per GroupNorm group, so a per-channel constant added before the norm - conv bias, time-embedding
+    # addend - cannot change the output: |grad| ~ 1e-9 against 1e-2 elsewhere).  They are held to an absolute bound.
+    floor = 1e-6 * float(t1["all_l2"].max())
+    bad = {}
     for k in [k[5:] for k in t1 if k.startswith("grad.")]:
-        assert rel_err(grads[k], t1["grad." + k]) < TOL_FP32, k
+        ref = t1["grad." + k]
+        if float(np.sqrt((ref.astype(np.float64) ** 2).sum())) < floor:
+            if float(grads[k].abs().max()) > floor:
+                bad[k] = "noise-level gradient came back large"
+        elif not rel_err(grads[k], ref) < TOL_FP32:
+            bad[k] = rel_err(grads[k], ref)
+    assert not bad, bad
     for k, s_ref, l2_ref in zip(t1["all_keys"], t1["all_sum"], t1["all_l2"]):     # every one of the 129 gradients
         gk = grads[str(k)].double()
-        assert abs(float(gk.pow(2).sum().sqrt()) - l2_ref) < TOL_FP32 * l2_ref + 1e-9, k
-        assert abs(float(gk.sum()) - s_ref) < TOL_FP32 * l2_ref * np.sqrt(gk.numel()) + 1e-9, k
+        assert abs(float(gk.pow(2).sum().sqrt()) - l2_ref) < TOL_FP32 * l2_ref + floor, k
+        assert abs(float(gk.sum()) - s_ref) < TOL_FP32 * l2_ref * np.sqrt(gk.numel()) + floor, k
     tr.optimizer_step()
     params = dict(tr.named_parameters())
     for k in [k[6:] for k in t1 if k.startswith("adamw.")]:
-        assert rel_err(params[k], t1["adamw." + k]) < 1e-5, k
+        # Adam's first step is lr * sign(g): where the gradient is analytically zero (whole tensors, see above; the key third of
+        # a qkv bias - softmax is invariant to a constant added to a row of logits) the sign of rounding noise decides, which is
+        # not a property of the algorithm.  Those elements are masked; everything else must agree.
+        gref = np.abs(t1["grad." + k])
+        live = torch.from_numpy(gref > 1e-4 * gref.max() + floor * 1e-3).to(DEV)
+        if not bool(live.any()):
+            continue
+        ref = torch.from_numpy(t1["adamw." + k]).to(DEV)
+        err = float(((params[k].detach() - ref).abs() * live).max() / ref.abs().max())
+        assert err < 1e-5, (k, err)
     assert float(tr.flat.grad.abs().max()) == 0.0      # zero_grad after the step
 
 
@@ -196,8 +216,12 @@ def test_training_step_bf16_tracks_the_fixture(golden):
     loss = tr.loss_and_backward(x0, torch.from_numpy(t1["t"]), nz)
     assert abs(float(loss) - float(t1["loss"])) < TOL_BF16 * float(t1["loss"])
     grads = {k: p.grad for k, p in tr.named_parameters()}
+    floor = 1e-6 * float(t1["all_l2"].max())
     for k in [k[5:] for k in t1 if k.startswith("grad.")]:
         a, b = grads[k].double().flatten().cpu(), torch.from_numpy(t1["grad." + k]).double().flatten()
+        if float(b.norm()) < floor:     # analytically zero (see the fp32 test): bf16 noise must stay small
+            assert float(a.norm()) < 1e-3 * float(t1["all_l2"].max()), k
+            continue
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.98, (k, cos)
     # a few steps reduce the loss on a fixed batch (the optimizer really descends)
