@@ -511,13 +511,67 @@ def cpu_baseline_sky(a, nfe):
             "unet_eval_s": t_unet}
 
 
+# ======================================================================================================================
+def run_train(args, rank, local_rank, world, dev):
+    """the LDM training step (tools/ldm/image.py:158-175) on the full AFHQ UNet - q_sample, UNet forward,
+    mixed-prediction MSE, backward, gradient all-reduce of the 2.08 GB slab (RCCL), fused AdamW - on synthetic latents."""
+    import torch
+    from ddmi_amd import _lib
+    from ddmi_amd import dist as D
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.train import LDMTrainStep
+    B = args.batch or 16
+    tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev)
+    st = {"model." + k: v for k, v in iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+    tr.load_state_dict(st, strict=False).finalize()
+    g = torch.Generator(device=dev).manual_seed(args.seed + rank)
+
+    def one_step():
+        z = torch.randn((B, 64, 64, 64), device=dev, generator=g)
+        return tr.train_step(z, world_size=world)
+
+    for _ in range(max(1, args.warmup)):
+        one_step()
+    _lib.profile_enable(1)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    prof = _lib.profile_collect()
+    _lib.profile_enable(0)
+    nranks = D.group_size(dev)
+    if rank != 0:
+        return None
+    conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
+    tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
+    flops = 3.0 * 265.5e9 * B * args.steps   # forward + dgrad + wgrad of the 265.5 GFLOP / sample forward (SURVEY 8d)
+    line = {"metric": "training samples/sec (whole node), AFHQ LDM step: p_losses + backward + all-reduce + AdamW",
+            "value": args.steps * world * B / elapsed, "unit": "samples/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "AFHQ UNet (519 M parameters) training step on synthetic [B,64,64,64] latents: q_sample, forward, mixed-prediction "
+                                   "MSE, backward (conv dgrad / wgrad on the forward MFMA kernels), flat-slab gradient all-reduce, fused AdamW; "
+                                   "fp32 master weights, bf16 activations", "batch_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"data-parallel x{world} (one 2.08 GB gradient all-reduce per step, two 1 GiB buckets)"},
+            "nccl_ranks": nranks, "loss_last_step": float(loss),
+            "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None),
+            "step_mfma_frac": round(flops / elapsed / 1e12 / PEAK_BF16_TFLOPS / world, 4),
+            "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
+            "profiled_kernel_ms_per_step": round(tot_ms / args.steps, 1)}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky"])
-    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 64, sky 16)")
+    ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 64, sky 16, train 16)")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
@@ -541,7 +595,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
-    line = {"afhq": run_afhq, "shapenet": run_shapenet, "sky": run_sky}[args.workload](args, rank, local_rank, world, dev)
+    line = {"afhq": run_afhq, "shapenet": run_shapenet, "sky": run_sky, "train": run_train}[args.workload](args, rank, local_rank, world, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

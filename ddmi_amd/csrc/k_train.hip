@@ -144,6 +144,7 @@ int launch_pack_dgrad_weight(const float* w, void* out, int dt, int Co, int Ci, 
 }
 int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo, int C, hipStream_t s) {
   const int64_t n = (int64_t)B * 4 * Ho * Wo * C;
+  PROF_SCOPE("dgrad_layout", 0, 1.25 * n * dt_size(dt), s);
   if (dt == DT_F32) hipLaunchKernelGGL(zero_insert2x_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)dy, (float*)u, B, Ho, Wo, C);
   else hipLaunchKernelGGL(zero_insert2x_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)u, B, Ho, Wo, C);
   HIP_TRY(hipGetLastError());
@@ -151,6 +152,7 @@ int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo,
 }
 int launch_sumpool2x(const void* up, void* dx, int dt, int B, int H, int W, int C, hipStream_t s) {
   const int64_t n = (int64_t)B * H * W * C;
+  PROF_SCOPE("dgrad_layout", 0, 5.0 * n * dt_size(dt), s);
   if (dt == DT_F32) hipLaunchKernelGGL(sumpool2x_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)up, (float*)dx, B, H, W, C);
   else hipLaunchKernelGGL(sumpool2x_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, (const bf16_t*)up, (bf16_t*)dx, B, H, W, C);
   HIP_TRY(hipGetLastError());
@@ -160,6 +162,7 @@ int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int C
                     hipStream_t s) {
   const int64_t P = (int64_t)B * Ho * Wo;
   dim3 g((unsigned)cdiv64(P, 32), (unsigned)cdiv(Ci, 32), (unsigned)(k * k));
+  PROF_SCOPE("wgrad_im2col_t", 0, 2.0 * k * k * (double)P * Ci * dt_size(dt), s);
   if (dt == DT_F32) hipLaunchKernelGGL(im2col_t_kernel<float>, g, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
   else hipLaunchKernelGGL(im2col_t_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
   HIP_TRY(hipGetLastError());
@@ -172,6 +175,7 @@ int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, hipSt
 }
 int launch_sum_hw(const void* dy, float* out, int dt, int B, int HW, int C, hipStream_t s) {
   dim3 g((unsigned)cdiv(C, 64), (unsigned)B);
+  PROF_SCOPE("bias_emb_grad", 0, (double)B * HW * C * dt_size(dt), s);
   if (dt == DT_F32) hipLaunchKernelGGL(sum_hw_kernel<float>, g, dim3(256), 0, s, (const float*)dy, out, HW, C);
   else hipLaunchKernelGGL(sum_hw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)dy, out, HW, C);
   HIP_TRY(hipGetLastError());
@@ -268,6 +272,7 @@ int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, con
   dim3 g(TR_GROUPS, B);
   const size_t lds = 4 * 256 * sizeof(float);
   const int64_t n = (int64_t)B * HW * C;
+  PROF_SCOPE("gn_bwd", 0, 5.0 * n * dt_size(dt), s);
   if (dt == DT_F32) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, g, dim3(256), lds, s, (const float*)x, (const float*)dy, meanrstd, gamma, beta, ab, dgp, dbp, HW, C, silu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)x, (const float*)dy, meanrstd, ab, gamma, beta,
@@ -559,6 +564,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float grad_scale, hipStream_t s) {
   DDMI_REQUIRE(step >= 1, "adamw: step counts from 1");
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  PROF_SCOPE("adamw", 0, 28.0 * n, s);
   hipLaunchKernelGGL(adamw_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), grad_scale);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;

@@ -157,7 +157,10 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
     void* A = c.take((size_t)Cout * P * es);
     void* Bm = c.take((size_t)N * P * es);
     float* G = (float*)c.take((size_t)N * Cout * sizeof(float));
-    DDMI_TRY(launch_transpose_2d(dy, A, dt, 1, (int)P, Cout, s));                       // A[co][p] = dY[p][co]
+    {
+      PROF_SCOPE("wgrad_transpose", 0, 2.0 * (double)P * Cout * es, s);
+      DDMI_TRY(launch_transpose_2d(dy, A, dt, 1, (int)P, Cout, s));                     // A[co][p] = dY[p][co]
+    }
     DDMI_TRY(launch_im2col_t(x, Bm, dt, B, H, W, Cin, Ho, Wo, k, stride, k / 2, ups ? 1 : 0, s));
     g.x = A; g.w = Bm; g.y_nchw = G;
     if (g.splitk > 1) g.splitk_ws = (float*)c.take((size_t)g.splitk * Cout * N * sizeof(float));
@@ -228,6 +231,7 @@ int ddmi_train_timestep_embedding(ddmi_train* h, const int64_t* t, float* out, i
 int ddmi_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* x_t, int B,
                         int64_t per_sample, void* stream) {
   DDMI_REQUIRE(x0 && noise && sqrt_ac && sqrt_1mac && x_t && B > 0 && per_sample > 0, "train_q_sample: bad arguments");
+  prof_begin_forward();   // a training step starts here: applies the profiler's sampling period (ddmi_profile_enable)
   return launch_q_sample(x0, noise, sqrt_ac, sqrt_1mac, x_t, B, per_sample, (hipStream_t)stream);
 }
 int ddmi_train_eps_loss(ddmi_train* h, const float* model_out, const float* x_t, const float* noise, const float* sqrt_1mac,

@@ -418,6 +418,22 @@ class FlatParams:
         self.grad.zero_()
 
 
+def allreduce_gradients(flat_grad: torch.Tensor, world_size: int, bucket_bytes: int = 1 << 30) -> torch.Tensor:
+    """Sum of the flat gradient slab over the data-parallel ranks (RCCL all-reduce over xGMI with the `nccl` backend; `gloo` in
+    the CPU tests) - what accelerate's DDP wrapper does for the reference (tools/ldm/image.py:96, 165).  The slab is reduced
+    in place in buckets of `bucket_bytes` (1 GiB: two collectives for the AFHQ UNet's 2.08 GB - a ring all-reduce over 7 xGMI
+    links is bandwidth-bound per link, so few large buckets; issued back to back on the collective stream they also overlap
+    their own reduce-scatter / all-gather phases).  The 1 / world_size of DDP's mean is folded into the AdamW kernel."""
+    import torch.distributed as dist
+    if world_size <= 1 or not dist.is_initialized():
+        return flat_grad
+    n_per = max(1, bucket_bytes // flat_grad.element_size())
+    works = [dist.all_reduce(flat_grad[a:a + n_per], async_op=True) for a in range(0, flat_grad.numel(), n_per)]
+    for w in works:
+        w.wait()
+    return flat_grad
+
+
 class LDMTrainStep:
     """`DDPM.forward` + backward + optimizer step of the reference's LDM trainer on one GPU of a data-parallel job.
 
@@ -502,9 +518,7 @@ class LDMTrainStep:
 
     def optimizer_step(self, world_size: int = 1):
         """All-reduce (sum) of the gradient slab over the ranks, fused AdamW, EMA every `ema_update_every` steps."""
-        import torch.distributed as dist
-        if world_size > 1 and dist.is_initialized():
-            dist.all_reduce(self.flat.grad)            # one bucket: the whole slab (2.08 GB for the AFHQ UNet, SURVEY 2.2)
+        allreduce_gradients(self.flat.grad, world_size)
         self.opt_step += 1
         f = self.flat
         _lib.check(_lib.lib().ddmi_train_adamw(f.data.data_ptr(), f.grad.data_ptr(), f.exp_avg.data_ptr(), f.exp_avg_sq.data_ptr(), f.n,
@@ -514,6 +528,25 @@ class LDMTrainStep:
         self.micro = 0
         if self.opt_step % self.ema_every == 0:
             _lib.check(_lib.lib().ddmi_train_ema(self.ema.data_ptr(), f.data.data_ptr(), f.n, self.ema_decay, _stream()))
+
+    # ---- checkpoints: the dict LDMTrainer.save writes (tools/ldm/image.py:104-119), minus the VAE / MLP it does not train ----
+    def checkpoint(self, vaemodel_state=None, mlp_state=None) -> Dict[str, object]:
+        sd = self.state_dict()
+        keys = [k for k, _ in self.named_parameters()]
+        ema, off = {}, 0
+        for k, (_, p) in zip(keys, self.named_parameters()):
+            ema["ema_model." + k] = self.ema[off:off + p.numel()].view(p.shape).clone()
+            ema["online_model." + k] = p.detach().clone()
+            off += p.numel()
+        ema["initted"], ema["step"] = torch.tensor(True), torch.tensor(self.opt_step)
+        return {"step": self.opt_step, "current_iters": self.opt_step * self.accum, "vaemodel": vaemodel_state or {}, "mlp": mlp_state or {},
+                "diffusion": sd, "ema": ema,
+                "dae_opt": {"exp_avg": self.flat.exp_avg.clone(), "exp_avg_sq": self.flat.exp_avg_sq.clone(), "step": self.opt_step,
+                            "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd},
+                "scaler": None}
+
+    def save(self, path, vaemodel_state=None, mlp_state=None):
+        torch.save(self.checkpoint(vaemodel_state, mlp_state), path)
 
     def train_step(self, z0, t=None, noise=None, world_size: int = 1):
         """The body of the reference's loop for one batch (tools/ldm/image.py:158-175)."""

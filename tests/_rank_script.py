@@ -28,6 +28,11 @@ def fake_finalize():
     rec["finalized_from"] = open(p).read() if p else None
 
 
+# the training step's gradient all-reduce (ddmi_amd/train.py): bucketed sum of the flat slab, in place
+from ddmi_amd.train import allreduce_gradients  # noqa: E402
+slab = torch.arange(10, dtype=torch.float32, device=dev) * (rank + 1)
+allreduce_gradients(slab, world, bucket_bytes=16)          # 4-element buckets: three collectives
+rec["grad_slab"] = slab.tolist()
 os.environ.pop("DDMI_TUNE_FILE", None)
 D.finalize_with_shared_plans(fake_finalize, rank, world)
 with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:

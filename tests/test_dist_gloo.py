@@ -65,6 +65,8 @@ def test_self_launch_starts_the_ranks(tmp_path):
         assert rec["world"] == 2 and rec["ranks"] == 2 and rec["rows"] == [0.0, 0.0, 1.0, 1.0] and rec["max"] == 1.0
         # one set of convolution plans for the whole job: every rank finalizes from rank 0's file
         assert rec["finalized_from"] == "v 2\nplans tuned by rank 0\n"
+        # the training step's bucketed gradient all-reduce: rank r held (r + 1) * arange(10) -> the sum is 3 * arange(10)
+        assert rec["grad_slab"] == [3.0 * i for i in range(10)]
     # a failing rank is the launcher's failure
     assert D.launch_ranks(2, os.path.join(ROOT, "tests", "_rank_script.py"), [os.path.join(str(tmp_path), "missing")]) != 0
 

@@ -230,3 +230,35 @@ def test_training_step_bf16_tracks_the_fixture(golden):
     for _ in range(5):
         l1 = float(tr.train_step(x0, torch.from_numpy(t1["t"]), nz))
     assert l1 < l0
+
+
+def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path):
+    """A few steps -> LDMTrainStep.save (the dict LDMTrainer.save writes, tools/ldm/image.py:104-119) -> ImagePipeline.load_checkpoint:
+    the inference UNet on the saved online weights equals the training-path forward, the EMA copy is what use_ema picks."""
+    import os
+    from ddmi_amd.pipeline import ImagePipeline
+    cfgs = golden.json("configs.json")
+    tr = _toy_trainer(golden, "fp32")
+    tr.ema_every = 1
+    x0, nz = g("T1", "x_start", (2, 64, 8, 8)), g("T1", "noise", (2, 64, 8, 8))
+    for i in range(3):
+        tr.train_step(x0, torch.tensor([3 + i, 900 - i]), nz)
+    pipe = ImagePipeline(cfgs["TOY_UNET"], cfgs["TOY_DD"], cfgs["MLP_CFG"], dict(timesteps=1000, sampling_timesteps=10, channels=64, image_size=8),
+                         cfgs["TOY_EMBED"], test_resolution=32, numerics="fp32", max_batch=2, device=DEV)
+    tt = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+    path = os.path.join(tmp_path, "ldm-last.pt")
+    tr.save(path, vaemodel_state=tt(named_state("ck.vae", pipe.vae.manifest())), mlp_state=tt(named_state("ck.mlp", pipe.mlp.manifest())))
+    xt, t = g("T1", "probe", (2, 64, 8, 8)).to(DEV), torch.tensor([17, 640], device=DEV)
+    with torch.no_grad():
+        want = tr.model(xt, t).clone()
+    pipe.load_checkpoint(path, use_ema=False)
+    pipe.finalize()
+    assert rel_err(pipe.unet(xt, t), want) < 1e-5
+    assert rel_err(pipe.ddpm.mixing_logit, tr.mixing_logit.detach()) < 1e-7
+    # EMA: decay 0.9999 per step from the initial snapshot - close to, but not, the online weights
+    pipe2 = ImagePipeline(cfgs["TOY_UNET"], cfgs["TOY_DD"], cfgs["MLP_CFG"], dict(timesteps=1000, sampling_timesteps=10, channels=64, image_size=8),
+                          cfgs["TOY_EMBED"], test_resolution=32, numerics="fp32", max_batch=2, device=DEV)
+    pipe2.load_checkpoint(path, use_ema=True)
+    pipe2.finalize()
+    e = rel_err(pipe2.unet(xt, t), want)
+    assert 0 < e < 5e-2
