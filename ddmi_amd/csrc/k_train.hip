@@ -111,17 +111,28 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ G, float* __restri
   }
 }
 
-// out[b][c] = sum over HW of dy[b][hw][c]   (grid (ceil(C/64), B), block 256 = 64 channels x 4 pixel lanes)
+// out[b][c] = sum over HW of dy[b][hw][c].  grid (ceil(C/64), B, S): S pixel slices per sample so that a launch fills the
+// chip (a [B, C/64] grid alone leaves most CUs idle); block 256 = 64 channels x 4 pixel lanes; the S partials of a (b, c)
+// are added by sum_slices_kernel in slice order (deterministic).
 template <typename T>
-__global__ void __launch_bounds__(256) sum_hw_kernel(const T* __restrict__ dy, float* __restrict__ out, int HW, int C) {
+__global__ void __launch_bounds__(256) sum_hw_kernel(const T* __restrict__ dy, float* __restrict__ part, int HW, int C, int S) {
   __shared__ float red[4][64];
-  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6, z = blockIdx.z;
+  const int per = (HW + S - 1) / S, p0 = z * per, p1 = min(HW, p0 + per);
   float acc = 0.f;
   if (c < C)
-    for (int p = lane; p < HW; p += 4) acc += tr_ld(dy + ((int64_t)b * HW + p) * C + c);
+    for (int p = p0 + lane; p < p1; p += 4) acc += tr_ld(dy + ((int64_t)b * HW + p) * C + c);
   red[lane][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (lane == 0 && c < C) out[(int64_t)b * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (lane == 0 && c < C)
+    part[((int64_t)z * gridDim.y + b) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int S) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int z = 0; z < S; ++z) acc += part[(int64_t)z * n + i];
+  out[i] = acc;
 }
 
 // out[c] = sum_b in[b][c]
@@ -173,11 +184,19 @@ int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, hipSt
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
-int launch_sum_hw(const void* dy, float* out, int dt, int B, int HW, int C, hipStream_t s) {
-  dim3 g((unsigned)cdiv(C, 64), (unsigned)B);
+int sum_hw_slices(int B, int HW, int C) {   // pixel slices per sample: ~1024 blocks per launch, at least 64 pixels per slice
+  const int base = std::max(1, cdiv(C, 64) * B);
+  return std::max(1, std::min(std::min(cdiv(1024, base), HW / 64), 64));
+}
+// `part` = scratch of sum_hw_slices(B, HW, C) * B * C floats (unused when the slice count is 1)
+int launch_sum_hw(const void* dy, float* out, float* part, int dt, int B, int HW, int C, hipStream_t s) {
+  const int S = sum_hw_slices(B, HW, C);
+  dim3 g((unsigned)cdiv(C, 64), (unsigned)B, (unsigned)S);
   PROF_SCOPE("bias_emb_grad", 0, (double)B * HW * C * dt_size(dt), s);
-  if (dt == DT_F32) hipLaunchKernelGGL(sum_hw_kernel<float>, g, dim3(256), 0, s, (const float*)dy, out, HW, C);
-  else hipLaunchKernelGGL(sum_hw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)dy, out, HW, C);
+  float* dst = S == 1 ? out : part;
+  if (dt == DT_F32) hipLaunchKernelGGL(sum_hw_kernel<float>, g, dim3(256), 0, s, (const float*)dy, dst, HW, C, S);
+  else hipLaunchKernelGGL(sum_hw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)dy, dst, HW, C, S);
+  if (S > 1) hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)cdiv64((int64_t)B * C, 256)), dim3(256), 0, s, part, out, (int64_t)B * C, S);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

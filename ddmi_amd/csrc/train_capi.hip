@@ -123,13 +123,15 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
                                 : 0;
   const size_t wgrad_bytes = al((size_t)Cout * P * es) + al((size_t)N * P * es) + al((size_t)N * Cout * sizeof(float)) +
                              (g.splitk > 1 ? al((size_t)g.splitk * Cout * N * sizeof(float)) : 0);
-  const size_t red_bytes = al((size_t)B * Cout * sizeof(float));
+  const size_t red_bytes = al((size_t)B * Cout * sizeof(float)) * (1 + (size_t)sum_hw_slices(B, Ho * Wo, Cout));
   DDMI_TRY(reserve(h, std::max(dgrad_bytes, wgrad_bytes) + red_bytes, s));
   // ---- bias / embedding gradients ---------------------------------------------------------------------------
   if (dbias || demb) {
     Carve c{h};
-    float* per = demb ? demb : (float*)c.take(red_bytes);
-    DDMI_TRY(launch_sum_hw(dy, per, dt, B, Ho * Wo, Cout, s));
+    float* per0 = (float*)c.take(al((size_t)B * Cout * sizeof(float)));
+    float* part = (float*)(h->ws + al((size_t)B * Cout * sizeof(float)));
+    float* per = demb ? demb : per0;
+    DDMI_TRY(launch_sum_hw(dy, per, part, dt, B, Ho * Wo, Cout, s));
     if (dbias) DDMI_TRY(launch_sum_b(per, dbias, B, Cout, s));
   }
   // ---- dgrad ------------------------------------------------------------------------------------------------

@@ -261,4 +261,11 @@ def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path)
     pipe2.load_checkpoint(path, use_ema=True)
     pipe2.finalize()
     e = rel_err(pipe2.unet(xt, t), want)
-    assert 0 < e < 5e-2
+    assert 0 < e < 0.5       # three lr = 1e-4 Adam steps moved every weight by 3e-4: ~10 % in the output of this random net
+    # and it is exactly the EMA slab: the training-path forward on those weights gives the same output
+    with torch.no_grad():
+        keep = tr.flat.data.clone()
+        tr.flat.data.copy_(tr.ema)
+        want_ema = tr.model(xt, t).clone()
+        tr.flat.data.copy_(keep)
+    assert rel_err(pipe2.unet(xt, t), want_ema) < 1e-5
