@@ -262,7 +262,9 @@ def run_afhq(args, rank, local_rank, world, dev):
                    "noise": {"philox": "per-chain Philox streams drawn in the sampler-step kernel",
                              "torch": "one torch device generator per chain",
                              "reference": "torch.manual_seed + CPU randn in the reference's draw order"}[args.rng],
-                   "conv_plans": "shared (rank 0's autotune broadcast)" if world > 1 else (plans or "autotuned at finalize")},
+                   "conv_plans": "shared (rank 0's plans broadcast)" if world > 1 else
+                                 (plans or (os.environ.get("DDMI_TUNE_DEFAULT", "") and "shipped plan file + autotune for other shapes")
+                                  or "autotuned at finalize")},
         "nccl_ranks": nranks,
         "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None),
         "unet_step_mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
