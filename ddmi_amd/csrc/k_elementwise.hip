@@ -101,6 +101,68 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const float* __restrict_
   }
 }
 
+// The sampling loop's form of the step (float4 vectors, < 2^31 quads, <= 1024 channels): the per-channel mixing
+// coefficient sigmoid(logit[c]) is computed once per block into LDS (the general kernel evaluated expf and two 64-bit
+// divisions per ELEMENT), sample / channel of a quad come from 32-bit divisions, and the noise is drawn with the
+// hardware transcendentals (philox.h).  HBM-bound: 12 B per element with in-kernel noise (x, eps in; x out).
+__global__ void __launch_bounds__(256) ddpm_step_fast_kernel(const float* __restrict__ x, const float* __restrict__ mo,
+                                                             const float* __restrict__ noise, const uint64_t* __restrict__ seeds,
+                                                             unsigned tag, const float* __restrict__ logit, StepCoefs k, int mode,
+                                                             int clip, float* __restrict__ out, float* __restrict__ x0_out, unsigned C,
+                                                             unsigned hw4, unsigned nquad) {
+  __shared__ float coef[1024];
+  for (unsigned c = threadIdx.x; c < C; c += 256) coef[c] = logit ? 1.0f / (1.0f + expf(-logit[c])) : 1.0f;
+  __syncthreads();
+  const unsigned qps = C * hw4;   // quads per sample
+  const unsigned stride = gridDim.x * 256;
+  auto one = [&](unsigned i, const float4& a, const float4& m, const float4& zn) {
+    const unsigned b = i / qps, r = i - b * qps, c = r / hw4;
+    float nv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mode != STEP_DDIM_LAST) {
+      if (seeds != nullptr) {
+        normal4(seeds[b], tag, r, nv);
+      } else if (noise != nullptr) {
+        nv[0] = zn.x; nv[1] = zn.y; nv[2] = zn.z; nv[3] = zn.w;
+      }
+    }
+    const float co = coef[c];
+    const float xv[4] = {a.x, a.y, a.z, a.w}, mv[4] = {m.x, m.y, m.z, m.w};
+    float ov[4], zv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float eps = mv[j];
+      if (logit != nullptr) {   // same operation order as the general kernel: results are bit-identical
+        const float mix = k.sqrt_one_minus_ac * xv[j];
+        eps = (1.0f - co) * mix + co * mv[j];
+      }
+      float x0 = k.sqrt_recip_ac * xv[j] - k.sqrt_recipm1_ac * eps;
+      if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      float rr;
+      if (mode == STEP_ANCESTRAL) rr = (k.coef1 * x0 + k.coef2 * xv[j]) + k.noise_scale * nv[j];
+      else if (mode == STEP_DDIM) rr = x0 * k.sqrt_ac_next + k.c_dir * eps + k.sigma * nv[j];
+      else rr = x0;
+      ov[j] = rr;
+      zv[j] = x0;
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (x0_out) reinterpret_cast<float4*>(x0_out)[i] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+  };
+  const bool rd_noise = noise != nullptr && seeds == nullptr && mode != STEP_DDIM_LAST;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned i = blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < nquad; i += 2 * stride) {   // two quads per trip: four (six) 16-byte loads in flight per thread
+    const float4 a0 = reinterpret_cast<const float4*>(x)[i], a1 = reinterpret_cast<const float4*>(x)[i + stride];
+    const float4 m0 = reinterpret_cast<const float4*>(mo)[i], m1 = reinterpret_cast<const float4*>(mo)[i + stride];
+    const float4 z0 = rd_noise ? reinterpret_cast<const float4*>(noise)[i] : zero4;
+    const float4 z1 = rd_noise ? reinterpret_cast<const float4*>(noise)[i + stride] : zero4;
+    one(i, a0, m0, z0);
+    one(i + stride, a1, m1, z1);
+  }
+  if (i < nquad)
+    one(i, reinterpret_cast<const float4*>(x)[i], reinterpret_cast<const float4*>(mo)[i],
+        rd_noise ? reinterpret_cast<const float4*>(noise)[i] : zero4);
+}
+
 int launch_ddpm_step(const float* x, const float* model_out, const float* noise, const float* mixing_logit,
                      StepCoefs k, int mode, int clip, float* x_out, float* x0_out, int B, int C, int HW,
                      hipStream_t stream, const uint64_t* seeds, unsigned tag) {
@@ -114,7 +176,10 @@ int launch_ddpm_step(const float* x, const float* model_out, const float* noise,
   int64_t nvec = vec4 ? n / 4 : n;
   int blocks = (int)std::min<int64_t>(cdiv64(nvec, 256), 256 * 8);
   PROF_SCOPE("ddpm_step", 0, (noise && mode != STEP_DDIM_LAST ? 16.0 : 12.0) * (double)n, stream);
-  if (vec4)
+  if (vec4 && nvec < (int64_t)1 << 31 && C <= 1024)
+    hipLaunchKernelGGL(ddpm_step_fast_kernel, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, seeds, tag, mixing_logit, k,
+                       mode, clip, x_out, x0_out, (unsigned)C, (unsigned)(HW / 4), (unsigned)nvec);
+  else if (vec4)
     hipLaunchKernelGGL(ddpm_step_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, model_out, noise, seeds, tag,
                        mixing_logit, k, mode, clip, x_out, x0_out, C, HW, nvec);
   else

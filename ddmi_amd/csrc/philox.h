@@ -25,11 +25,13 @@ __device__ __forceinline__ void normal4(uint64_t seed, unsigned tag, unsigned qu
   // u in (0, 1]: 24-bit mantissas, never 0 so the logarithm is finite
   const float u0 = ((r[0] >> 8) + 1) * (1.0f / 16777216.0f), u1 = (r[1] >> 8) * (1.0f / 16777216.0f);
   const float u2 = ((r[2] >> 8) + 1) * (1.0f / 16777216.0f), u3 = (r[3] >> 8) * (1.0f / 16777216.0f);
-  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-  float s0, c0, s1, c1;
-  sincospif(2.0f * u1, &s0, &c0);
-  sincospif(2.0f * u3, &s1, &c1);
-  z[0] = ra * c0; z[1] = ra * s0; z[2] = rb * c1; z[3] = rb * s1;
+  // Box-Muller on the hardware transcendentals: v_log_f32 (log2, 1 ulp), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
+  // revolutions - exactly what the uniform is).  The libm forms (logf, sincospif: ~300 instructions per quad) made the
+  // sampler-step kernel VALU-bound at 2.9 TB/s; every consumer of the streams goes through this one function.
+  const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // -2 ln u = -2 ln2 log2 u
+  const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  z[0] = ra * __builtin_amdgcn_cosf(u1); z[1] = ra * __builtin_amdgcn_sinf(u1);
+  z[2] = rb * __builtin_amdgcn_cosf(u3); z[3] = rb * __builtin_amdgcn_sinf(u3);
 }
 
 // stream tags: step n of a sampling loop uses tag n, x_T 0xFFFFFFFF; NoiseInjection draw of StyledConv c (0..11, call

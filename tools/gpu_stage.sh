@@ -18,6 +18,8 @@ for st in "$@"; do
     occvid)    timeout 1200 python -m pytest tests/test_gpu_occupancy.py tests/test_gpu_video.py -q > $log 2>&1 ;;
     train)     timeout 1500 python -m pytest tests/test_gpu_train.py -q -x > $log 2>&1 ;;
     trainall)  timeout 1500 python -m pytest tests/test_gpu_train.py -q > $log 2>&1 ;;
+    stepbench) timeout 300 python tools/bench_step.py > $log 2>&1 ;;
+    opstests)  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_networks.py -q -k "philox or ddpm_step or pipeline or generate_chain" > $log 2>&1 ;;
     mlpts)     DDMI_MLP2D_TS=1 timeout 300 python tools/bench_mlp.py --which 2d > $log 2>&1 ;;
     bench)     timeout 1500 python bench.py --steps 1 --warmup 1 > gpurun_out/${tag}_bench.json 2> $log ;;
     benchfast) timeout 900 python bench.py --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchfast.json 2> $log ;;
