@@ -522,7 +522,7 @@ def run_train(args, rank, local_rank, world, dev):
     from ddmi_amd import dist as D
     from ddmi_amd import initweights as iw
     from ddmi_amd.train import LDMTrainStep
-    B = args.batch or 16
+    B = args.batch or 64
     tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev)
     st = {"model." + k: v for k, v in iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
     tr.load_state_dict(st, strict=False).finalize()
@@ -560,7 +560,7 @@ def run_train(args, rank, local_rank, world, dev):
                                    "fp32 master weights, bf16 activations", "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"data-parallel x{world} (one 2.08 GB gradient all-reduce per step, two 1 GiB buckets)"},
             "nccl_ranks": nranks, "loss_last_step": float(loss),
-            "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None),
+            "roofline": dict(roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None) or {}, traffic=None),
             "step_mfma_frac": round(flops / elapsed / 1e12 / PEAK_BF16_TFLOPS / world, 4),
             "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
             "profiled_kernel_ms_per_step": round(tot_ms / args.steps, 1)}
@@ -573,7 +573,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
-    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 64, sky 16, train 16)")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 64, sky 16, train 64)")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")

@@ -100,14 +100,58 @@ __global__ void __launch_bounds__(256) im2col_t_kernel(const T* __restrict__ x, 
   }
 }
 
+// bf16 form with 16-byte accesses on both sides: a 64-pixel x 64-channel tile per block (one tap).  Reads are bf16x8 along
+// the channels of a pixel (NHWC rows), writes bf16x8 along the pixels of a channel (rows of the transposed image); the
+// transpose goes through an LDS tile with a 144-byte pitch.  The scalar kernel above moved 2 bytes per access: 0.85 TB/s.
+__global__ void __launch_bounds__(256) im2col_t_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W,
+                                                           int Ci, int Ho, int Wo, int k, int stride, int pad, int ups) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];
+  const int64_t P = (int64_t)B * Ho * Wo;
+  const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int Hin = ups ? 2 * H : H, Win = ups ? 2 * W : W;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x + 256 * j, r = idx >> 3, c8 = (idx & 7) * 8;
+    const int64_t p = p0 + r;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+    if (p < P && c0 + c8 < Ci) {
+      const int ow = (int)(p % Wo), oh = (int)((p / Wo) % Ho);
+      const int b = (int)(p / ((int64_t)Ho * Wo));
+      int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+      if (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) {
+        if (ups) { ih >>= 1; iw >>= 1; }
+        v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + ih) * W + iw) * Ci + c0 + c8);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(tile + r * 72 + c8) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x + 256 * j, c = idx >> 3, p8 = (idx & 7) * 8;
+    if (c0 + c < Ci && p0 + p8 < P) {   // P is a multiple of 8: a vector is wholly inside or outside
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[(p8 + e) * 72 + c];
+      *reinterpret_cast<bf16x8*>(out + ((int64_t)tap * Ci + c0 + c) * P + p0 + p8) = v;
+    }
+  }
+}
+
 // dw[co][ci][kh][kw] = G[tap * Ci + ci][co]   (G = the fp32 output of the pixel-axis GEMM, [taps * Ci][Co])
-__global__ void wgrad_finish_kernel(const float* __restrict__ G, float* __restrict__ dw, int Co, int Ci, int kk) {
+// accumulate != 0: dw += ... (the pixel axis is processed in chunks when the im2col image would exceed the 2 GiB descriptor range)
+__global__ void wgrad_finish_kernel(const float* __restrict__ G, float* __restrict__ dw, int Co, int Ci, int kk, int accumulate) {
   const int64_t n = (int64_t)Co * Ci * kk;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % kk);
     const int ci = (int)((i / kk) % Ci);
     const int co = (int)(i / ((int64_t)kk * Ci));
-    dw[i] = G[((int64_t)tap * Ci + ci) * Co + co];
+    const float v = G[((int64_t)tap * Ci + ci) * Co + co];
+    dw[i] = accumulate ? dw[i] + v : v;
   }
 }
 
@@ -175,12 +219,15 @@ int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int C
   dim3 g((unsigned)cdiv64(P, 32), (unsigned)cdiv(Ci, 32), (unsigned)(k * k));
   PROF_SCOPE("wgrad_im2col_t", 0, 2.0 * k * k * (double)P * Ci * dt_size(dt), s);
   if (dt == DT_F32) hipLaunchKernelGGL(im2col_t_kernel<float>, g, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
+  else if (Ci % 8 == 0 && P % 8 == 0)
+    hipLaunchKernelGGL(im2col_t_bf16_kernel, dim3((unsigned)cdiv64(P, 64), (unsigned)cdiv(Ci, 64), (unsigned)(k * k)), dim3(256), 0, s,
+                       (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
   else hipLaunchKernelGGL(im2col_t_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
-int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, hipStream_t s) {
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(tr_blocks((int64_t)Co * Ci * kk)), dim3(256), 0, s, G, dw, Co, Ci, kk);
+int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(tr_blocks((int64_t)Co * Ci * kk)), dim3(256), 0, s, G, dw, Co, Ci, kk, accumulate);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -219,87 +266,179 @@ __device__ __forceinline__ float tr_dsilu(float z) {
   return sg * (1.0f + z * (1.0f - sg));
 }
 
+// 16-byte vector access to NHWC rows (8 bf16 / 4 fp32 channels)
+template <typename T> struct TrVec;
+template <> struct TrVec<float> {
+  static constexpr int N = 4;
+  __device__ static void load(const float* p, float* v) { const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+  __device__ static void store(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct TrVec<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static void load(const bf16_t* p, float* v) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  __device__ static void store(bf16_t* p, const float* v) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+
+// pass 1, grid (nsplit, B), block = NV x R threads (NV = C / vector channel-vectors of a pixel, R pixel lanes): whole NHWC rows
+// are read with 16-byte loads (the first version gave a block ONE group's 7..84 channels of every pixel: 14-byte pieces of
+// 448-byte rows).  Per-thread sums of its channels over its pixels -> LDS -> per-channel partials of this pixel slice:
+// part[b][split][c] = (dgamma, dbeta, sum dx^, sum dx^ x^).  Fixed order everywhere: deterministic.
 template <typename T>
-__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mr,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ ab, float* __restrict__ dgp, float* __restrict__ dbp,
-                                                           int HW, int C, int silu) {
-  extern __shared__ float red[];   // [4][256]: dgamma, dbeta, A, Bs partials per thread
-  const int g = blockIdx.x, b = blockIdx.y, cpg = C / TR_GROUPS;
-  const int L = 256 / cpg;                      // pixel lanes
-  const int cc = threadIdx.x % cpg, lane = threadIdx.x / cpg;
-  const int c = g * cpg + cc;
-  const float mean = mr[((int64_t)b * TR_GROUPS + g) * 2], rstd = mr[((int64_t)b * TR_GROUPS + g) * 2 + 1];
-  float sdg = 0.f, sdb = 0.f, sA = 0.f, sB = 0.f;
-  if (lane < L) {
-    const float ga = gamma[c], be = beta[c];
-    for (int p = lane; p < HW; p += L) {
-      const int64_t o = ((int64_t)b * HW + p) * C + c;
-      const float xh = (tr_ld(x + o) - mean) * rstd;
-      float dz = tr_ld(dy + o);
-      if (silu) dz *= tr_dsilu(ga * xh + be);
-      sdg += dz * xh;
-      sdb += dz;
-      const float dxh = dz * ga;
-      sA += dxh;
-      sB += dxh * xh;
+__global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mr,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part,
+                                      int HW, int C, int NV, int R, int silu) {
+  constexpr int VN = TrVec<T>::N;
+  extern __shared__ float red[];   // [4][R][C]
+  __shared__ float smr[TR_GROUPS * 2];
+  const int b = blockIdx.y, tid = threadIdx.x, cpg = C / TR_GROUPS;
+  if (tid < TR_GROUPS * 2) smr[tid] = mr[(int64_t)b * TR_GROUPS * 2 + tid];
+  __syncthreads();
+  const int v = tid % NV, r = tid / NV;
+  const int per = cdiv(HW, gridDim.x), p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+  if (r < R) {
+    float mean[VN], rstd[VN], ga[VN], be[VN], s0[VN], s1[VN], s2[VN], s3[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int c = v * VN + i, g = c / cpg;
+      mean[i] = smr[2 * g]; rstd[i] = smr[2 * g + 1];
+      ga[i] = gamma[c]; be[i] = beta[c];
+      s0[i] = s1[i] = s2[i] = s3[i] = 0.f;
+    }
+    for (int p = p0 + r; p < p1; p += R) {
+      const int64_t o = ((int64_t)b * HW + p) * C + v * VN;
+      float xv[VN], gv[VN];
+      TrVec<T>::load(x + o, xv);
+      TrVec<T>::load(dy + o, gv);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) {
+        const float xh = (xv[i] - mean[i]) * rstd[i];
+        float dz = gv[i];
+        if (silu) dz *= tr_dsilu(ga[i] * xh + be[i]);
+        const float dxh = dz * ga[i];
+        s0[i] += dz * xh; s1[i] += dz; s2[i] += dxh; s3[i] += dxh * xh;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int c = v * VN + i;
+      red[(0 * R + r) * C + c] = s0[i]; red[(1 * R + r) * C + c] = s1[i];
+      red[(2 * R + r) * C + c] = s2[i]; red[(3 * R + r) * C + c] = s3[i];
     }
   }
-  red[threadIdx.x] = sdg; red[256 + threadIdx.x] = sdb; red[512 + threadIdx.x] = sA; red[768 + threadIdx.x] = sB;
   __syncthreads();
-  if (threadIdx.x < cpg) {   // per-channel sums over the pixel lanes
-    float a = 0.f, d = 0.f;
-    for (int l = 0; l < L; ++l) { a += red[l * cpg + threadIdx.x]; d += red[256 + l * cpg + threadIdx.x]; }
-    dgp[(int64_t)b * C + g * cpg + threadIdx.x] = a;
-    dbp[(int64_t)b * C + g * cpg + threadIdx.x] = d;
+  for (int c = tid; c < C; c += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+      a0 += red[(0 * R + rr) * C + c]; a1 += red[(1 * R + rr) * C + c];
+      a2 += red[(2 * R + rr) * C + c]; a3 += red[(3 * R + rr) * C + c];
+    }
+    *reinterpret_cast<float4*>(part + (((int64_t)b * gridDim.x + blockIdx.x) * C + c) * 4) = make_float4(a0, a1, a2, a3);
   }
-  if (threadIdx.x == 0) {
+}
+
+// pass 2, grid (B): slices summed in order -> dgp / dbp [B][C] and the group means ab [B][32][2]
+__global__ void gn_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ ab, float* __restrict__ dgp,
+                                     float* __restrict__ dbp, int nsplit, int HW, int C) {
+  extern __shared__ float ch[];   // [2][C]: per-channel sum dx^, sum dx^ x^
+  const int b = blockIdx.x, cpg = C / TR_GROUPS;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+      const float4 q = *reinterpret_cast<const float4*>(part + (((int64_t)b * nsplit + sidx) * C + c) * 4);
+      a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
+    }
+    dgp[(int64_t)b * C + c] = a0;
+    dbp[(int64_t)b * C + c] = a1;
+    ch[c] = a2;
+    ch[C + c] = a3;
+  }
+  __syncthreads();
+  if (threadIdx.x < TR_GROUPS) {
+    const int g = threadIdx.x;
     double a = 0.0, d = 0.0;
-    for (int t = 0; t < L * cpg; ++t) { a += red[512 + t]; d += red[768 + t]; }
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += ch[c]; d += ch[C + c]; }
     const double n = (double)HW * cpg;
     ab[((int64_t)b * TR_GROUPS + g) * 2] = (float)(a / n);
     ab[((int64_t)b * TR_GROUPS + g) * 2 + 1] = (float)(d / n);
   }
 }
 
+// pass 3, same grid / block shape as pass 1: dx = rstd (dz gamma - mean_g(dx^) - x^ mean_g(dx^ x^)), 16-byte accesses
 template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mr,
                                     const float* __restrict__ ab, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    T* __restrict__ dx, int64_t n, int HW, int C, int silu) {
-  const int cpg = C / TR_GROUPS;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)HW * C));
-    const int g = c / cpg;
-    const float mean = mr[((int64_t)b * TR_GROUPS + g) * 2], rstd = mr[((int64_t)b * TR_GROUPS + g) * 2 + 1];
-    const float mA = ab[((int64_t)b * TR_GROUPS + g) * 2], mB = ab[((int64_t)b * TR_GROUPS + g) * 2 + 1];
-    const float ga = gamma[c];
-    const float xh = (tr_ld(x + i) - mean) * rstd;
-    float dz = tr_ld(dy + i);
-    if (silu) dz *= tr_dsilu(ga * xh + beta[c]);
-    tr_st(dx + i, rstd * (dz * ga - mA - xh * mB));
+                                    T* __restrict__ dx, int HW, int C, int NV, int R, int silu) {
+  constexpr int VN = TrVec<T>::N;
+  __shared__ float smr[TR_GROUPS * 2], sab[TR_GROUPS * 2];
+  const int b = blockIdx.y, tid = threadIdx.x, cpg = C / TR_GROUPS;
+  if (tid < TR_GROUPS * 2) {
+    smr[tid] = mr[(int64_t)b * TR_GROUPS * 2 + tid];
+    sab[tid] = ab[(int64_t)b * TR_GROUPS * 2 + tid];
+  }
+  __syncthreads();
+  const int v = tid % NV, r = tid / NV;
+  if (r >= R) return;
+  float mean[VN], rstd[VN], ga[VN], be[VN], mA[VN], mB[VN];
+#pragma unroll
+  for (int i = 0; i < VN; ++i) {
+    const int c = v * VN + i, g = c / cpg;
+    mean[i] = smr[2 * g]; rstd[i] = smr[2 * g + 1]; mA[i] = sab[2 * g]; mB[i] = sab[2 * g + 1];
+    ga[i] = gamma[c]; be[i] = beta[c];
+  }
+  const int per = cdiv(HW, gridDim.x), p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+  for (int p = p0 + r; p < p1; p += R) {
+    const int64_t o = ((int64_t)b * HW + p) * C + v * VN;
+    float xv[VN], gv[VN], ov[VN];
+    TrVec<T>::load(x + o, xv);
+    TrVec<T>::load(dy + o, gv);
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const float xh = (xv[i] - mean[i]) * rstd[i];
+      float dz = gv[i];
+      if (silu) dz *= tr_dsilu(ga[i] * xh + be[i]);
+      ov[i] = rstd[i] * (dz * ga[i] - mA[i] - xh * mB[i]);
+    }
+    TrVec<T>::store(dx + o, ov);
   }
 }
 
+// scratch: ab [B*64] | dgp [B*C] | dbp [B*C] | part [B * nsplit * C * 4] floats
+size_t gn_backward_scratch_floats(int B, int HW, int C) { return (size_t)B * 64 + (size_t)2 * B * C + (size_t)B * gn_nsplit(B, HW) * C * 4; }
+
 int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
-                       float* dgamma, float* dbeta, float* scratch /* [B*32*2 + 2*B*C] */, int dt, int B, int HW, int C, int silu,
-                       hipStream_t s) {
-  DDMI_REQUIRE(C % TR_GROUPS == 0 && C / TR_GROUPS <= 256, "gn_backward: C must be a multiple of 32 with at most 256 channels per group");
+                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s) {
+  const int vn = dt == DT_F32 ? 4 : 8;
+  DDMI_REQUIRE(C % TR_GROUPS == 0 && C % vn == 0, "gn_backward: C must be a multiple of 32 and of the 16-byte vector");
+  const int NV = C / vn;
+  DDMI_REQUIRE(NV <= 1024, "gn_backward: too many channels");
+  const int R = std::max(1, 256 / NV);
+  const int threads = std::max(64, cdiv(NV * R, 64) * 64);
+  const int ns = gn_nsplit(B, HW);
   float* ab = scratch;
-  float* dgp = ab + (size_t)B * TR_GROUPS * 2;
+  float* dgp = ab + (size_t)B * 64;
   float* dbp = dgp + (size_t)B * C;
-  dim3 g(TR_GROUPS, B);
-  const size_t lds = 4 * 256 * sizeof(float);
-  const int64_t n = (int64_t)B * HW * C;
-  PROF_SCOPE("gn_bwd", 0, 5.0 * n * dt_size(dt), s);
+  float* part = dbp + (size_t)B * C;
+  dim3 g(ns, B);
+  const size_t lds = (size_t)4 * R * C * sizeof(float);
+  DDMI_REQUIRE(lds <= 64 * 1024, "gn_backward: channel count exceeds the reduction tile");
+  PROF_SCOPE("gn_bwd", 0, 5.0 * (double)B * HW * C * dt_size(dt), s);
   if (dt == DT_F32) {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, g, dim3(256), lds, s, (const float*)x, (const float*)dy, meanrstd, gamma, beta, ab, dgp, dbp, HW, C, silu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, (const float*)x, (const float*)dy, meanrstd, ab, gamma, beta,
-                       (float*)dx, n, HW, C, silu);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<float>, g, dim3(threads), lds, s, (const float*)x, (const float*)dy, meanrstd, gamma, beta, part, HW, C, NV, R, silu);
+    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B), dim3(256), (size_t)2 * C * sizeof(float), s, part, ab, dgp, dbp, ns, HW, C);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (const float*)dy, meanrstd, ab, gamma, beta, (float*)dx, HW, C, NV, R, silu);
   } else {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, g, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, gamma, beta, ab, dgp, dbp, HW, C, silu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, ab, gamma, beta,
-                       (bf16_t*)dx, n, HW, C, silu);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, gamma, beta, part, HW, C, NV, R, silu);
+    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B), dim3(256), (size_t)2 * C * sizeof(float), s, part, ab, dgp, dbp, ns, HW, C);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, ab, gamma, beta, (bf16_t*)dx, HW, C, NV, R, silu);
   }
   HIP_TRY(hipGetLastError());
   DDMI_TRY(launch_sum_b(dgp, dgamma, B, C, s));
@@ -436,6 +575,199 @@ __global__ void __launch_bounds__(128) attn_bwd_dkv_kernel(const T* __restrict__
   }
 }
 
+// ---- bf16 / MFMA form (T a multiple of 64, d = 32 = ONE k-step of v_mfma_f32_16x16x32_bf16) -------------------------------
+// The query (dq kernel) or the key (dkv kernel) sits on the MFMA lane: S^T = K Q^T (A = key rows from LDS, B = the wave's 16
+// query rows in registers) leaves a lane with 16 scores of ITS query per 64-key tile, so the softmax statistics and
+// dS = P (dP - D) are per-lane elementwise work.  The accumulation GEMMs (dQ^T += K^T dS^T etc.) take dS / P straight from
+// those accumulator registers as the B operand: the k-axis of that product (keys) is consumed in the order the accumulator
+// layout hands it out - position 8 lg + e + 4 (f & 1) of chunk f >> 1 is key 16 f + 4 lg + e - and the A operand (K^T, the
+// transposed tile) is staged in LDS with its columns in exactly that order.  P and dS enter the products rounded to bf16.
+#define AB_TILE 64
+#define AB_ROWP 40   // row pitch of the [64][32] row tiles in elements (80 B): conflict-free b128 fragment reads
+#define AB_TP 72     // row pitch of the transposed [32][64] tiles in elements (144 B)
+
+__device__ __forceinline__ int ab_pos(int key) {   // column of a tile row in the transposed images (see above)
+  const int f = key >> 4, lg = (key >> 2) & 3, e = key & 3;
+  return (f >> 1) * 32 + 8 * lg + e + 4 * (f & 1);
+}
+// stage one [64][32] row tile (rows of `src` with leading dimension ld) into R (row-major, pitch AB_ROWP) and, when TR is
+// non-null, its transpose into TR[d][ab_pos(row)] (pitch AB_TP).  256 threads: thread -> (row = tid >> 2, 8 channels).
+__device__ __forceinline__ void ab_stage(const bf16_t* __restrict__ src, int ld, bf16_t* R, bf16_t* TR) {
+  const int row = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + c8);
+  *reinterpret_cast<bf16x8*>(R + row * AB_ROWP + c8) = v;
+  if (TR != nullptr) {
+    const int pos = ab_pos(row);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) TR[(c8 + e) * AB_TP + pos] = v[e];
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                              float* __restrict__ lse, float* __restrict__ dsum, int Tn, int heads) {
+  constexpr int D = 32;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[AB_TILE * AB_ROWP], Vs[AB_TILE * AB_ROWP], KT[D * AB_TP];
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AB_TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int ld = heads * 3 * D, ldo = heads * D;
+  const bf16_t* base = qkv + (int64_t)b * Tn * ld + h * 3 * D;
+  const int q = q0 + 16 * wave + lr;                      // this lane's query
+  const float scale = 0.17677669529663687f;               // 1 / sqrt(32)
+  const float sl2 = scale * 1.4426950408889634f;          // logits in the exp2 domain
+  const bf16x8 qf = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * ld + 8 * lg);
+  const bf16x8 gof = *reinterpret_cast<const bf16x8*>(dout + ((int64_t)b * Tn + q) * ldo + h * D + 8 * lg);
+  float dsm;
+  {
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + ((int64_t)b * Tn + q) * ldo + h * D + 8 * lg);
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part += (float)gof[e] * (float)of[e];
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    dsm = part;                                            // D_q = dO_q . O_q
+  }
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- pass 1: row log-sum-exp (exp2 domain) ----------------------------------------------------------------------------
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < Tn; k0 += AB_TILE) {
+    __syncthreads();
+    ab_stage(base + (int64_t)k0 * ld + D, ld, Ks, nullptr);
+    __syncthreads();
+    float sc[16];
+    float tm = m;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (16 * f + lr) * AB_ROWP + 8 * lg);
+      const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, zero4, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[4 * f + e] = s4[e] * sl2;
+        tm = fmaxf(tm, sc[4 * f + e]);
+      }
+    }
+    float add = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) add += exp2f(sc[j] - tm);
+    l = l * exp2f(m - tm) + add;
+    m = tm;
+  }
+  {  // combine the four lanes (lg) that share a query
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+      const float mo = __shfl_xor(m, sh), lo = __shfl_xor(l, sh);
+      const float mn = fmaxf(m, mo);
+      l = l * exp2f(m - mn) + lo * exp2f(mo - mn);
+      m = mn;
+    }
+  }
+  const float L2 = m + log2f(l);                           // log2-domain log-sum-exp
+  // ---- pass 2: dQ --------------------------------------------------------------------------------------------------------
+  f32x4 dq[2] = {zero4, zero4};
+  for (int k0 = 0; k0 < Tn; k0 += AB_TILE) {
+    __syncthreads();
+    ab_stage(base + (int64_t)k0 * ld + D, ld, Ks, KT);
+    ab_stage(base + (int64_t)k0 * ld + 2 * D, ld, Vs, nullptr);
+    __syncthreads();
+    bf16x8 dsb[2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (16 * f + lr) * AB_ROWP + 8 * lg);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (16 * f + lr) * AB_ROWP + 8 * lg);
+      const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, zero4, 0, 0, 0);
+      const f32x4 p4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gof, zero4, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = exp2f(s4[e] * sl2 - L2);
+        dsb[f >> 1][4 * (f & 1) + e] = (bf16_t)(p * (p4[e] - dsm) * scale);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bf16x8 kt = *reinterpret_cast<const bf16x8*>(KT + (16 * r + lr) * AB_TP + 32 * c + 8 * lg);
+        dq[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsb[c], dq[r], 0, 0, 0);
+      }
+  }
+  if (lg == 0) {
+    lse[((int64_t)b * heads + h) * Tn + q] = L2 * 0.6931471805599453f;   // natural-log form (what the fp32 kernels store)
+    dsum[((int64_t)b * heads + h) * Tn + q] = dsm;
+  }
+  bf16_t* dst = dqkv + ((int64_t)b * Tn + q) * ld + h * 3 * D;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16_t)dq[r][e];
+    *reinterpret_cast<bf16x4*>(dst + 16 * r + 4 * lg) = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               bf16_t* __restrict__ dqkv, const float* __restrict__ lse,
+                                                               const float* __restrict__ dsum, int Tn, int heads) {
+  constexpr int D = 32;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[AB_TILE * AB_ROWP], Gs[AB_TILE * AB_ROWP], QT[D * AB_TP], GT[D * AB_TP];
+  __shared__ __attribute__((aligned(16))) float Ls[AB_TILE], Ds[AB_TILE];
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * AB_TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int ld = heads * 3 * D, ldo = heads * D;
+  const bf16_t* base = qkv + (int64_t)b * Tn * ld + h * 3 * D;
+  const int key = k0 + 16 * wave + lr;                    // this lane's key
+  const float scale = 0.17677669529663687f, sl2 = scale * 1.4426950408889634f;
+  const bf16x8 kf = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + D + 8 * lg);
+  const bf16x8 vf = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + 2 * D + 8 * lg);
+  const float* Lr = lse + ((int64_t)b * heads + h) * Tn;
+  const float* Dr = dsum + ((int64_t)b * heads + h) * Tn;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+  for (int q0 = 0; q0 < Tn; q0 += AB_TILE) {
+    __syncthreads();
+    ab_stage(base + (int64_t)q0 * ld, ld, Qs, QT);
+    ab_stage(dout + ((int64_t)b * Tn + q0) * ldo + h * D, ldo, Gs, GT);
+    if (threadIdx.x < AB_TILE) {
+      Ls[threadIdx.x] = Lr[q0 + threadIdx.x] * 1.4426950408889634f;   // back to the exp2 domain
+      Ds[threadIdx.x] = Dr[q0 + threadIdx.x];
+    }
+    __syncthreads();
+    bf16x8 pb[2], dsb[2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (16 * f + lr) * AB_ROWP + 8 * lg);
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + (16 * f + lr) * AB_ROWP + 8 * lg);
+      const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, zero4, 0, 0, 0);   // rows = queries 16f + 4lg + e, column = key
+      const f32x4 p4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, zero4, 0, 0, 0);
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + 16 * f + 4 * lg);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + 16 * f + 4 * lg);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = exp2f(s4[e] * sl2 - L4[e]);
+        pb[f >> 1][4 * (f & 1) + e] = (bf16_t)p;
+        dsb[f >> 1][4 * (f & 1) + e] = (bf16_t)(p * (p4[e] - D4[e]) * scale);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bf16x8 gt = *reinterpret_cast<const bf16x8*>(GT + (16 * r + lr) * AB_TP + 32 * c + 8 * lg);
+        const bf16x8 qt = *reinterpret_cast<const bf16x8*>(QT + (16 * r + lr) * AB_TP + 32 * c + 8 * lg);
+        dv[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pb[c], dv[r], 0, 0, 0);
+        dk[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsb[c], dk[r], 0, 0, 0);
+      }
+  }
+  bf16_t* dst = dqkv + ((int64_t)b * Tn + key) * ld + h * 3 * D;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    bf16x4 a, c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)dk[r][e]; c[e] = (bf16_t)dv[r][e]; }
+    *reinterpret_cast<bf16x4*>(dst + D + 16 * r + 4 * lg) = a;
+    *reinterpret_cast<bf16x4*>(dst + 2 * D + 16 * r + 4 * lg) = c;
+  }
+}
+
 int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch /* 2*B*heads*T */,
                                      int dt, int B, int T, int heads, int d, hipStream_t s) {
   DDMI_REQUIRE(d == 32, "attention backward: head dim 32 (num_head_channels of every DDMI config)");
@@ -443,7 +775,12 @@ int launch_attention_legacy_backward(const void* qkv, const void* out, const voi
   float* dsum = scratch + (size_t)B * heads * T;
   dim3 g((unsigned)cdiv(T, 128), (unsigned)heads, (unsigned)B);
   PROF_SCOPE("attention_legacy_bwd", 2.0 * 5.0 * B * heads * (double)T * T * d, 0, s);
-  if (dt == DT_F32) {
+  static const bool no_mfma = getenv("DDMI_ATTN_BWD_VALU") != nullptr;   // diagnostics: the plain kernels in bf16 too
+  if (dt == DT_BF16 && T % AB_TILE == 0 && !no_mfma) {
+    dim3 gm((unsigned)(T / AB_TILE), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, gm, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, T, heads);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gm, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, T, heads);
+  } else if (dt == DT_F32) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<float, 32>), g, dim3(128), 0, s, (const float*)qkv, (const float*)out, (const float*)dout, (float*)dqkv, lse, dsum, T, heads);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 32>), g, dim3(128), 0, s, (const float*)qkv, (const float*)dout, (float*)dqkv, lse, dsum, T, heads);
   } else {

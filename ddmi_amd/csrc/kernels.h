@@ -180,12 +180,13 @@ int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo,
 int launch_sumpool2x(const void* up, void* dx, int dt, int B, int H, int W, int C, hipStream_t s);
 int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int Ci, int Ho, int Wo, int k, int stride, int pad, int ups,
                     hipStream_t s);   // out [(tap * Ci + ci)][B * Ho * Wo]
-int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, hipStream_t s);
+int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, int accumulate, hipStream_t s);
 int sum_hw_slices(int B, int HW, int C);
 int launch_sum_hw(const void* dy, float* out, float* part, int dt, int B, int HW, int C, hipStream_t s);   // out [B][C]; part: slices*B*C floats
 int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s);
 int launch_gn_meanrstd(const double* part, float* mr, int B, int HW, int C, float eps, int nsplit, hipStream_t s);
 int gn_nsplit(int B, int HW);   // the split count launch_gn_stats uses (k_groupnorm.hip)
+size_t gn_backward_scratch_floats(int B, int HW, int C);
 int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
                        float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s);
 int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch, int dt, int B,

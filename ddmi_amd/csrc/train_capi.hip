@@ -2,6 +2,7 @@
 // handle's storage dtype + fp32 master parameters, composed from the forward kernels and k_train.hip.  The handle only owns
 // a scratch arena (grown on demand: the first call of a larger shape synchronises the stream once).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "kernels.h"
 #include "prof.h"
@@ -65,6 +66,16 @@ int ddmi_train_to_nchw(ddmi_train* h, const void* x_nhwc, float* y_nchw, int B, 
   return launch_nhwc_to_nchw(x_nhwc, h->dt, y_nchw, B, C, HW, (hipStream_t)stream);
 }
 
+// 3x3 / stride-1 convolutions on W in {8..64} have a faster kernel than the heuristic's pick (the halo kernel, k_conv.hip:
+// 1.2 vs 0.85 PFLOP/s); the inference networks reach it through the autotuner, the stateless training ops ask for it here.
+// launch_conv falls back by itself when the shape is not halo-eligible.
+static void prefer_halo(ConvArgs* c, int dt) {
+  if (dt != DT_BF16 || c->KH != 3 || c->stride != 1 || c->ups != 0) return;
+  const int p224 = cdiv(c->Cout, 224) * 224, p128 = cdiv(c->Cout, 128) * 128;
+  if (p224 * 100 <= c->Cout * 115) c->cfg = 20;        // halo<224,4,2>
+  else if (p128 * 100 <= c->Cout * 115) c->cfg = 21;   // halo<128,4,2>
+}
+
 static void conv_geometry(int H, int W, int k, int stride, int ups, int* Ho, int* Wo) {
   const int hin = ups ? 2 * H : H, win = ups ? 2 * W : W, pad = k / 2;
   *Ho = (hin + 2 * pad - k) / stride + 1;
@@ -82,6 +93,7 @@ int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const floa
   a.x = x; a.bias = bias; a.emb = emb; a.emb_stride = emb_stride; a.res = res; a.y = y;
   a.B = B; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout;
   a.KH = a.KW = k; a.stride = stride; a.pad = k / 2; a.ups = ups ? 1 : 0; a.out_scale = 1.f;
+  prefer_halo(&a, dt);
   a.splitk = conv_pick_splitk(a, dt);
   const size_t wbytes = al((size_t)Cout * Cin * k * k * dt_size(dt));
   const size_t sk = a.splitk > 1 ? al((size_t)a.splitk * B * Ho * Wo * Cout * sizeof(float)) : 0;
@@ -105,23 +117,31 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
   conv_geometry(H, W, k, stride, ups, &Ho, &Wo);
   const int64_t P = (int64_t)B * Ho * Wo;
   const int kk = k * k, N = kk * Cin;
-  DDMI_REQUIRE(P % (dt == DT_F32 ? 4 : 8) == 0, "train_conv_bwd: B*Ho*Wo must be a multiple of the 16-byte vector");
-  DDMI_REQUIRE((double)N * P * es < 3.9e9, "train_conv_bwd: im2col image exceeds 4 GB - lower the batch");
+  // wgrad works on chunks of whole samples: the transposed im2col image [N][Pc] (the GEMM's weight-side operand) has to
+  // stay inside one 2 GiB buffer descriptor; chunk results are accumulated in fp32 by the finish pass
+  static const double chunk_bytes = getenv("DDMI_WGRAD_CHUNK_BYTES") ? atof(getenv("DDMI_WGRAD_CHUNK_BYTES")) : 1.5e9;  // tests
+  int bc = B;
+  while (bc > 1 && (double)std::max(N, Cout) * ((double)bc * Ho * Wo) * es > chunk_bytes) bc = (bc + 1) / 2;
+  const int64_t Pc = (int64_t)bc * Ho * Wo;
+  DDMI_REQUIRE(Pc % (dt == DT_F32 ? 4 : 8) == 0 && P % (dt == DT_F32 ? 4 : 8) == 0,
+               "train_conv_bwd: (samples per chunk)*Ho*Wo must be a multiple of the 16-byte vector");
+  DDMI_REQUIRE((double)std::max(N, Cout) * Pc * es < 2.1e9, "train_conv_bwd: one sample's im2col image exceeds 2 GiB");
   // ---- scratch plan (the two phases reuse the arena) --------------------------------------------------------
   const int Hg = ups ? 2 * H : (stride == 2 ? 2 * Ho : H), Wg = ups ? 2 * W : (stride == 2 ? 2 * Wo : W);   // dgrad conv grid
   ConvArgs d{};   // dgrad: a stride-1 convolution of dY' with the transposed, flipped filter
   d.B = B; d.Hin = Hg; d.Win = Wg; d.Cin = Cout; d.Hout = Hg; d.Wout = Wg; d.Cout = Cin;
   d.KH = d.KW = k; d.stride = 1; d.pad = k / 2; d.ups = 0; d.out_scale = 1.f;
+  prefer_halo(&d, dt);
   d.splitk = dx ? conv_pick_splitk(d, dt) : 1;
-  ConvArgs g{};   // wgrad: G[n][co] = sum_p Bm[n][p] A[co][p] as a 1x1 "convolution" over rows of A
-  g.B = 1; g.Hin = 1; g.Win = Cout; g.Cin = (int)P; g.Hout = 1; g.Wout = Cout; g.Cout = N;
+  ConvArgs g{};   // wgrad: G[n][co] = sum_p Bm[n][p] A[co][p] as a 1x1 "convolution" over rows of A (one chunk of samples)
+  g.B = 1; g.Hin = 1; g.Win = Cout; g.Cin = (int)Pc; g.Hout = 1; g.Wout = Cout; g.Cout = N;
   g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.ups = 0; g.out_scale = 1.f;
   g.splitk = conv_pick_splitk(g, dt);
   const size_t dgrad_bytes = dx ? al((size_t)Cout * Cin * kk * es) + (stride == 2 ? al((size_t)B * Hg * Wg * Cout * es) : 0) +
                                       (ups ? al((size_t)B * Hg * Wg * Cin * es) : 0) +
                                       (d.splitk > 1 ? al((size_t)d.splitk * B * Hg * Wg * Cin * sizeof(float)) : 0)
                                 : 0;
-  const size_t wgrad_bytes = al((size_t)Cout * P * es) + al((size_t)N * P * es) + al((size_t)N * Cout * sizeof(float)) +
+  const size_t wgrad_bytes = al((size_t)Cout * Pc * es) + al((size_t)N * Pc * es) + al((size_t)N * Cout * sizeof(float)) +
                              (g.splitk > 1 ? al((size_t)g.splitk * Cout * N * sizeof(float)) : 0);
   const size_t red_bytes = al((size_t)B * Cout * sizeof(float)) * (1 + (size_t)sum_hw_slices(B, Ho * Wo, Cout));
   DDMI_TRY(reserve(h, std::max(dgrad_bytes, wgrad_bytes) + red_bytes, s));
@@ -156,18 +176,27 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
   {
     Carve c{h};
     c.take(red_bytes);
-    void* A = c.take((size_t)Cout * P * es);
-    void* Bm = c.take((size_t)N * P * es);
+    void* A = c.take((size_t)Cout * Pc * es);
+    void* Bm = c.take((size_t)N * Pc * es);
     float* G = (float*)c.take((size_t)N * Cout * sizeof(float));
-    {
-      PROF_SCOPE("wgrad_transpose", 0, 2.0 * (double)P * Cout * es, s);
-      DDMI_TRY(launch_transpose_2d(dy, A, dt, 1, (int)P, Cout, s));                     // A[co][p] = dY[p][co]
-    }
-    DDMI_TRY(launch_im2col_t(x, Bm, dt, B, H, W, Cin, Ho, Wo, k, stride, k / 2, ups ? 1 : 0, s));
-    g.x = A; g.w = Bm; g.y_nchw = G;
     if (g.splitk > 1) g.splitk_ws = (float*)c.take((size_t)g.splitk * Cout * N * sizeof(float));
-    DDMI_TRY(launch_conv(g, dt, s));
-    DDMI_TRY(launch_wgrad_finish(G, dw, Cout, Cin, kk, s));
+    for (int b0 = 0; b0 < B; b0 += bc) {
+      const int nb = std::min(bc, B - b0);
+      const int64_t Pn = (int64_t)nb * Ho * Wo;
+      const unsigned char* dyc = (const unsigned char*)dy + (size_t)b0 * Ho * Wo * Cout * es;
+      const unsigned char* xc = (const unsigned char*)x + (size_t)b0 * H * W * Cin * es;
+      {
+        PROF_SCOPE("wgrad_transpose", 0, 2.0 * (double)Pn * Cout * es, s);
+        DDMI_TRY(launch_transpose_2d(dyc, A, dt, 1, (int)Pn, Cout, s));                   // A[co][p] = dY[p][co]
+      }
+      DDMI_TRY(launch_im2col_t(xc, Bm, dt, nb, H, W, Cin, Ho, Wo, k, stride, k / 2, ups ? 1 : 0, s));
+      ConvArgs gc = g;
+      gc.Cin = (int)Pn;
+      gc.x = A; gc.w = Bm; gc.y_nchw = G;
+      if (nb != bc) { gc.splitk = conv_pick_splitk(gc, dt); if (gc.splitk > g.splitk) gc.splitk = g.splitk; if (gc.splitk <= 1) gc.splitk_ws = nullptr; }
+      DDMI_TRY(launch_conv(gc, dt, s));
+      DDMI_TRY(launch_wgrad_finish(G, dw, Cout, Cin, kk, b0 > 0, s));
+    }
   }
   return DDMI_OK;
 }
@@ -186,7 +215,7 @@ int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const fl
                       void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream) {
   DDMI_REQUIRE(h && x && gamma && beta && meanrstd && dy && dx && dgamma && dbeta, "train_gn_bwd: null argument");
   hipStream_t s = (hipStream_t)stream;
-  DDMI_TRY(reserve(h, ((size_t)B * 64 + (size_t)2 * B * C) * sizeof(float), s));
+  DDMI_TRY(reserve(h, gn_backward_scratch_floats(B, HW, C) * sizeof(float), s));
   return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s);
 }
 

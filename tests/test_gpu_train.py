@@ -16,6 +16,7 @@ from oracle import ddmi_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 
 
 def nhwc(x, tc):   # [B,C,H,W] fp32 cpu -> NHWC storage tensor on the device (leaf)
@@ -269,3 +270,38 @@ def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path)
         want_ema = tr.model(xt, t).clone()
         tr.flat.data.copy_(keep)
     assert rel_err(pipe2.unet(xt, t), want_ema) < 1e-5
+
+
+def test_conv_wgrad_in_sample_chunks():
+    """The wgrad GEMM runs over chunks of whole samples when its transposed im2col image would leave the 2 GiB descriptor range
+    (B = 64 at 64x64 on the AFHQ UNet does); forced here with a tiny threshold in a child process: 5 samples -> chunks 2 + 2 + 1."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np, torch, torch.nn.functional as F
+from ddmi_amd import train as T
+from ddmi_amd import initweights as iw
+from helpers import rel_err
+g = lambda k, s, std=1.0: torch.from_numpy(iw.normal('tcw', k, s, 0.0, std))
+for numerics, tol in (('fp32', 2e-5), ('bf16', 4e-2)):
+    tc = T.TrainContext(numerics, 'cuda:0')
+    B, cin, cout, hw = 5, 32, 64, 8
+    x, w, b = g('x', (B, cin, hw, hw)), g('w', (cout, cin, 3, 3), 1 / np.sqrt(cin * 9)), g('b', (cout,), 0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, padding=1)
+    dy = g('dy', tuple(yr.shape))
+    yr.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to('cuda:0', tc.dtype).requires_grad_(True)
+    wd, bd = w.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+    y = T.ConvFn.apply(tc, xd, wd, bd, None, None, 1, False)
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to('cuda:0', tc.dtype))
+    assert rel_err(wd.grad, wr.grad) < tol, (numerics, rel_err(wd.grad, wr.grad))
+    assert rel_err(xd.grad.float().permute(0, 3, 1, 2).cpu(), xr.grad) < tol
+print('chunked wgrad ok')
+""" % (ROOT, ROOT)
+    env = dict(os.environ, DDMI_WGRAD_CHUNK_BYTES="50000")   # 2 samples x 64 pixels x 288 rows x 4 B = 147 KB > 50 KB -> chunks
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "chunked wgrad ok" in out.stdout, out.stdout + out.stderr

@@ -25,6 +25,7 @@ for st in "$@"; do
     benchfast) timeout 900 python bench.py --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchfast.json 2> $log ;;
     benchshape) timeout 900 python bench.py --workload shapenet --steps 1 --warmup 1 > gpurun_out/${tag}_bench_shapenet.json 2> $log ;;
     benchtrain) timeout 1200 python bench.py --workload train --steps 2 --warmup 1 > gpurun_out/${tag}_bench_train.json 2> $log ;;
+    benchtrain64) timeout 1200 python bench.py --workload train --batch 64 --steps 3 --warmup 1 > gpurun_out/${tag}_bench_train64.json 2> $log ;;
     benchsky)  timeout 1200 python bench.py --workload sky --steps 1 --warmup 0 > gpurun_out/${tag}_bench_sky.json 2> $log ;;
     *) echo "unknown stage $st" ;;
   esac
