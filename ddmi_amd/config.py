@@ -35,6 +35,7 @@ def load_ldm_args(path: str, args: argparse.Namespace = None) -> argparse.Namesp
     args.loss_config = p.get("lossconfig")
     args.embed_dim = cfg.model.embed_dim
     args.resolution = p.ddconfig.resolution
+    args.lr = cfg.model.get("lr", 1e-4)
     args.pretrained = cfg.model.get("pretrained", True)
     args.resume = cfg.model.get("resume", False)
     args.use_fp16 = cfg.model.get("use_fp16", True)

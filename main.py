@@ -2,7 +2,8 @@
 """Entry point with the reference's surface: `python main.py --exp ldm --configs configs/ldm/afhq.yaml [--seed 777]`
 (reference main.py:54-65), also under `accelerate launch` / `torch.distributed.run` (one process per GPU).
 
-Only the generation path is implemented (`data.mode: gen | eval` of the `ldm` experiment; image, video and occupancy domains;
+The generation path (`data.mode: gen | eval` of the `ldm` experiment; image, video and occupancy domains) and the image-domain
+LDM training loop on latents (`data.mode: train`, ddmi_amd/train.py) are implemented;
 occupancy writes one Wavefront .obj per sample, tools/ldm/occupancy.py:205-230): image gen writes a
 grid of `test_batch_size` samples like tools/ldm/image.py:225-249; eval runs the sample-parallel 10k-image loop of
 evals/eval.py:215-234 (images written as PNG shards; Inception scoring needs downloaded weights and is out of scope).
@@ -33,6 +34,8 @@ def main(args):
     torch.cuda.set_device(local_rank)
     dc = args.data_config
     B = int(dc.test_batch_size)
+    if args.mode == "train":
+        return train_main(args, dc, rank, world, dev)
     if args.domain == "occupancy":  # exp/stage.py:207-241, tools/ldm/occupancy.py:205-230
         return occupancy_main(args, dc, B, rank, world, dev)
     if args.domain == "video":  # exp/stage.py:245-262, tools/ldm/video.py:214-236
@@ -89,7 +92,7 @@ def main(args):
         if rank == 0:
             print(f"wrote {total} samples to {fid_dir}")
     else:
-        raise SystemExit("data.mode must be gen or eval (training is out of scope)")
+        raise SystemExit("data.mode must be gen, eval or train")
 
 
 def load_weights(pipe, args, dc, tag):
@@ -122,6 +125,58 @@ def load_weights(pipe, args, dc, tag):
         print("stage-1 checkpoint: the diffusion model keeps its initialisation (named-seed weights)")
         pipe.load_named_seed(tag)
     pipe.load_checkpoint(path)
+
+
+def train_main(args, dc, rank, world, dev):
+    """`data.mode: train` (image domain): the LDM trainer's loop (tools/ldm/image.py:136-178) on LATENTS - the VAE encoder that
+    produces them from images is outside this path.  Latents come from `data.latents` (an .npy of [N,C,H,W] fp32, e.g.
+    `vaemodel.encode(y).sample()` dumped by the reference) or, without one, are synthetic N(0,1).  One process per GPU; every
+    rank draws its own batches and the gradient slab is all-reduced over RCCL each optimizer step.  Writes `ldm-last.pt` in the
+    layout LDMTrainer.save uses, so `mode: gen` picks it up."""
+    import numpy as np
+    import torch
+    from ddmi_amd import checkpoint as CK
+    from ddmi_amd.train import LDMTrainStep
+    if args.domain != "image":
+        raise SystemExit("mode: train is implemented for the image domain")
+    lc = args.loss_config or {}
+    B = int(dc.get("batch_size", dc.test_batch_size))
+    steps = int(os.environ.get("DDMI_TRAIN_STEPS", dc.get("train_steps", 100)))
+    step = LDMTrainStep(args.unetconfig, args.ddpmconfig, numerics=args.numerics, lr=float(getattr(args, "lr", None) or 1e-4),
+                        gradient_accumulate_every=int(lc.get("gradient_accumulate_every", 1)), ema_decay=float(lc.get("ema_decay", 0.9999)),
+                        ema_update_every=int(lc.get("ema_update_every", 10)), device=dev)
+    vae_state, mlp_state = {}, {}
+    path = CK.find_checkpoint(dc.save_pth, resume=bool(getattr(args, "resume", False)), pretrained=bool(args.pretrained))
+    if path is not None:   # the reference's start modes: resume / pretrained continue an LDM, otherwise the stage-1 VAE + MLP
+        ck = CK.read_checkpoint(path)
+        st = CK.sampling_states(ck, use_ema=False)
+        vae_state, mlp_state = st["vae"], st["mlp"]
+        if st["diffusion"] is not None:
+            step.load_state_dict({k: v for k, v in st["diffusion"].items() if k.startswith("model.") or k == "mixing_logit"}, strict=True)
+            print("Loading Models from previous training!" if getattr(args, "resume", False) else "Loading Pretrained Models!")
+    if path is None or not path.endswith("ldm-last.pt"):
+        from ddmi_amd import initweights as iw   # a fresh diffusion model: named-seed init (deterministic across ranks)
+        st = iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in step.model.state_dict().items()])
+        step.load_state_dict({"model." + k: v for k, v in st.items()}, strict=False)
+    step.finalize()
+    lat = None
+    if dc.get("latents") and os.path.exists(dc.latents):
+        lat = torch.from_numpy(np.load(dc.latents).astype(np.float32))
+    g = torch.Generator(device=dev).manual_seed(args.seed * 1000 + rank)
+    C_, S_ = int(args.ddpmconfig.get("channels", 64)), int(args.ddpmconfig.get("image_size", 64))
+    for it in range(steps):
+        if lat is not None:
+            idx = torch.randint(0, lat.shape[0], (B,), generator=torch.Generator().manual_seed(args.seed * 7919 + it * world + rank))
+            z = lat[idx].to(dev)
+        else:
+            z = torch.randn((B, C_, S_, S_), device=dev, generator=g)
+        loss = step.train_step(z, world_size=world)
+        if rank == 0 and (it % 10 == 0 or it == steps - 1):
+            print(f"iter {it}: Dae loss : {float(loss):.4f}", flush=True)
+    if rank == 0:
+        os.makedirs(dc.save_pth, exist_ok=True)
+        step.save(os.path.join(dc.save_pth, "ldm-last.pt"), vae_state, mlp_state)
+        print(f"saved {os.path.join(dc.save_pth, 'ldm-last.pt')} after {step.opt_step} optimizer steps")
 
 
 def generator_settings(dc):

@@ -305,3 +305,42 @@ print('chunked wgrad ok')
     env = dict(os.environ, DDMI_WGRAD_CHUNK_BYTES="50000")   # 2 samples x 64 pixels x 288 rows x 4 B = 147 KB > 50 KB -> chunks
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "chunked wgrad ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_main_train_then_gen_end_to_end(golden, tmp_path):
+    """`python main.py --exp ldm --configs <yaml>` with data.mode train (stage-1 checkpoint -> 4 optimizer steps on synthetic
+    latents -> ldm-last.pt in the reference's layout) and then data.mode gen from that checkpoint: the reference's two modes
+    chained through its own file formats."""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from ddmi_amd.autoencoder import decoder_manifest
+    from ddmi_amd.mlp import mlp_manifest
+    cfgs = golden.json("configs.json")
+    save = str(tmp_path)
+    tt = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+    torch.save({"model": tt(named_state("e2e.vae", decoder_manifest(cfgs["TOY_DD"], cfgs["TOY_EMBED"]))), "mlp": tt(named_state("e2e.mlp", mlp_manifest()))},
+               os.path.join(save, "model-last.pt"))
+    base = {"model": {"embed_dim": cfgs["TOY_EMBED"], "lr": 1e-4, "pretrained": False, "resume": False,
+                      "params": {"unetconfig": cfgs["TOY_UNET"], "ddconfig": cfgs["TOY_DD"], "mlpconfig": cfgs["MLP_CFG"],
+                                 "ddpmconfig": {"timesteps": 1000, "sampling_timesteps": 5, "ddim_sampling_eta": 0.0, "image_size": 8, "channels": 64},
+                                 "lossconfig": {"gradient_accumulate_every": 2, "ema_decay": 0.9999, "ema_update_every": 1}}},
+            "data": {"domain": "image", "mode": "train", "save_pth": save, "test_batch_size": 2, "batch_size": 4, "test_resolution": 32, "train_steps": 8}}
+    def run(cfg, name):
+        path = os.path.join(save, name)
+        with open(path, "w") as f:
+            yaml.safe_dump(cfg, f)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--exp", "ldm", "--configs", path, "--numerics", "fp32"],
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return out.stdout
+    log = run(base, "train.yaml")
+    assert "Dae loss" in log and "after 4 optimizer steps" in log            # 8 micro-steps / gradient_accumulate_every 2
+    ck = torch.load(os.path.join(save, "ldm-last.pt"), map_location="cpu", weights_only=True)
+    assert {"diffusion", "ema", "vaemodel", "mlp", "step"} <= set(ck) and "ema_model.mixing_logit" in ck["ema"]
+    gen = dict(base, data=dict(base["data"], mode="gen"), model=dict(base["model"], pretrained=True))
+    log = run(gen, "gen.yaml")
+    assert "Loading Pretrained Models!" in log and "Finished generating images!" in log
+    img = np.load(os.path.join(save, "results", "generation.npy"))
+    assert img.shape == (2, 32, 32, 3) and img.dtype == np.uint8 and img.std() > 0
