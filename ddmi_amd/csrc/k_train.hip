@@ -18,6 +18,7 @@
 
 template <typename T> __device__ __forceinline__ float tr_ld(const T* p) { return to_f32(*p); }
 template <typename T> __device__ __forceinline__ void tr_st(T* p, float v) { *p = from_f32<T>(v); }
+static inline int tr_blocks(int64_t n) { return (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // convolution gradients: layout helpers
@@ -71,7 +72,7 @@ __global__ void sumpool2x_kernel(const T* __restrict__ up, T* __restrict__ dx, i
 // reads (channel-contiguous) and the writes (pixel-contiguous) are coalesced.
 template <typename T>
 __global__ void __launch_bounds__(256) im2col_t_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int Ci,
-                                                      int Ho, int Wo, int k, int stride, int pad, int ups) {
+                                                      int Ho, int Wo, int k, int stride, int pad, int ups, int64_t ldp) {
   __shared__ float tile[32][33];
   const int64_t P = (int64_t)B * Ho * Wo;
   const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) im2col_t_kernel(const T* __restrict__ x, 
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {   // r = channel within the tile, tx = pixel
     const int64_t p = p0 + tx;
-    if (p < P && c0 + r < Ci) tr_st(out + ((int64_t)tap * Ci + c0 + r) * P + p, tile[tx][r]);
+    if (p < ldp && c0 + r < Ci) tr_st(out + ((int64_t)tap * Ci + c0 + r) * ldp + p, tile[tx][r]);   // columns [P, ldp) are zeros
   }
 }
 
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) im2col_t_kernel(const T* __restrict__ x, 
 // the channels of a pixel (NHWC rows), writes bf16x8 along the pixels of a channel (rows of the transposed image); the
 // transpose goes through an LDS tile with a 144-byte pitch.  The scalar kernel above moved 2 bytes per access: 0.85 TB/s.
 __global__ void __launch_bounds__(256) im2col_t_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W,
-                                                           int Ci, int Ho, int Wo, int k, int stride, int pad, int ups) {
+                                                           int Ci, int Ho, int Wo, int k, int stride, int pad, int ups, int64_t ldp) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];
   const int64_t P = (int64_t)B * Ho * Wo;
   const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
@@ -133,11 +134,11 @@ __global__ void __launch_bounds__(256) im2col_t_bf16_kernel(const bf16_t* __rest
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int idx = threadIdx.x + 256 * j, c = idx >> 3, p8 = (idx & 7) * 8;
-    if (c0 + c < Ci && p0 + p8 < P) {   // P is a multiple of 8: a vector is wholly inside or outside
+    if (c0 + c < Ci && p0 + p8 < ldp) {   // P and ldp are multiples of 8: a vector is wholly inside or outside; [P, ldp) = zeros
       bf16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[(p8 + e) * 72 + c];
-      *reinterpret_cast<bf16x8*>(out + ((int64_t)tap * Ci + c0 + c) * P + p0 + p8) = v;
+      *reinterpret_cast<bf16x8*>(out + ((int64_t)tap * Ci + c0 + c) * ldp + p0 + p8) = v;
     }
   }
 }
@@ -153,6 +154,181 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ G, float* __restri
     const float v = G[((int64_t)tap * Ci + ci) * Co + co];
     dw[i] = accumulate ? dw[i] + v : v;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// wgrad as a TN implicit GEMM (bf16; 3x3 pad 1 or 1x1, stride 1, W in {8, 16, 32, 64}):
+//     dW[co][ci][tap] = sum over pixels p of dY[p][co] * X[p + tap][ci]
+// Both operands are PIXEL-major in memory (NHWC) while the MFMA wants 8 consecutive k (= pixels) per lane: the tiles are
+// staged row-major in LDS with coalesced 16-byte loads - dY as [128 pixels][64 co], X as the (TR+2) x (W+2) halo of the
+// same pixels x 64 ci, zero outside the image - and the fragments are fetched with ds_read_b64_tr_b16 (the hardware's
+// 4 x 16 transpose: lane 4q+p of a 16-lane group supplies row q / columns 4p.., lane i receives column i).  The nine taps
+// read the SAME halo at shifted rows, so nothing like the 9x im2col image of the GEMM formulation exists (that image made
+// the small-channel layers bandwidth-bound: 74 FLOP per byte).  Workgroup = 8 waves = a 64 co x 64 ci x 9 tap tile of dW
+// for one slice of the pixel axis; wave (wc, wi) = 32 co x 16 ci x 9 taps (18 accumulator fragments); slices are summed in
+// slice order by wgrad_tn_finish_kernel (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+#define WG_ROWP 72   // LDS row pitch in elements (144 B) for both tiles
+struct WgradTnK {
+  const bf16_t* dy;   // [B][H][W][Co]
+  const bf16_t* x;    // [B][H][W][Ci]
+  float* slab;        // [S][Co][Ci][KK]
+  int B, H, W, Co, Ci, S, TR, wshift;
+};
+
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wg_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) wg_s16x4* wg_lds4;
+__device__ __forceinline__ bf16x8 wg_tr_frag(const bf16_t* lo, const bf16_t* hi) {
+  const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds4)lo);
+  const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds4)hi);
+  const wg_s16x8 both = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (see k_attention.hip on the element-wise trap)
+}
+
+template <int KK>
+__global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
+  constexpr int KS3 = KK == 9 ? 3 : 1;
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[128 * WG_ROWP];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[272 * WG_ROWP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wi = wave >> 1;
+  const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, p4 = lr & 3;
+  const int W = a.W, H = a.H, TR = a.TR, PT = TR * W;          // pixels per tile (<= 128)
+  const int HWd = KK == 9 ? W + 2 : W, HR = KK == 9 ? TR + 2 : TR, NHR = HR * HWd;   // halo geometry (no halo for 1x1)
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int tiles_per_sample = (H * W) / PT, ntiles = a.B * tiles_per_sample;
+  const int per = (ntiles + a.S - 1) / a.S, t_begin = blockIdx.z * per, t_end = min(ntiles, t_begin + per);
+
+  bf16x8 ry[2], rx[5];
+  auto load_tile = [&](int t) {
+    const int b = t / tiles_per_sample, ty0 = (t - b * tiles_per_sample) * TR;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {   // dY: PT rows x 8 chunks of 8 co
+      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+      if (r < PT && co0 + c8 < a.Co) v = *reinterpret_cast<const bf16x8*>(a.dy + ((int64_t)b * H * W + ty0 * W + r) * a.Co + co0 + c8);
+      ry[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {   // X halo: NHR rows x 8 chunks of 8 ci
+      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+      if (r < NHR && ci0 + c8 < a.Ci) {
+        const int hy = r / HWd, hx = r - hy * HWd;
+        const int iy = KK == 9 ? ty0 - 1 + hy : ty0 + hy, ix = KK == 9 ? hx - 1 : hx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          v = *reinterpret_cast<const bf16x8*>(a.x + ((int64_t)b * H * W + iy * W + ix) * a.Ci + ci0 + c8);
+      }
+      rx[j] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
+      if (r < 128) *reinterpret_cast<bf16x8*>(Ys + r * WG_ROWP + c8) = ry[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
+      if (r < 272) *reinterpret_cast<bf16x8*>(Xs + r * WG_ROWP + c8) = rx[j];
+    }
+  };
+
+  f32x4 acc[2][KK];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    store_tile();
+  }
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) load_tile(t + 1);
+    for (int ks = 0; ks < PT / 32; ++ks) {
+      // this lane supplies, for both 4-pixel blocks of its lane group, the address of pixel (8 lg + 4 r + q) of the k-step
+      const int pl0 = ks * 32 + 8 * lg + q, pl1 = pl0 + 4;
+      const bf16_t* ylo = Ys + pl0 * WG_ROWP + 32 * wc + 4 * p4;
+      const bf16_t* yhi = Ys + pl1 * WG_ROWP + 32 * wc + 4 * p4;
+      const bf16x8 af0 = wg_tr_frag(ylo, yhi), af1 = wg_tr_frag(ylo + 16, yhi + 16);
+      const int ty_0 = pl0 >> a.wshift, tx_0 = pl0 & (W - 1), ty_1 = pl1 >> a.wshift, tx_1 = pl1 & (W - 1);
+      const bf16_t* xlo = Xs + (ty_0 * HWd + tx_0) * WG_ROWP + 16 * wi + 4 * p4;
+      const bf16_t* xhi = Xs + (ty_1 * HWd + tx_1) * WG_ROWP + 16 * wi + 4 * p4;
+#pragma unroll
+      for (int kh = 0; kh < KS3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS3; ++kw) {
+          const int sh = (kh * HWd + kw) * WG_ROWP;
+          const bf16x8 bf = wg_tr_frag(xlo + sh, xhi + sh);
+          acc[0][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf, acc[0][kh * KS3 + kw], 0, 0, 0);
+          acc[1][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf, acc[1][kh * KS3 + kw], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (t + 1 < t_end) store_tile();
+    __syncthreads();
+  }
+  // slab[z][co][ci][tap]: lane (lr = ci, lg -> co rows 4 lg + e) of accumulator fragment f
+  const int ci = ci0 + 16 * wi + lr;
+  if (ci < a.Ci) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + 32 * wc + 16 * f + 4 * lg + e;
+        if (co < a.Co) {
+          float* dst = a.slab + (((int64_t)blockIdx.z * a.Co + co) * a.Ci + ci) * KK;
+#pragma unroll
+          for (int t = 0; t < KK; ++t) dst[t] = acc[f][t][e];
+        }
+      }
+  }
+}
+
+__global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n, int S) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int z = 0; z < S; ++z) acc += slab[(int64_t)z * n + i];
+    dw[i] = acc;
+  }
+}
+
+bool wgrad_tn_ok(int dt, int H, int W, int Ci, int Co, int k, int stride, int ups) {
+  if (dt != DT_BF16 || stride != 1 || ups || !(k == 1 || k == 3)) return false;
+  if (!(W == 8 || W == 16 || W == 32 || W == 64) || Ci % 8 || Co % 8) return false;
+  const int PT = std::min(128, H * W);
+  return (H * W) % PT == 0 && PT % 32 == 0 && PT % W == 0;
+}
+int wgrad_tn_splits(int B, int H, int W, int Ci, int Co) {
+  const int tiles = cdiv(Ci, 64) * cdiv(Co, 64), PT = std::min(128, H * W), ntiles = B * (H * W / PT);
+  return std::max(1, std::min(std::min(cdiv(1024, tiles), ntiles), 64));
+}
+// slab: wgrad_tn_splits(...) * Co * Ci * k*k floats
+int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s) {
+  WgradTnK a{};
+  a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
+  a.B = B; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci;
+  a.S = wgrad_tn_splits(B, H, W, Ci, Co);
+  a.TR = std::min(128, H * W) / W;
+  a.wshift = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
+  dim3 g((unsigned)cdiv(Ci, 64), (unsigned)cdiv(Co, 64), (unsigned)a.S);
+  const int kk = k * k;
+  PROF_SCOPE("wgrad_tn", 2.0 * B * H * W * (double)Co * Ci * kk, ((double)B * H * W * (Co + Ci)) * 2.0, s);
+  if (k == 3) hipLaunchKernelGGL(wgrad_tn_kernel<9>, g, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(wgrad_tn_kernel<1>, g, dim3(512), 0, s, a);
+  const int64_t n = (int64_t)Co * Ci * kk;
+  hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
 }
 
 // out[b][c] = sum over HW of dy[b][hw][c].  grid (ceil(C/64), B, S): S pixel slices per sample so that a launch fills the
@@ -188,7 +364,6 @@ __global__ void sum_b_kernel(const float* __restrict__ in, float* __restrict__ o
   out[c] = acc;
 }
 
-static inline int tr_blocks(int64_t n) { return (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16); }
 
 int launch_pack_dgrad_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s) {
   const int64_t n = (int64_t)Co * Ci * k * k;
@@ -213,16 +388,20 @@ int launch_sumpool2x(const void* up, void* dx, int dt, int B, int H, int W, int 
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
+// out rows have pitch ldp >= P = B*Ho*Wo elements; columns [P, ldp) are written as zeros.  A pitch that is not a large power
+// of two matters: the wgrad GEMM walks hundreds of these rows in lock step, and rows 2^k bytes apart fall on the same L2 / HBM
+// channels.
 int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int Ci, int Ho, int Wo, int k, int stride, int pad, int ups,
-                    hipStream_t s) {
+                    int64_t ldp, hipStream_t s) {
   const int64_t P = (int64_t)B * Ho * Wo;
-  dim3 g((unsigned)cdiv64(P, 32), (unsigned)cdiv(Ci, 32), (unsigned)(k * k));
+  DDMI_REQUIRE(ldp >= P, "im2col_t: row pitch below the row length");
+  dim3 g((unsigned)cdiv64(ldp, 32), (unsigned)cdiv(Ci, 32), (unsigned)(k * k));
   PROF_SCOPE("wgrad_im2col_t", 0, 2.0 * k * k * (double)P * Ci * dt_size(dt), s);
-  if (dt == DT_F32) hipLaunchKernelGGL(im2col_t_kernel<float>, g, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
-  else if (Ci % 8 == 0 && P % 8 == 0)
-    hipLaunchKernelGGL(im2col_t_bf16_kernel, dim3((unsigned)cdiv64(P, 64), (unsigned)cdiv(Ci, 64), (unsigned)(k * k)), dim3(256), 0, s,
-                       (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
-  else hipLaunchKernelGGL(im2col_t_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups);
+  if (dt == DT_F32) hipLaunchKernelGGL(im2col_t_kernel<float>, g, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups, ldp);
+  else if (Ci % 8 == 0 && P % 8 == 0 && ldp % 8 == 0)
+    hipLaunchKernelGGL(im2col_t_bf16_kernel, dim3((unsigned)cdiv64(ldp, 64), (unsigned)cdiv(Ci, 64), (unsigned)(k * k)), dim3(256), 0, s,
+                       (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups, ldp);
+  else hipLaunchKernelGGL(im2col_t_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, Ci, Ho, Wo, k, stride, pad, ups, ldp);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

@@ -179,7 +179,7 @@ int launch_pack_dgrad_weight(const float* w_oihw, void* out, int dt, int Co, int
 int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo, int C, hipStream_t s);
 int launch_sumpool2x(const void* up, void* dx, int dt, int B, int H, int W, int C, hipStream_t s);
 int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int Ci, int Ho, int Wo, int k, int stride, int pad, int ups,
-                    hipStream_t s);   // out [(tap * Ci + ci)][B * Ho * Wo]
+                    int64_t ldp, hipStream_t s);   // out [(tap * Ci + ci)][ldp >= B * Ho * Wo], tail columns zero
 int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, int accumulate, hipStream_t s);
 int sum_hw_slices(int B, int HW, int C);
 int launch_sum_hw(const void* dy, float* out, float* part, int dt, int B, int HW, int C, hipStream_t s);   // out [B][C]; part: slices*B*C floats
@@ -200,3 +200,7 @@ int launch_eps_loss(const float* model_out, const float* x_t, const float* noise
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
                  float grad_scale, hipStream_t s);
 int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s);
+// wgrad as a TN implicit GEMM with transposing LDS reads (bf16, 3x3 / 1x1 stride 1, W in {8,16,32,64}); slab = splits*Co*Ci*k*k floats
+bool wgrad_tn_ok(int dt, int H, int W, int Ci, int Co, int k, int stride, int ups);
+int wgrad_tn_splits(int B, int H, int W, int Ci, int Co);
+int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s);

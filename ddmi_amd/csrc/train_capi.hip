@@ -76,6 +76,22 @@ static void prefer_halo(ConvArgs* c, int dt) {
   else if (p128 * 100 <= c->Cout * 115) c->cfg = 21;   // halo<128,4,2>
 }
 
+// wgrad GEMM G[N][M] over a long pixel axis: the software-pipelined 128x224 tile (pipe kernel) instead of the heuristic's ring
+// tile, and a split-K that fills whole waves of 256 workgroups (M = Cout = 224 gives only 2 x N/224 tiles: with the generic
+// pick 18 tiles x 16 splits = 288 workgroups = one full round + one at 12 %)
+static void plan_wgrad_gemm(ConvArgs* g, int dt) {
+  if (dt != DT_BF16 || g->Cout % 112 != 0) { g->splitk = conv_pick_splitk(*g, dt); return; }
+  g->cfg = 15;   // pipe<128,224,2,2>
+  const int tiles = cdiv(g->Win, 128) * cdiv(g->Cout, 224), stages = cdiv(g->Cin, 64);
+  int best = 1;
+  double best_eff = 0.0;
+  for (int sk = 1; sk <= 16 && stages / sk >= 16; ++sk) {
+    const double wg = (double)tiles * sk, eff = wg / (std::ceil(wg / 256.0) * 256.0);
+    if (eff > best_eff + 0.03) { best = sk; best_eff = eff; }
+  }
+  g->splitk = best;
+}
+
 static void conv_geometry(int H, int W, int k, int stride, int ups, int* Ho, int* Wo) {
   const int hin = ups ? 2 * H : H, win = ups ? 2 * W : W, pad = k / 2;
   *Ho = (hin + 2 * pad - k) / stride + 1;
@@ -123,6 +139,7 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
   int bc = B;
   while (bc > 1 && (double)std::max(N, Cout) * ((double)bc * Ho * Wo) * es > chunk_bytes) bc = (bc + 1) / 2;
   const int64_t Pc = (int64_t)bc * Ho * Wo;
+  const int WPAD = 64;   // both GEMM operands get rows of Pn + 64 elements (zeros in the tail): see launch_im2col_t
   DDMI_REQUIRE(Pc % (dt == DT_F32 ? 4 : 8) == 0 && P % (dt == DT_F32 ? 4 : 8) == 0,
                "train_conv_bwd: (samples per chunk)*Ho*Wo must be a multiple of the 16-byte vector");
   DDMI_REQUIRE((double)std::max(N, Cout) * Pc * es < 2.1e9, "train_conv_bwd: one sample's im2col image exceeds 2 GiB");
@@ -134,17 +151,20 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
   prefer_halo(&d, dt);
   d.splitk = dx ? conv_pick_splitk(d, dt) : 1;
   ConvArgs g{};   // wgrad: G[n][co] = sum_p Bm[n][p] A[co][p] as a 1x1 "convolution" over rows of A (one chunk of samples)
-  g.B = 1; g.Hin = 1; g.Win = Cout; g.Cin = (int)Pc; g.Hout = 1; g.Wout = Cout; g.Cout = N;
+  g.B = 1; g.Hin = 1; g.Win = Cout; g.Cin = (int)Pc + WPAD; g.Hout = 1; g.Wout = Cout; g.Cout = N;
   g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.ups = 0; g.out_scale = 1.f;
-  g.splitk = conv_pick_splitk(g, dt);
+  plan_wgrad_gemm(&g, dt);
   const size_t dgrad_bytes = dx ? al((size_t)Cout * Cin * kk * es) + (stride == 2 ? al((size_t)B * Hg * Wg * Cout * es) : 0) +
                                       (ups ? al((size_t)B * Hg * Wg * Cin * es) : 0) +
                                       (d.splitk > 1 ? al((size_t)d.splitk * B * Hg * Wg * Cin * sizeof(float)) : 0)
                                 : 0;
-  const size_t wgrad_bytes = al((size_t)Cout * Pc * es) + al((size_t)N * Pc * es) + al((size_t)N * Cout * sizeof(float)) +
+  const size_t wgrad_bytes = al((size_t)Cout * (Pc + WPAD) * es) + al((size_t)N * (Pc + WPAD) * es) + al((size_t)N * Cout * sizeof(float)) +
                              (g.splitk > 1 ? al((size_t)g.splitk * Cout * N * sizeof(float)) : 0);
   const size_t red_bytes = al((size_t)B * Cout * sizeof(float)) * (1 + (size_t)sum_hw_slices(B, Ho * Wo, Cout));
-  DDMI_TRY(reserve(h, std::max(dgrad_bytes, wgrad_bytes) + red_bytes, s));
+  static const bool no_tn = getenv("DDMI_WGRAD_GEMM") != nullptr;   // diagnostics: the im2col + GEMM formulation everywhere
+  const bool tn = !no_tn && wgrad_tn_ok(dt, H, W, Cin, Cout, k, stride, ups);
+  const size_t tn_bytes = tn ? al((size_t)wgrad_tn_splits(B, H, W, Cin, Cout) * Cout * Cin * kk * sizeof(float)) : 0;
+  DDMI_TRY(reserve(h, std::max(dgrad_bytes, tn ? tn_bytes : wgrad_bytes) + red_bytes, s));
   // ---- bias / embedding gradients ---------------------------------------------------------------------------
   if (dbias || demb) {
     Carve c{h};
@@ -173,11 +193,15 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
     if (ups) DDMI_TRY(launch_sumpool2x(dst, dx, dt, B, H, W, Cin, s));
   }
   // ---- wgrad ------------------------------------------------------------------------------------------------
-  {
+  if (tn) {   // TN implicit GEMM straight from dY and x (k_train.hip): no transposed copies, no im2col image
     Carve c{h};
     c.take(red_bytes);
-    void* A = c.take((size_t)Cout * Pc * es);
-    void* Bm = c.take((size_t)N * Pc * es);
+    DDMI_TRY(launch_wgrad_tn(dy, x, dw, (float*)c.take(tn_bytes), B, H, W, Cin, Cout, k, s));
+  } else {
+    Carve c{h};
+    c.take(red_bytes);
+    void* A = c.take((size_t)Cout * (Pc + WPAD) * es);
+    void* Bm = c.take((size_t)N * (Pc + WPAD) * es);
     float* G = (float*)c.take((size_t)N * Cout * sizeof(float));
     if (g.splitk > 1) g.splitk_ws = (float*)c.take((size_t)g.splitk * Cout * N * sizeof(float));
     for (int b0 = 0; b0 < B; b0 += bc) {
@@ -185,15 +209,13 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
       const int64_t Pn = (int64_t)nb * Ho * Wo;
       const unsigned char* dyc = (const unsigned char*)dy + (size_t)b0 * Ho * Wo * Cout * es;
       const unsigned char* xc = (const unsigned char*)x + (size_t)b0 * H * W * Cin * es;
-      {
-        PROF_SCOPE("wgrad_transpose", 0, 2.0 * (double)Pn * Cout * es, s);
-        DDMI_TRY(launch_transpose_2d(dyc, A, dt, 1, (int)Pn, Cout, s));                   // A[co][p] = dY[p][co]
-      }
-      DDMI_TRY(launch_im2col_t(xc, Bm, dt, nb, H, W, Cin, Ho, Wo, k, stride, k / 2, ups ? 1 : 0, s));
+      // A[co][p] = dY[p][co]: the transpose is the k = 1 case of the transposed im2col (dY as a [nb, Ho, Wo, Cout] image)
+      DDMI_TRY(launch_im2col_t(dyc, A, dt, nb, Ho, Wo, Cout, Ho, Wo, 1, 1, 0, 0, Pn + WPAD, s));
+      DDMI_TRY(launch_im2col_t(xc, Bm, dt, nb, H, W, Cin, Ho, Wo, k, stride, k / 2, ups ? 1 : 0, Pn + WPAD, s));
       ConvArgs gc = g;
-      gc.Cin = (int)Pn;
+      gc.Cin = (int)Pn + WPAD;
       gc.x = A; gc.w = Bm; gc.y_nchw = G;
-      if (nb != bc) { gc.splitk = conv_pick_splitk(gc, dt); if (gc.splitk > g.splitk) gc.splitk = g.splitk; if (gc.splitk <= 1) gc.splitk_ws = nullptr; }
+      if (nb != bc) { plan_wgrad_gemm(&gc, dt); if (gc.splitk > g.splitk) gc.splitk = g.splitk; if (gc.splitk <= 1) gc.splitk_ws = nullptr; }
       DDMI_TRY(launch_conv(gc, dt, s));
       DDMI_TRY(launch_wgrad_finish(G, dw, Cout, Cin, kk, b0 > 0, s));
     }

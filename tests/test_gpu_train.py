@@ -33,7 +33,10 @@ def g(tag, key, shape, std=1.0):
 
 @pytest.mark.parametrize("numerics,tol", [("fp32", 2e-5), ("bf16", TOL_BF16)])
 @pytest.mark.parametrize("k,stride,ups,cin,cout,hw", [(3, 1, 0, 32, 64, 8), (1, 1, 0, 64, 96, 8), (3, 2, 0, 32, 32, 8), (3, 1, 1, 32, 32, 4),
-                                                     (3, 1, 0, 224, 224, 16)])
+                                                     (3, 1, 0, 224, 224, 16),
+                                                     # the TN implicit-GEMM wgrad (bf16): several pixel tiles per sample, ragged
+                                                     # channel tiles, W = 64 (two rows per tile), 1x1 at 448 channels
+                                                     (3, 1, 0, 96, 160, 32), (3, 1, 0, 72, 40, 64), (1, 1, 0, 224, 448, 16)])
 def test_conv_forward_backward_vs_torch(numerics, tol, k, stride, ups, cin, cout, hw):
     tc = T.TrainContext(numerics, DEV)
     B = 2
@@ -302,7 +305,8 @@ for numerics, tol in (('fp32', 2e-5), ('bf16', 4e-2)):
     assert rel_err(xd.grad.float().permute(0, 3, 1, 2).cpu(), xr.grad) < tol
 print('chunked wgrad ok')
 """ % (ROOT, ROOT)
-    env = dict(os.environ, DDMI_WGRAD_CHUNK_BYTES="50000")   # 2 samples x 64 pixels x 288 rows x 4 B = 147 KB > 50 KB -> chunks
+    # DDMI_WGRAD_GEMM: keep the bf16 leg on the im2col + GEMM formulation too (its default here is the TN kernel)
+    env = dict(os.environ, DDMI_WGRAD_CHUNK_BYTES="50000", DDMI_WGRAD_GEMM="1")   # 2 samples x 64 pixels x 288 rows x 4 B = 147 KB > 50 KB -> chunks
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "chunked wgrad ok" in out.stdout, out.stdout + out.stderr
 
