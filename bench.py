@@ -523,7 +523,8 @@ def run_train(args, rank, local_rank, world, dev):
     from ddmi_amd import initweights as iw
     from ddmi_amd.train import LDMTrainStep
     B = args.batch or 64
-    tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev)
+    tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev,
+                      use_graph=not args.no_graph)
     st = {"model." + k: v for k, v in iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
     tr.load_state_dict(st, strict=False).finalize()
     g = torch.Generator(device=dev).manual_seed(args.seed + rank)
@@ -532,9 +533,8 @@ def run_train(args, rank, local_rank, world, dev):
         z = torch.randn((B, 64, 64, 64), device=dev, generator=g)
         return tr.train_step(z, world_size=world)
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, args.warmup) + (0 if args.no_graph else 1)):   # graph mode: eager step, then the capturing step
         one_step()
-    _lib.profile_enable(1)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -543,6 +543,11 @@ def run_train(args, rank, local_rank, world, dev):
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    # per-kernel HIP-event scopes of ONE more step, outside the timed region (two event records per launch are host work)
+    tr.use_graph = False   # the scopes record HIP events around every launch: an eager step
+    _lib.profile_enable(1)
+    one_step()
+    torch.cuda.synchronize()
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
     nranks = D.group_size(dev)
@@ -557,13 +562,13 @@ def run_train(args, rank, local_rank, world, dev):
             "data": "synthetic",
             "config": {"workload": "AFHQ UNet (519 M parameters) training step on synthetic [B,64,64,64] latents: q_sample, forward, mixed-prediction "
                                    "MSE, backward (conv dgrad / wgrad on the forward MFMA kernels), flat-slab gradient all-reduce, fused AdamW; "
-                                   "fp32 master weights, bf16 activations", "batch_per_gpu": B, "global_batch": world * B,
+                                   "fp32 master weights, bf16 activations" + ("" if args.no_graph else "; micro-step replayed as one hipGraph"), "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"data-parallel x{world} (one 2.08 GB gradient all-reduce per step, two 1 GiB buckets)"},
             "nccl_ranks": nranks, "loss_last_step": float(loss),
             "roofline": dict(roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None) or {}, traffic=None),
             "step_mfma_frac": round(flops / elapsed / 1e12 / PEAK_BF16_TFLOPS / world, 4),
             "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
-            "profiled_kernel_ms_per_step": round(tot_ms / args.steps, 1)}
+            "profiled_kernel_ms_per_step": round(tot_ms, 1)}
     return line
 
 
@@ -574,6 +579,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 64, sky 16, train 64)")
+    ap.add_argument("--no-graph", action="store_true", help="train workload: eager launches instead of the hipGraph replay")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")

@@ -36,6 +36,41 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, T* __restr
     out[i] = from_f32<T>(w[(((int64_t)co * Ci + ci) * k + kh) * k + kw]);
   }
 }
+// the same through an LDS tile (this runs for every convolution of every training step: 2 GB of master weights): a block owns
+// 128 co x TCI ci x kk taps; the source rows (TCI * kk contiguous floats per co) are read in whole runs, the destination is
+// written as 128 consecutive co per (ci, tap).  TCI * kk <= 72: grid (ceil(Ci / TCI), ceil(Co / 128)).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_dgrad_weight_tiled_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int k,
+                                                                      int TCI) {
+  __shared__ float tile[128][73];
+  const int kk = k * k, run = TCI * kk;                  // contiguous floats of one co row inside the tile
+  const int ci0 = blockIdx.x * TCI, co0 = blockIdx.y * 128;
+  const int nci = min(TCI, Ci - ci0), len = nci * kk;
+  for (int i = threadIdx.x; i < 128 * run; i += 256) {
+    const int r = i / run, j = i - r * run;
+    if (co0 + r < Co && j < len) tile[r][j] = w[((int64_t)(co0 + r) * Ci + ci0) * kk + j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < run * 128; i += 256) {
+    const int j = i >> 7, r = i & 127;                   // j = (ci, destination tap), r = co
+    const int ci = j / kk, tp = j - ci * kk;
+    if (co0 + r < Co && ci < nci) out[((int64_t)(ci0 + ci) * kk + tp) * Co + co0 + r] = from_f32<T>(tile[r][ci * kk + (kk - 1 - tp)]);
+  }
+}
+// forward layout [Co][k*k][Ci] (launch_pack_conv_weight) through LDS: a block owns one co and up to 256 ci - the source run
+// (256 * kk floats) is contiguous, the destination is kk runs of 256 ci
+template <typename T>
+__global__ void __launch_bounds__(256) pack_fwd_weight_tiled_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int kk) {
+  __shared__ float tile[256 * 9 + 8];
+  const int co = blockIdx.y, ci0 = blockIdx.x * 256, nci = min(256, Ci - ci0), len = nci * kk;
+  const float* src = w + ((int64_t)co * Ci + ci0) * kk;
+  for (int i = threadIdx.x; i < len; i += 256) tile[i] = src[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const int tp = i / nci, ci = i - tp * nci;
+    out[((int64_t)co * kk + tp) * Ci + ci0 + ci] = from_f32<T>(tile[ci * kk + tp]);
+  }
+}
 
 // u[b][2i][2j][c] = dy[b][i][j][c], 0 elsewhere  (u is [B][2Ho][2Wo][C])
 template <typename T>
@@ -160,131 +195,152 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ G, float* __restri
 // wgrad as a TN implicit GEMM (bf16; 3x3 pad 1 or 1x1, stride 1, W in {8, 16, 32, 64}):
 //     dW[co][ci][tap] = sum over pixels p of dY[p][co] * X[p + tap][ci]
 // Both operands are PIXEL-major in memory (NHWC) while the MFMA wants 8 consecutive k (= pixels) per lane: the tiles are
-// staged row-major in LDS with coalesced 16-byte loads - dY as [128 pixels][64 co], X as the (TR+2) x (W+2) halo of the
-// same pixels x 64 ci, zero outside the image - and the fragments are fetched with ds_read_b64_tr_b16 (the hardware's
-// 4 x 16 transpose: lane 4q+p of a 16-lane group supplies row q / columns 4p.., lane i receives column i).  The nine taps
-// read the SAME halo at shifted rows, so nothing like the 9x im2col image of the GEMM formulation exists (that image made
-// the small-channel layers bandwidth-bound: 74 FLOP per byte).  Workgroup = 8 waves = a 64 co x 64 ci x 9 tap tile of dW
-// for one slice of the pixel axis; wave (wc, wi) = 32 co x 16 ci x 9 taps (18 accumulator fragments); slices are summed in
-// slice order by wgrad_tn_finish_kernel (deterministic).
+// staged row-major in LDS - dY as two [128 pixels][64 co] halves, X as the (TR+2) x (W+2) halo of the same pixels x 64 ci,
+// zero outside the image - and the fragments are fetched with ds_read_b64_tr_b16 (the hardware's 4 x 16 transpose: lane
+// 4q+p of a 16-lane group supplies row q / columns 4p.., lane i receives column i).  The nine taps read the SAME halo at
+// shifted rows, so nothing like the 9x im2col image of the GEMM formulation exists (that image made the small-channel
+// layers bandwidth-bound: 74 FLOP per byte).
+//   * Workgroup = 8 waves = a 128 co x 64 ci x 9 tap tile of dW for one slice of the pixel axis; wave (hf, wi) = 64 co x
+//     16 ci x 9 taps = 36 accumulator fragments: 26 transposing reads per 36 MFMAs keeps the LDS pipe under the MFMA time.
+//   * Tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, 1 KiB = 8 rows per wave instruction, zero fill through
+//     the descriptor's range check) into a two-stage ring: tile t+1 is in flight while tile t is multiplied, one barrier per
+//     tile, no staging registers.  One DMA instruction moves 8 rows x 128 B (whole cache lines) into one KiB of LDS laid
+//     out [16-channel unit u][row & 7][32 B] - the lane -> (row, chunk) assignment on the SOURCE side is free - and the k
+//     index of a k-step is permuted so that lane group lg owns the 4-pixel blocks lg and lg + 4: a 32-lane half of a
+//     transposing read then covers 8 consecutive rows of one unit = 256 contiguous bytes, all 64 banks once.
+//   * Pixel slices are summed in slice order by wgrad_tn_finish_kernel (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
-#define WG_ROWP 72   // LDS row pitch in elements (144 B) for both tiles
 struct WgradTnK {
   const bf16_t* dy;   // [B][H][W][Co]
   const bf16_t* x;    // [B][H][W][Ci]
   float* slab;        // [S][Co][Ci][KK]
   int B, H, W, Co, Ci, S, TR, wshift;
 };
+#define WG_YB (128 * 128)                 // bytes of one dY half tile: 128 pixels x 64 co
+#define WG_XROWS 272                      // halo rows rounded up to whole DMA instructions (>= 4 x 66)
+#define WG_XB (WG_XROWS * 128)
+#define WG_STAGE (2 * WG_YB + WG_XB)      // 67584 B; two stages = 132 KiB of the CU's 160
+#define WG_OOB 0x80000000u
 
 typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
 typedef short wg_s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) wg_s16x4* wg_lds4;
-__device__ __forceinline__ bf16x8 wg_tr_frag(const bf16_t* lo, const bf16_t* hi) {
+typedef __attribute__((address_space(3))) void wg_lds_void;
+__device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* lo, const unsigned char* hi) {
   const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds4)lo);
   const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds4)hi);
   const wg_s16x8 both = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (see k_attention.hip on the element-wise trap)
 }
+// byte offset inside a [rows][64 channel] tile of (row r, 16-channel unit 0): KiB blocks of 8 rows, [unit][row & 7][32 B]
+__device__ __forceinline__ int wg_row(int r) { return (r >> 3) * 768 + r * 32; }
 
 template <int KK>
 __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
-  constexpr int KS3 = KK == 9 ? 3 : 1;
-  __shared__ __attribute__((aligned(16))) bf16_t Ys[128 * WG_ROWP];
-  __shared__ __attribute__((aligned(16))) bf16_t Xs[272 * WG_ROWP];
+  constexpr int KS3 = KK == 9 ? 3 : 1, PAD = KK == 9 ? 1 : 0;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char wg_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wi = wave >> 1;
+  const int wi = wave & 3, hf = wave >> 2;
   const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, p4 = lr & 3;
   const int W = a.W, H = a.H, TR = a.TR, PT = TR * W;          // pixels per tile (<= 128)
-  const int HWd = KK == 9 ? W + 2 : W, HR = KK == 9 ? TR + 2 : TR, NHR = HR * HWd;   // halo geometry (no halo for 1x1)
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int HWd = W + 2 * PAD, NHR = (TR + 2 * PAD) * HWd;     // halo geometry (no halo for 1x1)
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
   const int tiles_per_sample = (H * W) / PT, ntiles = a.B * tiles_per_sample;
   const int per = (ntiles + a.S - 1) / a.S, t_begin = blockIdx.z * per, t_end = min(ntiles, t_begin + per);
 
-  bf16x8 ry[2], rx[5];
-  auto load_tile = [&](int t) {
+  // ---- DMA roles (fixed over the tiles): instruction gi = wave + 8 j moves rows 8 gi .. 8 gi + 7; lane = (row, 16-byte slot)
+  const int drow = (lane >> 1) & 7, dchunk = 2 * (lane >> 4) + (lane & 1);   // LDS position 16 lane = [unit][row][half]
+  unsigned yoff[4];            // dY: 32 instructions (2 halves x 16 row groups)
+  int xoff[5], xhy[5];         // X halo: <= 34 instructions; byte offset relative to the tile's first pixel row, halo row - PAD
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gi = wave + 8 * j, yh = gi >> 4, r = 8 * (gi & 15) + drow;
+    const int co = co0 + 64 * yh + 8 * dchunk;
+    yoff[j] = (r < PT && co < a.Co) ? (unsigned)((r * a.Co + co) * 2) : WG_OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int gi = wave + 8 * j, r = 8 * gi + drow;
+    const int ci = ci0 + 8 * dchunk;
+    const int hy = r / HWd, hx = r - hy * HWd;
+    const bool ok = r < NHR && ci < a.Ci && hx >= PAD && hx < W + PAD;
+    xoff[j] = (((hy - PAD) * W + hx - PAD) * a.Ci + ci) * 2;
+    xhy[j] = ok ? hy - PAD : -(1 << 20);
+  }
+  auto issue = [&](int t, int stage) {
     const int b = t / tiles_per_sample, ty0 = (t - b * tiles_per_sample) * TR;
+    unsigned char* base = wg_smem + stage * WG_STAGE;
+    const bf16_t* yg = a.dy + ((int64_t)b * H * W + ty0 * W) * a.Co;
+    const bf16_t* xg = a.x + (int64_t)b * H * W * a.Ci;
+    auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yg, 0, (unsigned)(PT * a.Co * 2), 0x00020000);
+    auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (unsigned)(H * W * a.Ci * 2), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {   // dY: PT rows x 8 chunks of 8 co
-      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
-      bf16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
-      if (r < PT && co0 + c8 < a.Co) v = *reinterpret_cast<const bf16x8*>(a.dy + ((int64_t)b * H * W + ty0 * W + r) * a.Co + co0 + c8);
-      ry[j] = v;
+    for (int j = 0; j < 4; ++j) {
+      const int gi = wave + 8 * j;
+      if (8 * (gi & 15) < PT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (wg_lds_void*)(base + (gi >> 4) * WG_YB + (gi & 15) * 1024), 16, yoff[j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {   // X halo: NHR rows x 8 chunks of 8 ci
-      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
-      bf16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
-      if (r < NHR && ci0 + c8 < a.Ci) {
-        const int hy = r / HWd, hx = r - hy * HWd;
-        const int iy = KK == 9 ? ty0 - 1 + hy : ty0 + hy, ix = KK == 9 ? hx - 1 : hx;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-          v = *reinterpret_cast<const bf16x8*>(a.x + ((int64_t)b * H * W + iy * W + ix) * a.Ci + ci0 + c8);
-      }
-      rx[j] = v;
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
-      if (r < 128) *reinterpret_cast<bf16x8*>(Ys + r * WG_ROWP + c8) = ry[j];
-    }
+    const int tile_off = ty0 * W * a.Ci * 2;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const int idx = tid + 512 * j, r = idx >> 3, c8 = (idx & 7) * 8;
-      if (r < 272) *reinterpret_cast<bf16x8*>(Xs + r * WG_ROWP + c8) = rx[j];
+      const int gi = wave + 8 * j;
+      if (8 * gi < NHR) {
+        const unsigned voff = (unsigned)(ty0 + xhy[j]) < (unsigned)H ? (unsigned)(xoff[j] + tile_off) : WG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (wg_lds_void*)(base + 2 * WG_YB + gi * 1024), 16, voff, 0, 0, 0);
+      }
     }
   };
 
-  f32x4 acc[2][KK];
+  f32x4 acc[4][KK];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (t_begin < t_end) {
-    load_tile(t_begin);
-    store_tile();
-  }
+  if (t_begin < t_end) issue(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int stage = 0;
   for (int t = t_begin; t < t_end; ++t) {
-    if (t + 1 < t_end) load_tile(t + 1);
+    if (t + 1 < t_end) issue(t + 1, stage ^ 1);   // the other stage was last read before the barrier that ended tile t-1
+    const unsigned char* Y = wg_smem + stage * WG_STAGE + hf * WG_YB;
+    const unsigned char* X = wg_smem + stage * WG_STAGE + 2 * WG_YB;
+#pragma unroll 1
     for (int ks = 0; ks < PT / 32; ++ks) {
-      // this lane supplies, for both 4-pixel blocks of its lane group, the address of pixel (8 lg + 4 r + q) of the k-step
-      const int pl0 = ks * 32 + 8 * lg + q, pl1 = pl0 + 4;
-      const bf16_t* ylo = Ys + pl0 * WG_ROWP + 32 * wc + 4 * p4;
-      const bf16_t* yhi = Ys + pl1 * WG_ROWP + 32 * wc + 4 * p4;
-      const bf16x8 af0 = wg_tr_frag(ylo, yhi), af1 = wg_tr_frag(ylo + 16, yhi + 16);
-      const int ty_0 = pl0 >> a.wshift, tx_0 = pl0 & (W - 1), ty_1 = pl1 >> a.wshift, tx_1 = pl1 & (W - 1);
-      const bf16_t* xlo = Xs + (ty_0 * HWd + tx_0) * WG_ROWP + 16 * wi + 4 * p4;
-      const bf16_t* xhi = Xs + (ty_1 * HWd + tx_1) * WG_ROWP + 16 * wi + 4 * p4;
+      // k index of the k-step: lane group lg, element e -> pixel 4 lg + e (e < 4), 16 + 4 lg + e - 4 (e >= 4); this lane
+      // supplies the address of row q of both blocks
+      const int pl0 = ks * 32 + 4 * lg + q, pl1 = pl0 + 16;
+      const unsigned char* y0 = Y + wg_row(pl0) + 8 * p4;
+      const unsigned char* y1 = Y + wg_row(pl1) + 8 * p4;
+      bf16x8 af[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) af[f] = wg_tr_frag(y0 + 256 * f, y1 + 256 * f);
+      const int r0 = (pl0 >> a.wshift) * HWd + (pl0 & (W - 1)), r1 = (pl1 >> a.wshift) * HWd + (pl1 & (W - 1));
+      const unsigned char* xb = X + 256 * wi + 8 * p4;
 #pragma unroll
       for (int kh = 0; kh < KS3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < KS3; ++kw) {
-          const int sh = (kh * HWd + kw) * WG_ROWP;
-          const bf16x8 bf = wg_tr_frag(xlo + sh, xhi + sh);
-          acc[0][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf, acc[0][kh * KS3 + kw], 0, 0, 0);
-          acc[1][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf, acc[1][kh * KS3 + kw], 0, 0, 0);
+          const int sh = kh * HWd + kw;
+          const bf16x8 bf = wg_tr_frag(xb + wg_row(r0 + sh), xb + wg_row(r1 + sh));
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            acc[f][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bf, acc[f][kh * KS3 + kw], 0, 0, 0);
         }
     }
-    __syncthreads();
-    if (t + 1 < t_end) store_tile();
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t+1 has landed
+    __syncthreads();                                    // ... everyone's has, and everyone is done reading tile t
+    stage ^= 1;
   }
   // slab[z][co][ci][tap]: lane (lr = ci, lg -> co rows 4 lg + e) of accumulator fragment f
   const int ci = ci0 + 16 * wi + lr;
   if (ci < a.Ci) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int co = co0 + 32 * wc + 16 * f + 4 * lg + e;
+        const int co = co0 + 64 * hf + 16 * f + 4 * lg + e;
         if (co < a.Co) {
           float* dst = a.slab + (((int64_t)blockIdx.z * a.Co + co) * a.Ci + ci) * KK;
 #pragma unroll
@@ -309,8 +365,10 @@ bool wgrad_tn_ok(int dt, int H, int W, int Ci, int Co, int k, int stride, int up
   return (H * W) % PT == 0 && PT % 32 == 0 && PT % W == 0;
 }
 int wgrad_tn_splits(int B, int H, int W, int Ci, int Co) {
-  const int tiles = cdiv(Ci, 64) * cdiv(Co, 64), PT = std::min(128, H * W), ntiles = B * (H * W / PT);
-  return std::max(1, std::min(std::min(cdiv(1024, tiles), ntiles), 64));
+  const int tiles = cdiv(Ci, 64) * cdiv(Co, 128), PT = std::min(128, H * W), ntiles = B * (H * W / PT);
+  // one workgroup per CU (132 KiB of LDS): fill the 256 CUs once, keep the fp32 slabs (S x |dW|) small
+  static const int target = getenv("DDMI_WGRAD_TN_WGS") ? atoi(getenv("DDMI_WGRAD_TN_WGS")) : 256;
+  return std::max(1, std::min(std::min(target / tiles, ntiles), 64));
 }
 // slab: wgrad_tn_splits(...) * Co * Ci * k*k floats
 int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s) {
@@ -320,11 +378,17 @@ int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B
   a.S = wgrad_tn_splits(B, H, W, Ci, Co);
   a.TR = std::min(128, H * W) / W;
   a.wshift = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
-  dim3 g((unsigned)cdiv(Ci, 64), (unsigned)cdiv(Co, 64), (unsigned)a.S);
+  dim3 g((unsigned)cdiv(Ci, 64), (unsigned)cdiv(Co, 128), (unsigned)a.S);
   const int kk = k * k;
   PROF_SCOPE("wgrad_tn", 2.0 * B * H * W * (double)Co * Ci * kk, ((double)B * H * W * (Co + Ci)) * 2.0, s);
-  if (k == 3) hipLaunchKernelGGL(wgrad_tn_kernel<9>, g, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL(wgrad_tn_kernel<1>, g, dim3(512), 0, s, a);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
+    attr_done = true;
+  }
+  if (k == 3) hipLaunchKernelGGL(wgrad_tn_kernel<9>, g, dim3(512), 2 * WG_STAGE, s, a);
+  else hipLaunchKernelGGL(wgrad_tn_kernel<1>, g, dim3(512), 2 * WG_STAGE, s, a);
   const int64_t n = (int64_t)Co * Ci * kk;
   hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S);
   HIP_TRY(hipGetLastError());
@@ -347,6 +411,28 @@ __global__ void __launch_bounds__(256) sum_hw_kernel(const T* __restrict__ dy, f
   if (lane == 0 && c < C)
     part[((int64_t)z * gridDim.y + b) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
+// bf16, C % 8 == 0: 16-byte loads - block 256 = 8 channel chunks (64 channels) x 32 pixel lanes, same grid and slices
+__global__ void __launch_bounds__(256) sum_hw_bf16x8_kernel(const bf16_t* __restrict__ dy, float* __restrict__ part, int HW, int C, int S) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.y, ch = threadIdx.x & 7, lane = threadIdx.x >> 3, z = blockIdx.z;
+  const int c = blockIdx.x * 64 + 8 * ch;
+  const int per = (HW + S - 1) / S, p0 = z * per, p1 = min(HW, p0 + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int p = p0 + lane; p < p1; p += 32) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + ((int64_t)b * HW + p) * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[lane][8 * ch + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+    float t = 0.f;
+    for (int l = 0; l < 32; ++l) t += red[l][threadIdx.x];   // fixed order: deterministic
+    part[((int64_t)z * gridDim.y + b) * C + blockIdx.x * 64 + threadIdx.x] = t;
+  }
+}
 __global__ void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int S) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -355,20 +441,45 @@ __global__ void sum_slices_kernel(const float* __restrict__ part, float* __restr
   out[i] = acc;
 }
 
-// out[c] = sum_b in[b][c]
-__global__ void sum_b_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float acc = 0.f;
-  for (int b = 0; b < B; ++b) acc += in[(int64_t)b * C + c];
-  out[c] = acc;
+// out[c] = sum_b in[b][c]: block 256 = 64 channels x 4 batch lanes (a lane adds every 4th row, four loads in flight), the four
+// partials are added in lane order (deterministic)
+__global__ void __launch_bounds__(256) sum_b_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int b = bl;
+    for (; b + 12 < B; b += 16) {
+      a0 += in[(int64_t)b * C + c];
+      a1 += in[(int64_t)(b + 4) * C + c];
+      a2 += in[(int64_t)(b + 8) * C + c];
+      a3 += in[(int64_t)(b + 12) * C + c];
+    }
+    for (; b < B; b += 4) a0 += in[(int64_t)b * C + c];
+  }
+  red[bl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (bl == 0 && c < C) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
-
 
 int launch_pack_dgrad_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s) {
   const int64_t n = (int64_t)Co * Ci * k * k;
-  if (dt == DT_F32) hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, w, (float*)out, Co, Ci, k);
+  if (k == 1 || k == 3) {
+    const int TCI = k == 1 ? 64 : 8;
+    dim3 g((unsigned)cdiv(Ci, TCI), (unsigned)cdiv(Co, 128));
+    if (dt == DT_F32) hipLaunchKernelGGL(pack_dgrad_weight_tiled_kernel<float>, g, dim3(256), 0, s, w, (float*)out, Co, Ci, k, TCI);
+    else hipLaunchKernelGGL(pack_dgrad_weight_tiled_kernel<bf16_t>, g, dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, k, TCI);
+  } else if (dt == DT_F32) hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, w, (float*)out, Co, Ci, k);
   else hipLaunchKernelGGL(pack_dgrad_weight_kernel<bf16_t>, dim3(tr_blocks(n)), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, k);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+// the training step's forward pack: same result as launch_pack_conv_weight (k_elementwise.hip), LDS-tiled
+int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s) {
+  if (k * k > 9) return launch_pack_conv_weight(w, out, dt, Co, Ci, k, k, s);
+  dim3 g((unsigned)cdiv(Ci, 256), (unsigned)Co);
+  if (dt == DT_F32) hipLaunchKernelGGL(pack_fwd_weight_tiled_kernel<float>, g, dim3(256), 0, s, w, (float*)out, Co, Ci, k * k);
+  else hipLaunchKernelGGL(pack_fwd_weight_tiled_kernel<bf16_t>, g, dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, k * k);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -421,13 +532,14 @@ int launch_sum_hw(const void* dy, float* out, float* part, int dt, int B, int HW
   PROF_SCOPE("bias_emb_grad", 0, (double)B * HW * C * dt_size(dt), s);
   float* dst = S == 1 ? out : part;
   if (dt == DT_F32) hipLaunchKernelGGL(sum_hw_kernel<float>, g, dim3(256), 0, s, (const float*)dy, dst, HW, C, S);
+  else if (C % 8 == 0) hipLaunchKernelGGL(sum_hw_bf16x8_kernel, g, dim3(256), 0, s, (const bf16_t*)dy, dst, HW, C, S);
   else hipLaunchKernelGGL(sum_hw_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)dy, dst, HW, C, S);
   if (S > 1) hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)cdiv64((int64_t)B * C, 256)), dim3(256), 0, s, part, out, (int64_t)B * C, S);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
 int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s) {
-  hipLaunchKernelGGL(sum_b_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, in, out, B, C);
+  hipLaunchKernelGGL(sum_b_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, in, out, B, C);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -1001,6 +1113,77 @@ int launch_linear_small_backward(const float* x, const float* W, const float* dy
                                  int silu_in, hipStream_t s) {
   if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(K, 128), B), dim3(128), 0, s, x, W, dy, dx, B, K, N, silu_in);
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(K, 128), N), dim3(128), 0, s, x, dy, dW, db, B, K, N, silu_in);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 GEMM of the time-embedding path, any operand orientation:  C[m][n] = bias[n] + sum_r A[m sam + r sar] B[r sbr + n sbn]
+// (forward: A = act, B = W^T; input gradient: A = dy, B = W; weight gradient: A = dy^T, B = act).  64 x 64 tile, 16-deep
+// chunks through LDS, 256 threads x 4 x 4 outputs, plain fp32 FMAs in r order (the parity path's arithmetic).  grid.z = S
+// slices of the reduction axis write S partial matrices (summed in slice order by sum_slices_kernel) - the input gradient of
+// the batched embedding projection reduces over ~12k rows into a 64 x 896 result.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sgemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sar, const float* __restrict__ Bm,
+                                                    int64_t sbr, int64_t sbn, float* __restrict__ C, const float* __restrict__ bias, int M,
+                                                    int N, int R, int rper) {
+  __shared__ float As[16][68], Bs[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int r_begin = blockIdx.z * rper, r_end = min(R, r_begin + rper);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const bool a_rfast = sar == 1, b_nfast = sbn == 1;
+  for (int r0 = r_begin; r0 < r_end; r0 += 16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      const int ar = a_rfast ? (idx & 15) : (idx >> 6), am = a_rfast ? (idx >> 4) : (idx & 63);
+      As[ar][am] = (m0 + am < M && r0 + ar < r_end) ? A[(int64_t)(m0 + am) * sam + (int64_t)(r0 + ar) * sar] : 0.f;
+      const int br = b_nfast ? (idx >> 6) : (idx & 15), bn = b_nfast ? (idx & 63) : (idx >> 4);
+      Bs[br][bn] = (n0 + bn < N && r0 + br < r_end) ? Bm[(int64_t)(r0 + br) * sbr + (int64_t)(n0 + bn) * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 av = *reinterpret_cast<const float4*>(&As[r][4 * ty]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Bs[r][4 * tx]);
+      const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], b4[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float* Cz = C + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * ty + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tx + j;
+      if (n < N) Cz[(int64_t)m * N + n] = acc[i][j] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
+    }
+  }
+}
+int sgemm_splits(int M, int N, int R) {
+  const int tiles = cdiv(M, 64) * cdiv(N, 64);
+  return std::max(1, std::min(std::min(256 / std::max(1, tiles), R / 64), 64));
+}
+// slab: sgemm_splits(M, N, R) * M * N floats when that is > 1 (else unused)
+int launch_sgemm(const float* A, int64_t sam, int64_t sar, const float* Bm, int64_t sbr, int64_t sbn, float* C, const float* bias, int M, int N,
+                 int R, float* slab, hipStream_t s) {
+  const int S = sgemm_splits(M, N, R);
+  const int rper = cdiv(cdiv(R, S), 16) * 16;
+  PROF_SCOPE("sgemm_f32", 2.0 * M * (double)N * R, 4.0 * ((double)M * R + (double)R * N + (double)M * N), s);
+  hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)S), dim3(256), 0, s, A, sam, sar, Bm, sbr, sbn,
+                     S > 1 ? slab : C, bias, M, N, R, rper);
+  if (S > 1) hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)cdiv64((int64_t)M * N, 256)), dim3(256), 0, s, slab, C, (int64_t)M * N, S);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

@@ -204,3 +204,8 @@ int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s
 bool wgrad_tn_ok(int dt, int H, int W, int Ci, int Co, int k, int stride, int ups);
 int wgrad_tn_splits(int B, int H, int W, int Ci, int Co);
 int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s);
+int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s);
+// fp32 GEMM with strided operands: C[m][n] = bias[n] + sum_r A[m sam + r sar] B[r sbr + n sbn]; slab = sgemm_splits * M * N floats
+int sgemm_splits(int M, int N, int R);
+int launch_sgemm(const float* A, int64_t sam, int64_t sar, const float* Bm, int64_t sbr, int64_t sbn, float* C, const float* bias, int M, int N,
+                 int R, float* slab, hipStream_t s);

@@ -11,6 +11,8 @@ struct ddmi_train {
   int dt = DT_F32;
   unsigned char* ws = nullptr;
   size_t ws_bytes = 0;
+  float* freq = nullptr;   // sinusoidal-embedding frequency table of the last `dim` asked for (device, lives with the handle)
+  int freq_dim = 0;
 };
 
 namespace {
@@ -52,6 +54,7 @@ int ddmi_train_create(int numerics, ddmi_train** out) {
 int ddmi_train_destroy(ddmi_train* h) {
   if (h) {
     if (h->ws) (void)hipFree(h->ws);
+    if (h->freq) (void)hipFree(h->freq);
     delete h;
   }
   return DDMI_OK;
@@ -116,7 +119,7 @@ int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const floa
   DDMI_TRY(reserve(h, wbytes + sk, s));
   Carve c{h};
   void* wp = c.take(wbytes);
-  DDMI_TRY(launch_pack_conv_weight(w, wp, dt, Cout, Cin, k, k, s));
+  DDMI_TRY(launch_pack_fwd_weight(w, wp, dt, Cout, Cin, k, s));
   a.w = wp;
   if (a.splitk > 1) a.splitk_ws = (float*)c.take(sk);
   return launch_conv(a, dt, s);
@@ -264,10 +267,32 @@ int ddmi_train_linear_bwd(ddmi_train* h, const float* x, const float* W, const f
   return launch_linear_small_backward(x, W, dy, dx, dW, db, B, K, N, silu_in, (hipStream_t)stream);
 }
 
+int ddmi_train_matmul(ddmi_train* h, const float* A, int64_t sam, int64_t sar, const float* Bm, int64_t sbr, int64_t sbn, float* C,
+                      const float* bias, int M, int N, int R, void* stream) {
+  DDMI_REQUIRE(h && A && Bm && C && M > 0 && N > 0 && R > 0, "train_matmul: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int S = sgemm_splits(M, N, R);
+  float* slab = nullptr;
+  if (S > 1) {
+    DDMI_TRY(reserve(h, (size_t)S * M * N * sizeof(float), s));
+    slab = (float*)h->ws;
+  }
+  return launch_sgemm(A, sam, sar, Bm, sbr, sbn, C, bias, M, N, R, slab, s);
+}
+
 int ddmi_train_timestep_embedding(ddmi_train* h, const int64_t* t, float* out, int B, int dim, void* stream) {
   DDMI_REQUIRE(h && t && out && dim % 2 == 0, "train_timestep_embedding: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int half = dim / 2;
+  // the table is built once per handle and dimension: no copy, no host synchronisation in the steady state (a per-step sync
+  // here would serialise the host's launch queue with the device, and is not capturable in a hipGraph)
+  if (h->freq && h->freq_dim == dim) return launch_timestep_embedding(t, h->freq, out, B, dim, s);
+  if (h->freq) {
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(h->freq);
+    h->freq = nullptr;
+    h->freq_dim = 0;
+  }
   std::vector<float> fr(half);
   const float neg_log = (float)(-std::log(10000.0));
   for (int i = 0; i < half; ++i) {   // fp32 product, then fp32 division, as torch evaluates util.py:161-163
@@ -275,10 +300,10 @@ int ddmi_train_timestep_embedding(ddmi_train* h, const int64_t* t, float* out, i
     volatile float q = a / (float)half;
     fr[i] = std::exp((float)q);
   }
-  DDMI_TRY(reserve(h, half * sizeof(float), s));
-  HIP_TRY(hipMemcpyAsync(h->ws, fr.data(), half * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));   // `fr` leaves scope; tiny, once per step
-  return launch_timestep_embedding(t, (const float*)h->ws, out, B, dim, s);
+  HIP_TRY(hipMalloc((void**)&h->freq, half * sizeof(float)));
+  HIP_TRY(hipMemcpy(h->freq, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  h->freq_dim = dim;
+  return launch_timestep_embedding(t, h->freq, out, B, dim, s);
 }
 
 int ddmi_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* x_t, int B,

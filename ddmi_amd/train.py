@@ -19,6 +19,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from .ddpm import make_beta_schedule
@@ -101,9 +102,10 @@ class ConvFn(torch.autograd.Function):
         hin, win, pad = (2 * H if ups else H), (2 * W if ups else W), k // 2
         Ho, Wo = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
         y = torch.empty((B, Ho, Wo, Cout), dtype=tc.dtype, device=x.device)
-        emb_c = emb.contiguous() if emb is not None else None
+        # emb [B, Cout] fp32, rows may be pitched (a column block of the batched embedding projection, EmbSliceFn)
+        emb_c = (emb if emb.stride(1) == 1 else emb.contiguous()) if emb is not None else None
         res_c = res.contiguous() if res is not None else None
-        _lib.check(_lib.lib().ddmi_train_conv_fwd(tc.h, x.data_ptr(), w.data_ptr(), _p(bias), _p(emb_c), Cout if emb_c is not None else 0,
+        _lib.check(_lib.lib().ddmi_train_conv_fwd(tc.h, x.data_ptr(), w.data_ptr(), _p(bias), _p(emb_c), emb_c.stride(0) if emb_c is not None else 0,
                                                   _p(res_c), y.data_ptr(), B, H, W, Cin, Cout, k, stride, int(ups), _stream()))
         ctx.save_for_backward(x, w)
         ctx.tc, ctx.meta = tc, (B, H, W, Cin, Cout, k, stride, int(ups), bias is not None, emb is not None, res is not None)
@@ -173,18 +175,30 @@ class AttentionLegacyFn(torch.autograd.Function):
         return None, dqkv, None
 
 
+def _matmul(tc, A, sam, sar, Bm, sbr, sbn, M, N, R, bias=None):
+    """C[m][n] = bias[n] + sum_r A[m sam + r sar] Bm[r sbr + n sbn] on fp32 device tensors (ddmi_train_matmul)."""
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _lib.check(_lib.lib().ddmi_train_matmul(tc.h, A.data_ptr(), sam, sar, Bm.data_ptr(), sbr, sbn, out.data_ptr(), _p(bias), M, N, R, _stream()))
+    return out
+
+
+def _silu_grad(x):
+    sg = torch.sigmoid(x)
+    return sg * (1.0 + x * (1.0 - sg))
+
+
 class LinearFn(torch.autograd.Function):
-    """y = act(x) W^T + b on fp32 [B,K]; act = SiLU when silu_in (time_embed, ResBlock.emb_layers)."""
+    """y = act(x) W^T + b on fp32 [B,K]; act = SiLU when silu_in (time_embed; the ResBlock emb_layers run batched, EmbProjFn)."""
 
     @staticmethod
     def forward(ctx, tc, x, W, b, silu_in):
         x = x.contiguous()
         B, K = x.shape
         N = W.shape[0]
-        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().ddmi_train_linear_fwd(tc.h, x.data_ptr(), W.data_ptr(), _p(b), y.data_ptr(), B, K, N, int(silu_in), _stream()))
+        xa = F.silu(x) if silu_in else x
+        y = _matmul(tc, xa, K, 1, W, 1, K, B, N, K, b)                      # A = act(x) [B,K], B(r = k, n) = W[n][k]
         ctx.save_for_backward(x, W)
-        ctx.tc, ctx.silu_in, ctx.has_b = tc, int(silu_in), b is not None
+        ctx.tc, ctx.silu_in, ctx.has_b = tc, bool(silu_in), b is not None
         return y
 
     @staticmethod
@@ -193,12 +207,70 @@ class LinearFn(torch.autograd.Function):
         B, K = x.shape
         N = W.shape[0]
         dy = dy.contiguous()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        dW = torch.empty_like(W)
-        db = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.has_b else None
-        _lib.check(_lib.lib().ddmi_train_linear_bwd(ctx.tc.h, x.data_ptr(), W.data_ptr(), dy.data_ptr(), _p(dx), dW.data_ptr(), _p(db), B, K, N,
-                                                    ctx.silu_in, _stream()))
+        xa = F.silu(x) if ctx.silu_in else x
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = _matmul(ctx.tc, dy, N, 1, W, K, 1, B, K, N)                  # A = dy [B,N], B(r = n, k) = W[n][k]
+            if ctx.silu_in:
+                dx = dx * _silu_grad(x)
+        dW = _matmul(ctx.tc, dy, 1, N, xa, K, 1, N, K, B)                      # A(m = n, r = b) = dy[b][n], B(r = b, k) = act(x)[b][k]
+        db = dy.sum(0) if ctx.has_b else None
         return None, dx, dW, db, None
+
+
+class EmbProjFn(torch.autograd.Function):
+    """Every ResBlock's `emb_layers` (SiLU -> Linear(E, cout), openaimodel.py:207-213) of one UNet evaluation as ONE projection:
+    the 22 weight matrices are stacked to [sum cout, E], SiLU(emb) is taken once, and the blocks read their columns of the
+    [B, sum cout] result in place (the conv epilogue takes a row pitch).  Three GEMMs per step instead of 66 small launches whose
+    latency, not arithmetic, filled 10 ms of a B = 64 step."""
+
+    @staticmethod
+    def forward(ctx, tc, emb, n_blocks, *wb):
+        ws, bs = wb[:n_blocks], wb[n_blocks:]
+        emb = emb.contiguous()
+        B, E = emb.shape
+        Wall, ball = torch.cat(ws, 0), torch.cat(bs, 0)
+        total = Wall.shape[0]
+        semb = F.silu(emb)
+        y = _matmul(tc, semb, E, 1, Wall, 1, E, B, total, E, ball)
+        ctx.save_for_backward(emb, Wall)
+        ctx.tc, ctx.sizes = tc, [int(w.shape[0]) for w in ws]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        emb, Wall = ctx.saved_tensors
+        B, E = emb.shape
+        total = Wall.shape[0]
+        dy = dy.contiguous()
+        semb = F.silu(emb)
+        demb = _matmul(ctx.tc, dy, total, 1, Wall, E, 1, B, E, total) * _silu_grad(emb) if ctx.needs_input_grad[1] else None
+        dW = _matmul(ctx.tc, dy, 1, total, semb, E, 1, total, E, B)
+        db = dy.sum(0)
+        return (None, demb, None) + tuple(dW.split(ctx.sizes, 0)) + tuple(db.split(ctx.sizes, 0))
+
+
+class EmbSliceFn(torch.autograd.Function):
+    """Column block [a, b) of the batched projection as a (row-pitched) view; the gradient of all blocks gathers in ONE
+    [B, total] buffer shared through `bucket` instead of 22 zero-padded full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, y_all, a, b, bucket):
+        ctx.a, ctx.b, ctx.bucket, ctx.shape = a, b, bucket, y_all.shape
+        return y_all[:, a:b]
+
+    @staticmethod
+    def backward(ctx, g):
+        bk = ctx.bucket
+        if bk.get("buf") is None:
+            bk["buf"] = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+            bk["pending"] = bk["n"]
+        bk["buf"][:, ctx.a:ctx.b] = g
+        bk["pending"] -= 1
+        if bk["pending"] == 0:       # the last block to report hands the full gradient on; the others contribute nothing more
+            out, bk["buf"] = bk["buf"], None
+            return out, None, None, None
+        return None, None, None, None
 
 
 class EpsLossFn(torch.autograd.Function):
@@ -273,8 +345,9 @@ class ResBlock(nn.Module):
         self.skip_connection = _Conv(cin, cout, 1) if cin != cout else nn.Identity()
 
     def run(self, tc, x, emb):
+        """`emb` is this block's emb_layers OUTPUT [B, cout]: TrainUNetModel.forward projects all blocks at once (EmbProjFn)."""
         h = self.in_layers[0].run(tc, x, silu=True)
-        h = self.in_layers[2].run(tc, h, emb=self.emb_layers[1].run(tc, emb, silu_in=True))   # h + emb_out[..., None, None]
+        h = self.in_layers[2].run(tc, h, emb=emb)                                                # h + emb_out[..., None, None]
         h = self.out_layers[0].run(tc, h, silu=True)
         skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection.run(tc, x)
         return self.out_layers[3].run(tc, h, res=skip)                                          # skip_connection(x) + h
@@ -326,6 +399,7 @@ class TrainUNetModel(nn.Module):
         mc, E = model_channels, 4 * model_channels
         self.model_channels, self.in_channels, self.out_channels = mc, in_channels, out_channels
         self._numerics, self._device, self._tc = numerics, device, None   # the native handle is created on first use
+        self._rb = None
         self.time_embed = _seq(_Linear(mc, E), None, _Linear(E, E))
         self.input_blocks = nn.ModuleList([nn.Sequential(_Conv(in_channels, mc, 3))])
         chans, ch, ds = [mc], mc, 1
@@ -365,10 +439,31 @@ class TrainUNetModel(nn.Module):
         return self._tc
 
     @staticmethod
-    def _run_block(tc, block, h, emb):
+    def _run_block(tc, block, h, embs):
         for layer in block:
-            h = layer.run(tc, h, emb) if not isinstance(layer, _Conv) else layer.run(tc, h)
+            if isinstance(layer, ResBlock):
+                h = layer.run(tc, h, embs[id(layer)])
+            else:
+                h = layer.run(tc, h, None) if not isinstance(layer, _Conv) else layer.run(tc, h)
         return h
+
+    def _resblocks(self):
+        if self._rb is None:
+            blocks = list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
+            self._rb = [layer for blk in blocks for layer in blk if isinstance(layer, ResBlock)]
+        return self._rb
+
+    def _project_embeddings(self, tc, emb):
+        """emb_layers of every ResBlock in one GEMM (EmbProjFn); returns {id(block): [B, cout] column view}."""
+        rbs = self._resblocks()
+        lin = [rb.emb_layers[1] for rb in rbs]
+        y_all = EmbProjFn.apply(tc, emb, len(rbs), *[m.weight for m in lin], *[m.bias for m in lin])
+        bucket, out, a = {"n": len(rbs), "buf": None}, {}, 0
+        for rb, m in zip(rbs, lin):
+            n = m.weight.shape[0]
+            out[id(rb)] = EmbSliceFn.apply(y_all, a, a + n, bucket)
+            a += n
+        return out
 
     def forward(self, x, timesteps, context=None, **kw):
         """x [B,C,H,W] fp32, timesteps [B] int64 -> eps [B,C,H,W] fp32 (openaimodel.py:761-793)."""
@@ -378,15 +473,16 @@ class TrainUNetModel(nn.Module):
         t64 = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
         _lib.check(_lib.lib().ddmi_train_timestep_embedding(tc.h, t64.data_ptr(), temb.data_ptr(), B, self.model_channels, _stream()))
         emb = self.time_embed[2].run(tc, self.time_embed[0].run(tc, temb, silu_in=False), silu_in=True)
+        embs = self._project_embeddings(tc, emb)
         h = ToNHWC.apply(tc, x)
         hs = []
         for block in self.input_blocks:
-            h = self._run_block(tc, block, h, emb)
+            h = self._run_block(tc, block, h, embs)
             hs.append(h)
-        h = self._run_block(tc, self.middle_block, h, emb)
+        h = self._run_block(tc, self.middle_block, h, embs)
         for block in self.output_blocks:
             h = torch.cat([h, hs.pop()], dim=-1)        # th.cat([h, hs.pop()], dim=1) in NHWC
-            h = self._run_block(tc, block, h, emb)
+            h = self._run_block(tc, block, h, embs)
         h = self.out[2].run(tc, self.out[0].run(tc, h, silu=True))
         return ToNCHW.apply(tc, h)
 
@@ -442,7 +538,7 @@ class LDMTrainStep:
     1 / (world_size * gradient_accumulate_every) inside the fused AdamW kernel."""
 
     def __init__(self, unetconfig, ddpmconfig, numerics="bf16", lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
-                 gradient_accumulate_every=1, ema_decay=0.9999, ema_update_every=10, device="cuda:0"):
+                 gradient_accumulate_every=1, ema_decay=0.9999, ema_update_every=10, device="cuda:0", use_graph=False):
         cfg = dict(ddpmconfig)
         self.device = torch.device(device)
         self.model = TrainUNetModel(**dict(unetconfig), numerics=numerics, device=device)
@@ -463,6 +559,8 @@ class LDMTrainStep:
         self.ema: Optional[torch.Tensor] = None
         self.opt_step = 0
         self.micro = 0
+        self.use_graph = bool(use_graph)     # replay the micro-step as a hipGraph (see _graphed_micro)
+        self._graphs: Dict[tuple, object] = {}
 
     # ---- parameters ----------------------------------------------------------------------------------------------------
     def named_parameters(self):
@@ -494,6 +592,43 @@ class LDMTrainStep:
         return self
 
     # ---- one micro-step -------------------------------------------------------------------------------------------------
+    def _micro_body(self, z0, t, noise):
+        """q_sample -> UNet -> mixed-prediction MSE -> backward, every launch on the current stream, no host synchronisation
+        (so that the whole body can also be recorded once in a hipGraph and replayed)."""
+        B = z0.shape[0]
+        a, s = self.sqrt_ac[t].contiguous(), self.sqrt_1mac[t].contiguous()
+        x_t = torch.empty_like(z0)
+        _lib.check(_lib.lib().ddmi_train_q_sample(z0.data_ptr(), noise.data_ptr(), a.data_ptr(), s.data_ptr(), x_t.data_ptr(), B,
+                                                  z0[0].numel(), _stream()))
+        model_out = self.model(x_t, t)
+        loss = EpsLossFn.apply(self.model.tc, model_out, x_t, noise, s, self.mixing_logit)
+        loss.backward()
+        return loss.detach()
+
+    def _graphed_micro(self, z0, t, noise):
+        """The micro-step as a hipGraph replay.  ~3000 launches per step leave the host (Python tape + ctypes) as the slower
+        side below B = 64 per GPU; a replay costs one launch.  The first call for a batch shape runs eagerly (lazy plans, scratch
+        growth, kernel attributes: none of that is legal inside a capture); the second records the body on static input
+        buffers - the gradients already land in the static flat slab - and replays it; later calls copy the inputs and replay."""
+        key = tuple(z0.shape)
+        g = self._graphs.get(key)
+        if g is None:
+            self._graphs[key] = "warm"
+            return self._micro_body(z0, t, noise)
+        if g == "warm":
+            bufs = (torch.empty_like(z0), torch.empty_like(t), torch.empty_like(noise))
+            for dst, src in zip(bufs, (z0, t, noise)):
+                dst.copy_(src)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self._micro_body(*bufs)
+            g = self._graphs[key] = (graph, bufs, loss)
+        else:
+            for dst, src in zip(g[1], (z0, t, noise)):
+                dst.copy_(src)
+        g[0].replay()
+        return g[2].clone()
+
     def loss_and_backward(self, z0, t=None, noise=None):
         """p_losses on a latent batch z0 [B,C,H,W] fp32 and the backward pass; gradients ACCUMULATE in the flat slab."""
         if self.flat is None:
@@ -506,15 +641,9 @@ class LDMTrainStep:
         if noise is None:
             noise = torch.randn_like(z0)                                                 # ddpm.py:410
         noise = noise.to(self.device, torch.float32).contiguous()
-        a, s = self.sqrt_ac[t].contiguous(), self.sqrt_1mac[t].contiguous()
-        x_t = torch.empty_like(z0)
-        _lib.check(_lib.lib().ddmi_train_q_sample(z0.data_ptr(), noise.data_ptr(), a.data_ptr(), s.data_ptr(), x_t.data_ptr(), B,
-                                                  z0[0].numel(), _stream()))
-        model_out = self.model(x_t, t)
-        loss = EpsLossFn.apply(self.model.tc, model_out, x_t, noise, s, self.mixing_logit)
-        loss.backward()
+        loss = self._graphed_micro(z0, t, noise) if self.use_graph else self._micro_body(z0, t, noise)
         self.micro += 1
-        return loss.detach()
+        return loss
 
     def optimizer_step(self, world_size: int = 1):
         """All-reduce (sum) of the gradient slab over the ranks, fused AdamW, EMA every `ema_update_every` steps."""

@@ -352,6 +352,10 @@ int ddmi_train_linear_fwd(ddmi_train* h, const float* x, const float* W, const f
                           void* stream);
 int ddmi_train_linear_bwd(ddmi_train* h, const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K,
                           int N, int silu_in, void* stream);
+/* fp32 GEMM with strided operands, C[m][n] = bias[n] + sum_r A[m*sam + r*sar] * B[r*sbr + n*sbn] (bias may be NULL): the batched
+ * ResBlock.emb_layers projection of a training step (forward, input gradient, weight gradient are three orientations of it) */
+int ddmi_train_matmul(ddmi_train* h, const float* A, int64_t sam, int64_t sar, const float* B, int64_t sbr, int64_t sbn, float* C,
+                      const float* bias, int M, int N, int R, void* stream);
 int ddmi_train_timestep_embedding(ddmi_train* h, const int64_t* t, float* out, int B, int dim, void* stream);   /* util.py:150-170 */
 /* q_sample ddpm.py:383-386 with per-sample coefficients sqrt(abar_t), sqrt(1 - abar_t) [B] */
 int ddmi_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* x_t, int B,

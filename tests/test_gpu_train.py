@@ -236,6 +236,27 @@ def test_training_step_bf16_tracks_the_fixture(golden):
     assert l1 < l0
 
 
+@pytest.mark.parametrize("numerics", ["fp32", "bf16"])
+def test_graph_replay_equals_eager_steps(golden, numerics):
+    """LDMTrainStep(use_graph=True) - first step eager, second captured into a hipGraph, later ones replayed - walks through the
+    same states as the eager trainer, bit for bit (same kernels, same order, same static gradient slab)."""
+    t1 = golden.npz("T1_train_step.npz")
+    runs = []
+    for use_graph in (False, True):
+        tr = _toy_trainer(golden, numerics)
+        tr.use_graph = use_graph
+        losses = []
+        for step in range(5):
+            x0, nz = g("T1g", f"x{step}", (2, 64, 8, 8)), g("T1g", f"n{step}", (2, 64, 8, 8))
+            t = (torch.from_numpy(t1["t"]) + 37 * step) % 1000
+            losses.append(float(tr.train_step(x0, t, nz)))
+        runs.append((losses, tr.flat.data.clone(), tr.flat.exp_avg_sq.clone()))
+        if use_graph:
+            assert isinstance(tr._graphs[(2, 64, 8, 8)], tuple)      # a graph was really captured and replayed
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
 def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path):
     """A few steps -> LDMTrainStep.save (the dict LDMTrainer.save writes, tools/ldm/image.py:104-119) -> ImagePipeline.load_checkpoint:
     the inference UNet on the saved online weights equals the training-path forward, the EMA copy is what use_ema picks."""
