@@ -350,6 +350,86 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
   }
 }
 
+// The 1x1 convolutions (attention qkv / proj_out, ResBlock skip connections): dW[co][ci] = sum_p dY[p][co] X[p][ci] over the flat
+// pixel list - the same machinery without a halo, but with ONE tap the 64 x 16 wave tile above would fetch ten fragments for
+// four MFMAs.  Here a wave owns 128 co x 64 ci (32 accumulator fragments, 12 fragment fetches per 32 MFMAs), the workgroup
+// 256 co x 256 ci, a stage is 64 pixels of both operands (4 + 4 panels of [64 px][64 ch], 64 KiB), two stages.
+#define WG1_PANEL (64 * 128)            // bytes of one [64 px][64 ch] panel
+#define WG1_STAGE (8 * WG1_PANEL)       // 4 dY panels + 4 X panels
+__global__ void __launch_bounds__(512) wgrad_tn1_kernel(WgradTnK a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char wg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 3, hf = wave >> 2;
+  const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, p4 = lr & 3;
+  const int ci0 = blockIdx.x * 256, co0 = blockIdx.y * 256;
+  const int ntiles = a.B;                         // a.B = number of 64-pixel tiles of the flat pixel list here
+  const int per = (ntiles + a.S - 1) / a.S, t_begin = blockIdx.z * per, t_end = min(ntiles, t_begin + per);
+  const int drow = (lane >> 1) & 7, dchunk = 2 * (lane >> 4) + (lane & 1);
+  unsigned yoff[4], xoff[4];                       // instruction gi = wave + 8 j: panel gi >> 3, rows 8 (gi & 7) ..
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gi = wave + 8 * j, panel = gi >> 3, r = 8 * (gi & 7) + drow;
+    const int co = co0 + 64 * panel + 8 * dchunk, ci = ci0 + 64 * panel + 8 * dchunk;
+    yoff[j] = co < a.Co ? (unsigned)((r * a.Co + co) * 2) : WG_OOB;
+    xoff[j] = ci < a.Ci ? (unsigned)((r * a.Ci + ci) * 2) : WG_OOB;
+  }
+  auto issue = [&](int t, int stage) {
+    unsigned char* base = wg_smem + stage * WG1_STAGE;
+    auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)t * 64 * a.Co), 0, (unsigned)(64 * a.Co * 2), 0x00020000);
+    auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)t * 64 * a.Ci), 0, (unsigned)(64 * a.Ci * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gi = wave + 8 * j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (wg_lds_void*)(base + gi * 1024), 16, yoff[j], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (wg_lds_void*)(base + 4 * WG1_PANEL + gi * 1024), 16, xoff[j], 0, 0, 0);
+    }
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[f][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (t_begin < t_end) issue(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int stage = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) issue(t + 1, stage ^ 1);
+    const unsigned char* Y = wg_smem + stage * WG1_STAGE + 2 * hf * WG1_PANEL + 8 * p4;
+    const unsigned char* X = wg_smem + stage * WG1_STAGE + (4 + wi) * WG1_PANEL + 8 * p4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int o0 = wg_row(ks * 32 + 4 * lg + q), o1 = wg_row(ks * 32 + 16 + 4 * lg + q);
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bfr[u] = wg_tr_frag(X + o0 + 256 * u, X + o1 + 256 * u);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int fo = (f >> 2) * WG1_PANEL + 256 * (f & 3);
+        const bf16x8 af = wg_tr_frag(Y + o0 + fo, Y + o1 + fo);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[f][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[u], acc[f][u], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage ^= 1;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ci = ci0 + 64 * wi + 16 * u + lr;
+    if (ci >= a.Ci) continue;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + 128 * hf + 16 * f + 4 * lg + e;
+        if (co < a.Co) a.slab[((int64_t)blockIdx.z * a.Co + co) * a.Ci + ci] = acc[f][u][e];
+      }
+  }
+}
+
 __global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n, int S) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
@@ -358,16 +438,21 @@ __global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __
   }
 }
 
-bool wgrad_tn_ok(int dt, int H, int W, int Ci, int Co, int k, int stride, int ups) {
-  if (dt != DT_BF16 || stride != 1 || ups || !(k == 1 || k == 3)) return false;
-  if (!(W == 8 || W == 16 || W == 32 || W == 64) || Ci % 8 || Co % 8) return false;
+bool wgrad_tn_ok(int dt, int B, int H, int W, int Ci, int Co, int k, int stride, int ups) {
+  if (dt != DT_BF16 || stride != 1 || ups || !(k == 1 || k == 3) || Ci % 8 || Co % 8) return false;
+  if (k == 1) return ((int64_t)B * H * W) % 64 == 0;          // flat pixel list in 64-pixel tiles
+  if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
   const int PT = std::min(128, H * W);
   return (H * W) % PT == 0 && PT % 32 == 0 && PT % W == 0;
 }
-int wgrad_tn_splits(int B, int H, int W, int Ci, int Co) {
-  const int tiles = cdiv(Ci, 64) * cdiv(Co, 128), PT = std::min(128, H * W), ntiles = B * (H * W / PT);
-  // one workgroup per CU (132 KiB of LDS): fill the 256 CUs once, keep the fp32 slabs (S x |dW|) small
+int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k) {
+  // one workgroup per CU (128+ KiB of LDS): fill the 256 CUs once, keep the fp32 slabs (S x |dW|) small
   static const int target = getenv("DDMI_WGRAD_TN_WGS") ? atoi(getenv("DDMI_WGRAD_TN_WGS")) : 256;
+  if (k == 1) {
+    const int tiles = cdiv(Ci, 256) * cdiv(Co, 256), ntiles = (int)((int64_t)B * H * W / 64);
+    return std::max(1, std::min(std::min(target / tiles, ntiles), 128));
+  }
+  const int tiles = cdiv(Ci, 64) * cdiv(Co, 128), PT = std::min(128, H * W), ntiles = B * (H * W / PT);
   return std::max(1, std::min(std::min(target / tiles, ntiles), 64));
 }
 // slab: wgrad_tn_splits(...) * Co * Ci * k*k floats
@@ -375,20 +460,25 @@ int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B
   WgradTnK a{};
   a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
   a.B = B; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci;
-  a.S = wgrad_tn_splits(B, H, W, Ci, Co);
-  a.TR = std::min(128, H * W) / W;
-  a.wshift = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
-  dim3 g((unsigned)cdiv(Ci, 64), (unsigned)cdiv(Co, 128), (unsigned)a.S);
+  a.S = wgrad_tn_splits(B, H, W, Ci, Co, k);
   const int kk = k * k;
-  PROF_SCOPE("wgrad_tn", 2.0 * B * H * W * (double)Co * Ci * kk, ((double)B * H * W * (Co + Ci)) * 2.0, s);
   static bool attr_done = false;
   if (!attr_done) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG1_STAGE));
     attr_done = true;
   }
-  if (k == 3) hipLaunchKernelGGL(wgrad_tn_kernel<9>, g, dim3(512), 2 * WG_STAGE, s, a);
-  else hipLaunchKernelGGL(wgrad_tn_kernel<1>, g, dim3(512), 2 * WG_STAGE, s, a);
+  PROF_SCOPE("wgrad_tn", 2.0 * B * H * W * (double)Co * Ci * kk, ((double)B * H * W * (Co + Ci)) * 2.0, s);
+  if (k == 3) {
+    a.TR = std::min(128, H * W) / W;
+    a.wshift = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
+    dim3 g((unsigned)cdiv(Ci, 64), (unsigned)cdiv(Co, 128), (unsigned)a.S);
+    hipLaunchKernelGGL(wgrad_tn_kernel<9>, g, dim3(512), 2 * WG_STAGE, s, a);
+  } else {
+    a.B = (int)((int64_t)B * H * W / 64);   // 64-pixel tiles of the flat pixel list
+    dim3 g((unsigned)cdiv(Ci, 256), (unsigned)cdiv(Co, 256), (unsigned)a.S);
+    hipLaunchKernelGGL(wgrad_tn1_kernel, g, dim3(512), 2 * WG1_STAGE, s, a);
+  }
   const int64_t n = (int64_t)Co * Ci * kk;
   hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S);
   HIP_TRY(hipGetLastError());

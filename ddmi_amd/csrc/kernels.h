@@ -201,8 +201,8 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float grad_scale, hipStream_t s);
 int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s);
 // wgrad as a TN implicit GEMM with transposing LDS reads (bf16, 3x3 / 1x1 stride 1, W in {8,16,32,64}); slab = splits*Co*Ci*k*k floats
-bool wgrad_tn_ok(int dt, int H, int W, int Ci, int Co, int k, int stride, int ups);
-int wgrad_tn_splits(int B, int H, int W, int Ci, int Co);
+bool wgrad_tn_ok(int dt, int B, int H, int W, int Ci, int Co, int k, int stride, int ups);
+int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k);
 int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s);
 int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s);
 // fp32 GEMM with strided operands: C[m][n] = bias[n] + sum_r A[m sam + r sar] B[r sbr + n sbn]; slab = sgemm_splits * M * N floats

@@ -165,8 +165,8 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
                              (g.splitk > 1 ? al((size_t)g.splitk * Cout * N * sizeof(float)) : 0);
   const size_t red_bytes = al((size_t)B * Cout * sizeof(float)) * (1 + (size_t)sum_hw_slices(B, Ho * Wo, Cout));
   static const bool no_tn = getenv("DDMI_WGRAD_GEMM") != nullptr;   // diagnostics: the im2col + GEMM formulation everywhere
-  const bool tn = !no_tn && wgrad_tn_ok(dt, H, W, Cin, Cout, k, stride, ups);
-  const size_t tn_bytes = tn ? al((size_t)wgrad_tn_splits(B, H, W, Cin, Cout) * Cout * Cin * kk * sizeof(float)) : 0;
+  const bool tn = !no_tn && wgrad_tn_ok(dt, B, H, W, Cin, Cout, k, stride, ups);
+  const size_t tn_bytes = tn ? al((size_t)wgrad_tn_splits(B, H, W, Cin, Cout, k) * Cout * Cin * kk * sizeof(float)) : 0;
   DDMI_TRY(reserve(h, std::max(dgrad_bytes, tn ? tn_bytes : wgrad_bytes) + red_bytes, s));
   // ---- bias / embedding gradients ---------------------------------------------------------------------------
   if (dbias || demb) {
