@@ -34,6 +34,7 @@ struct ConvK {
   void* y;
   float* y_nchw;
   float* ws;
+  float* chstat;   // optional [M / (16 FM)][Cout][2] per-channel (sum, sum of squares) of the STORED values per wave row block
   int B, Hin, Win, Cin, Hout, Wout, Cout;
   int KH, KW, stride, pad, ups;
   int emb_stride, emb_mod;
@@ -256,6 +257,18 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
     if constexpr (ODD) cb[FN - 1] += *reinterpret_cast<const f32x4*>(pe + n_odd);
   }
 
+  // GroupNorm statistics of the consumer, gathered here so that no separate pass has to read the tensor back: per channel the
+  // sum and the sum of squares of the values AS STORED (bf16-rounded) over this wave's 16 FM rows, fp32 (<= 64 terms each),
+  // written per row block; launch_gn_chstat_finish adds the blocks of a sample in fp64 in a fixed order (deterministic).
+  const bool st = a.chstat != nullptr;
+  float s1p[NPAIR > 0 ? NPAIR : 1][8], s2p[NPAIR > 0 ? NPAIR : 1][8], s1o[4], s2o[4];
+#pragma unroll
+  for (int p = 0; p < (NPAIR > 0 ? NPAIR : 1); ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1p[p][e] = s2p[p][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s1o[e] = s2o[e] = 0.f;
+
   bf16x8 rp[2][NPAIR > 0 ? NPAIR : 1];
   bf16x4 ro[2];
   auto load_res = [&](int i, int slot) {
@@ -290,6 +303,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
 #pragma unroll
       for (int e = 0; e < 8; ++e) t[e] = (bf16_t)(v[e] * a.out_scale);
       *reinterpret_cast<bf16x8*>(row + n_pair + 32 * p) = t;
+      if (st) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float q = (float)t[e];
+          s1p[p][e] += q;
+          s2p[p][e] = fmaf(q, q, s2p[p][e]);
+        }
+      }
     }
     if constexpr (ODD) {
       float v[4];
@@ -303,6 +324,52 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] = (bf16_t)(v[e] * a.out_scale);
       *reinterpret_cast<bf16x4*>(row + n_odd) = t;
+      if (st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = (float)t[e];
+          s1o[e] += q;
+          s2o[e] = fmaf(q, q, s2o[e]);
+        }
+      }
+    }
+  }
+  if (st) {   // lanes lr = 0..15 of a lane group hold the 16 rows of a fragment: butterfly over the group, lane lr = 0 writes
+    // DPP row rotations (a row = the 16 lanes of a lane group): VALU-rate, where __shfl_xor's ds_bpermute sends 1 800 requests per
+    // tile through the LDS pipe (measured: + 58 us on the 1 660 us dominant launch)
+    auto red16 = [](float v) {
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+      return v;
+    };
+    float* d = a.chstat + (int64_t)(m_base / (FM * 16)) * a.Cout * 2;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      float o[16];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[2 * e] = red16(s1p[p][e]);
+        o[2 * e + 1] = red16(s2p[p][e]);
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(d + (n_pair + 32 * p) * 2 + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+      }
+    }
+    if constexpr (ODD) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = red16(s1o[e]);
+        o[2 * e + 1] = red16(s2o[e]);
+      }
+      if (lr == 0) {
+        *reinterpret_cast<f32x4*>(d + n_odd * 2) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(d + n_odd * 2 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
     }
   }
 }
@@ -1278,6 +1345,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   ConvK k{};
   k.x = a.x; k.w = a.w; k.bias = a.bias; k.emb = a.emb; k.res = a.res; k.y = a.y; k.y_nchw = a.y_nchw;
   k.ws = splitk > 1 ? a.splitk_ws : nullptr;
+  k.chstat = nullptr;   // launch_conv sets it after checking that every wave takes the fast epilogue
   k.B = a.B; k.Hin = a.Hin; k.Win = a.Win; k.Cin = a.Cin; k.Hout = a.Hout; k.Wout = a.Wout; k.Cout = a.Cout;
   k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
   k.emb_stride = a.emb_stride; k.emb_mod = a.emb_mod;
@@ -1538,6 +1606,27 @@ static int check_conv(const ConvArgs& a, int dt) {
   return DDMI_OK;
 }
 
+// wave tile (rows, channels) of the bf16 configurations kRing[id]
+static const int kRingWave[][2] = {{32, 112}, {32, 112}, {32, 112}, {32, 112}, {64, 64}, {32, 64}, {32, 64}, {32, 32}, {64, 64}, {64, 112}, {64, 112},
+                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64}};
+static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave tile per ring configuration");
+
+// Rows per statistics block (the wave tile height) when a launch of `a` with a.chstat set would fill the WHOLE
+// [M / rows][Cout][2] buffer - every wave on conv_epilogue_fast - else 0 (the caller then runs the statistics pass).
+int conv_chstat_rows(const ConvArgs& a, int dt) {
+  static const bool off = getenv("DDMI_GN_CHSTAT") && atoi(getenv("DDMI_GN_CHSTAT")) == 0;
+  static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
+  if (off || dbg || dt != DT_BF16 || a.splitk > 1 || a.y_nchw || a.ups == 3 || !a.y) return 0;
+  const int M = conv_rows(a);
+  TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
+  if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
+  if (t.id < 0) return 0;
+  const bool paired = t.kps != -1 || a.order > 2 || (a.order == 0 && a.KH * a.KW == 1);   // ring and halo kernels always are
+  const int TM = kRingWave[t.id][0], TN = kRingWave[t.id][1], hw = a.Hout * a.Wout;
+  if (!paired || a.Cout % TN || hw % TM || M % TM) return 0;
+  return TM;
+}
+
 int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   DDMI_TRY(check_conv(a, dt));
   int splitk = std::max(1, a.splitk);
@@ -1559,6 +1648,10 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
       tm = wgt > act ? 2 : 1;
     }
     k.tile_map = tm < 0 ? 0 : tm;
+  }
+  if (a.chstat) {
+    DDMI_REQUIRE(conv_chstat_rows(a, dt) > 0, "conv: channel statistics asked of a launch that cannot provide them");
+    k.chstat = a.chstat;
   }
   DDMI_TRY(dispatch(k, t, dt, splitk, a.ups == 3 ? 4 : 1, s));
   if (splitk > 1) DDMI_TRY(launch_splitk_finish(a, dt, s));

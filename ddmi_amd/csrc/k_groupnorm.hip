@@ -175,6 +175,46 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
   }
 }
 
+static int gn_splits_of(int B, int HW);
+// Statistics from the producers' epilogues (ConvArgs::chstat): per row block of `rows` pixels, per channel (sum, sumsq) in fp32.
+// grid (nsplit, B) like gn_stats_kernel: block (sidx, b) adds its share of the sample's row blocks per channel (fp64, block
+// order), then the channels of each group, and writes split `sidx` of the layout gn_apply_kernel reads.  The input may be the
+// channel concatenation of two tensors, each with its own buffer and block height.
+__global__ void __launch_bounds__(256) gn_chstat_finish_kernel(const float* __restrict__ cs1, int rows1, const float* __restrict__ cs2, int rows2,
+                                                               int C1, int C, int HW, double* __restrict__ part) {
+  extern __shared__ double cred[];   // [2 C]: (sum, sumsq) per channel
+  const int b = blockIdx.y, sidx = blockIdx.x, ns = gridDim.x, tid = threadIdx.x;
+  for (int i = tid; i < 2 * C; i += 256) {
+    const int c = i >> 1;
+    const bool second = cs2 != nullptr && c >= C1;
+    const int ldc = cs2 == nullptr ? C : (second ? C - C1 : C1), nblk = HW / (second ? rows2 : rows1);
+    const int k0 = (int)((int64_t)sidx * nblk / ns), k1 = (int)((int64_t)(sidx + 1) * nblk / ns);
+    const float* p = (second ? cs2 : cs1) + ((int64_t)b * nblk * ldc) * 2 + (i - (second ? 2 * C1 : 0));
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) acc += (double)p[(int64_t)k * ldc * 2];
+    cred[i] = acc;
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS * 2) {
+    const int g = tid >> 1, which = tid & 1, cpg = C / GN_GROUPS;
+    double acc = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += cred[2 * c + which];
+    part[((int64_t)b * GN_MAXSPLIT + sidx) * (GN_GROUPS * 2) + tid] = acc;
+  }
+}
+
+int launch_gn_chstat_finish(const float* cs1, int rows1, const float* cs2, int rows2, int C1, double* stats, int B, int HW, int C,
+                            hipStream_t s) {
+  DDMI_REQUIRE(cs1 && rows1 > 0 && HW % rows1 == 0 && (cs2 == nullptr || (rows2 > 0 && HW % rows2 == 0 && C1 > 0 && C1 < C)),
+               "groupnorm: bad channel-statistics buffers");
+  DDMI_REQUIRE(C % GN_GROUPS == 0, "groupnorm: C must be a multiple of 32");
+  PROF_SCOPE("gn_stats", 0, 8.0 * B * C * (HW / rows1), s);
+  hipLaunchKernelGGL(gn_chstat_finish_kernel, dim3(gn_splits_of(B, HW), B), dim3(256), (size_t)2 * C * sizeof(double), s, cs1, rows1, cs2, rows2,
+                     C1, C, HW, stats);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 static int gn_splits(int B, int HW) {
   // enough blocks to fill 256 CUs a few times over, at least 16 pixels per block
   int want = std::max(1, (256 * 4) / std::max(B, 1));
@@ -182,6 +222,7 @@ static int gn_splits(int B, int HW) {
 }
 
 int gn_nsplit(int B, int HW) { return gn_splits(B, HW); }
+static int gn_splits_of(int B, int HW) { return gn_splits(B, HW); }
 
 int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg, int nseg,
                     const void* x2, int C1) {

@@ -55,6 +55,11 @@ int launch_linear_small(const float* x, int x_stride, const float* W, const floa
 // (replaces th.cat before a ResBlock's in_layers, openaimodel.py:787); the output is one C-channel tensor.
 int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, hipStream_t s, int seg = 0, int nseg = 1,
                     const void* x2 = nullptr, int C1 = 0);
+// GroupNorm statistics from the per-channel sums the producing convolutions wrote (ConvArgs::chstat, `rows` pixels per block);
+// cs2 / rows2 / C1: second source of a channel-concatenated input (C1 = channels of the first), else null.  Same `stats` layout
+// as launch_gn_stats with one segment.
+int launch_gn_chstat_finish(const float* cs1, int rows1, const float* cs2, int rows2, int C1, double* stats, int B, int HW, int C,
+                            hipStream_t s);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1,
                     const void* x2 = nullptr, int C1 = 0);
@@ -81,6 +86,8 @@ struct ConvArgs {
   int order;          // K walk: 0 = heuristic, 1 = tap-major, 2 = channel-major (taps innermost); 3 / 4 = the same walks
                       // on the pipe kernel's paired-fragment instantiation (16-byte epilogue accesses)
   int tile_map;       // blockIdx -> tile: 0 = heuristic, -1 = row-major, 1 / 2 = XCD-contiguous m-major / n-major (k_conv.hip)
+  float* chstat;      // optional: per-channel (sum, sum of squares) of the stored output per block of conv_chstat_rows() rows,
+                      // [M / rows][Cout][2] fp32 - the consumer GroupNorm's statistics without a pass over the tensor
 };
 // bump when the meaning of (cfg, order) changes: plan files written for other tables are ignored (net.hip)
 #define CONV_PLAN_VERSION 2
@@ -89,6 +96,8 @@ struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // res
 // `ws`/`ws_bytes`: split-K slab scratch for the trials.  Synchronises; only called at finalize.
 int conv_autotune(const ConvArgs& a, int dt, float* ws, size_t ws_bytes, ConvPlan* best);
 int launch_conv(const ConvArgs& a, int dt, hipStream_t s);
+// rows per block of ConvArgs::chstat for this launch, 0 when the launch cannot fill it (split-K, fp32, ragged channel tiles ...)
+int conv_chstat_rows(const ConvArgs& a, int dt);
 // split-K finish: y = (ws + bias + emb + res) * scale
 int launch_splitk_finish(const ConvArgs& a, int dt, hipStream_t s);
 int conv_pick_splitk(const ConvArgs& a, int dt);

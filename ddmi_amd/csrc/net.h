@@ -60,6 +60,9 @@ struct Op {
   int ext = -1;       // external pointer slot (inputs / outputs of the network)
   int gn_slot = -1;   // index into the GN statistics arena
   int tmp0 = -1, tmp1 = -1, tmp2 = -1;  // scratch tensors (OP_ATTN_FULL)
+  // GroupNorm statistics out of the producer's epilogue (plan()): OP_CONV writes per-channel sums of its output into tensor
+  // `stat_out`; OP_GN reads the ones of its input(s) instead of running the statistics pass when every producer delivered
+  int stat_out = -1, stat_in = -1, stat_in2 = -1;
   float scale = 1.f;
   ConvPlan tuned;     // OP_CONV: autotuned launch plan for B == max_batch (cfg 0 = heuristic)
   // tri-plane networks stack the three planes (shared weights) along the batch axis: an op runs on bmul * B samples;
@@ -110,6 +113,7 @@ struct Net {
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
   int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
   int pack_up4_weights();  // parity-form weights of the marked upsample convolutions (called by plan)
+  void attach_channel_stats();  // pairs GroupNorm inputs with the convolutions that produce them (called by plan)
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }
   size_t tbytes(int id, int B) const;

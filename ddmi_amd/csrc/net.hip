@@ -218,8 +218,40 @@ int Net::pack_up4_weights() {
   return DDMI_OK;
 }
 
+// A GroupNorm's statistics pass re-reads a tensor some convolution has just written.  Where every source of a GN input is the
+// plain NHWC output of a bf16 convolution, that convolution gets a small companion tensor ([pixels / 32][C][2] fp32 at most) for
+// the per-channel sums of its epilogue (k_conv.hip conv_epilogue_fast); whether a launch can fill it is decided per launch
+// (conv_chstat_rows), so run() falls back to the pass whenever a producer could not.
+void Net::attach_channel_stats() {
+  static const bool off = getenv("DDMI_GN_CHSTAT") && atoi(getenv("DDMI_GN_CHSTAT")) == 0;
+  if (off || dt != DT_BF16) return;
+  std::vector<int> producer(tensors.size(), -1);
+  for (size_t i = 0; i < ops.size(); ++i)
+    if (ops[i].kind == OP_CONV && ops[i].out >= 0 && !ops[i].out_nchw && ops[i].bmul == 1 && ops[i].out_boff == 0) producer[ops[i].out] = (int)i;
+    else if (ops[i].out >= 0 && ops[i].kind != OP_CONV) producer[ops[i].out] = -1;
+  const size_t n_ops = ops.size();
+  for (size_t i = 0; i < n_ops; ++i) {
+    if (ops[i].kind != OP_GN || ops[i].bmul != 1) continue;
+    const int in = ops[i].in, in2 = ops[i].in2;
+    if (producer[in] < 0 || (in2 >= 0 && producer[in2] < 0)) continue;
+    const TensorDesc& t = tensors[in];
+    if ((t.H * t.W) % 64 != 0) continue;
+    auto stat_tensor = [&](int src) {
+      Op& p = ops[producer[src]];
+      if (p.stat_out < 0) {
+        const TensorDesc& ts = tensors[src];
+        p.stat_out = new_tensor(2 * ts.C, (ts.H * ts.W) / 32, 1, DT_F32, 1);
+      }
+      return p.stat_out;
+    };
+    ops[i].stat_in = stat_tensor(in);
+    if (in2 >= 0) ops[i].stat_in2 = stat_tensor(in2);
+  }
+}
+
 int Net::plan() {
   DDMI_TRY(pack_up4_weights());
+  attach_channel_stats();
   const int nops = (int)ops.size();
   auto touch = [&](int id, int i, bool write) {
     if (id < 0) return;
@@ -232,6 +264,7 @@ int Net::plan() {
     const Op& o = ops[i];
     touch(o.in, i, false); touch(o.in2, i, false); touch(o.res, i, false);
     touch(o.out, i, true); touch(o.out2, i, true); touch(o.tmp0, i, true); touch(o.tmp1, i, true); touch(o.tmp2, i, true);
+    touch(o.stat_out, i, true); touch(o.stat_in, i, false); touch(o.stat_in2, i, false);
   }
   // first-fit allocator over op order
   struct Blk { size_t off, size; };
@@ -419,6 +452,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
   if (!finalized) return ddmi_fail(DDMI_ERR_STATE, "network not finalized");
   DDMI_REQUIRE(B >= 1 && B <= max_batch, "batch exceeds max_batch given at create time");
   const int Bnet = B;
+  std::vector<int> stat_rows(tensors.size(), 0);   // rows per block of the channel statistics a conv wrote for its output (0: none)
   for (const Op& o : ops) {
     const int B = Bnet * o.bmul;  // samples this op runs on
     auto plane_ptr = [&](int id, int boff) -> void* {
@@ -438,7 +472,11 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         const void* x2 = o.in2 >= 0 ? tptr(o.in2) : nullptr;
         DDMI_REQUIRE(g.C == C, "groupnorm channel mismatch");
         double* st = gn_stats;
-        DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, C, s, 0, 1, x2, t.C));
+        if (o.stat_in >= 0 && stat_rows[o.in] > 0 && (o.in2 < 0 || (o.stat_in2 >= 0 && stat_rows[o.in2] > 0)))
+          DDMI_TRY(launch_gn_chstat_finish((const float*)tptr(o.stat_in), stat_rows[o.in], o.in2 >= 0 ? (const float*)tptr(o.stat_in2) : nullptr,
+                                           o.in2 >= 0 ? stat_rows[o.in2] : 0, t.C, st, B, t.H * t.W, C, s));
+        else
+          DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, C, s, 0, 1, x2, t.C));
         DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, C, s, nullptr,
                                  1, x2, t.C));
         break;
@@ -466,6 +504,11 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         a.splitk_ws = splitk_ws;
         if (a.splitk > 1)
           DDMI_REQUIRE((size_t)a.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
+        if (o.stat_out >= 0) {
+          const int rows = conv_chstat_rows(a, dt);
+          if (rows > 0) a.chstat = (float*)tptr(o.stat_out);
+          stat_rows[o.out] = rows;
+        }
         DDMI_TRY(launch_conv(a, dt, s));
         break;
       }
