@@ -107,13 +107,11 @@ def cpu_baseline_afhq(threads=None):
                              "what": "BASELINE config 1 in full: 10-step DDIM on [1,64,16,16] + decode + MLP at 64x64, 1 sample"}}
 
 
-def pmc_traffic(live_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied).
-    The newest file wins; a kernel that is not in it reports null rather than a stale number."""
+def _profile_entry(glob_pat, live_name):
+    """The entry of the newest committed profiles/<glob_pat> table whose rocprof kernel name is the live scope `live_name`."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))   # r1_..., r2_...: the newest round wins
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", glob_pat)))   # r1_..., r2_...: the newest round wins
     if not files or not live_name:
         return None
     m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)>", live_name)
@@ -126,13 +124,33 @@ def pmc_traffic(live_name):
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
-        pat = re.compile(re.escape(live_name.split("<")[0]))
+        alias = {"mlp2d_fused": "mlp2d_v2_kernel", "mlp3d_fused": "mlp3d_v2_kernel", "mlpvideo_fused": "mlpv_v2_kernel"}
+        pat = re.compile(re.escape(alias.get(live_name, live_name.split("<")[0])))
     with open(files[-1]) as f:
         table = json.load(f)["kernels"]
     for name, v in table.items():
         if pat.search(name):
-            return v["hbm_bytes_per_launch"]
+            return v
     return None
+
+
+def pmc_traffic(live_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied).
+    The newest file wins; a kernel that is not in it reports null rather than a stale number."""
+    v = _profile_entry("*pmc_traffic*.json", live_name)
+    return v["hbm_bytes_per_launch"] if v else None
+
+
+def effective_clock(live_name, achieved_tflops):
+    """Context for `frac`: the shader clock the chip sustained under this kernel in the committed `rocprofv3 --pmc GRBM_GUI_ACTIVE`
+    pass (profiles/*effective_clock*.json, tools/pmc_clock.py) and the fraction of the dense peak AT THAT CLOCK (the 2.5 PFLOP/s
+    of `peak` is quoted at 2.4 GHz; DVFS holds MFMA-dense loops below it).  Informational - `frac` stays against the nominal peak."""
+    v = _profile_entry("*effective_clock*.json", live_name)
+    if not v:
+        return None
+    return {"effective_ghz": v["effective_ghz"], "peak_at_clock": v["mfma_peak_at_clock_tflops"],
+            "frac_at_clock": round(achieved_tflops / v["mfma_peak_at_clock_tflops"], 4), "source": "profiles (rocprofv3 --pmc GRBM_GUI_ACTIVE pass)"}
 
 
 def roofline_of(prof, pick):
@@ -143,7 +161,7 @@ def roofline_of(prof, pick):
     d = prof[dom]
     ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom), "clock": effective_clock(dom, ach),
             "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_timed": d["launches"],
             "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
             "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}

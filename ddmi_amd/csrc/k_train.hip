@@ -37,22 +37,23 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, T* __restr
   }
 }
 // the same through an LDS tile (this runs for every convolution of every training step: 2 GB of master weights): a block owns
-// 128 co x TCI ci x kk taps; the source rows (TCI * kk contiguous floats per co) are read in whole runs, the destination is
-// written as 128 consecutive co per (ci, tap).  TCI * kk <= 72: grid (ceil(Ci / TCI), ceil(Co / 128)).
+// 32 co x TCI ci x kk taps; the source rows (TCI * kk contiguous floats per co) are read in whole runs, the destination is
+// written as 32 consecutive co per (ci, tap).  TCI * kk <= 72: grid (ceil(Ci / TCI), ceil(Co / 32)) - small tiles on purpose,
+// a 224 x 224 x 9 filter must still spread over the chip (196 blocks; 128-co tiles gave it 56).
 template <typename T>
 __global__ void __launch_bounds__(256) pack_dgrad_weight_tiled_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int k,
                                                                       int TCI) {
-  __shared__ float tile[128][73];
+  __shared__ float tile[32][73];
   const int kk = k * k, run = TCI * kk;                  // contiguous floats of one co row inside the tile
-  const int ci0 = blockIdx.x * TCI, co0 = blockIdx.y * 128;
+  const int ci0 = blockIdx.x * TCI, co0 = blockIdx.y * 32;
   const int nci = min(TCI, Ci - ci0), len = nci * kk;
-  for (int i = threadIdx.x; i < 128 * run; i += 256) {
+  for (int i = threadIdx.x; i < 32 * run; i += 256) {
     const int r = i / run, j = i - r * run;
     if (co0 + r < Co && j < len) tile[r][j] = w[((int64_t)(co0 + r) * Ci + ci0) * kk + j];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < run * 128; i += 256) {
-    const int j = i >> 7, r = i & 127;                   // j = (ci, destination tap), r = co
+  for (int i = threadIdx.x; i < run * 32; i += 256) {
+    const int j = i >> 5, r = i & 31;                    // j = (ci, destination tap), r = co
     const int ci = j / kk, tp = j - ci * kk;
     if (co0 + r < Co && ci < nci) out[((int64_t)(ci0 + ci) * kk + tp) * Co + co0 + r] = from_f32<T>(tile[r][ci * kk + (kk - 1 - tp)]);
   }
@@ -430,11 +431,11 @@ __global__ void __launch_bounds__(512) wgrad_tn1_kernel(WgradTnK a) {
   }
 }
 
-__global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n, int S) {
+__global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n, int S, int accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
     for (int z = 0; z < S; ++z) acc += slab[(int64_t)z * n + i];
-    dw[i] = acc;
+    dw[i] = accumulate ? dw[i] + acc : acc;
   }
 }
 
@@ -456,7 +457,8 @@ int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k) {
   return std::max(1, std::min(std::min(target / tiles, ntiles), 64));
 }
 // slab: wgrad_tn_splits(...) * Co * Ci * k*k floats
-int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s) {
+int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s,
+                    int accumulate) {
   WgradTnK a{};
   a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
   a.B = B; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci;
@@ -480,7 +482,7 @@ int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B
     hipLaunchKernelGGL(wgrad_tn1_kernel, g, dim3(512), 2 * WG1_STAGE, s, a);
   }
   const int64_t n = (int64_t)Co * Ci * kk;
-  hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S);
+  hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S, accumulate);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -533,7 +535,7 @@ __global__ void sum_slices_kernel(const float* __restrict__ part, float* __restr
 
 // out[c] = sum_b in[b][c]: block 256 = 64 channels x 4 batch lanes (a lane adds every 4th row, four loads in flight), the four
 // partials are added in lane order (deterministic)
-__global__ void __launch_bounds__(256) sum_b_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
+__global__ void __launch_bounds__(256) sum_b_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int accumulate) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -549,14 +551,14 @@ __global__ void __launch_bounds__(256) sum_b_kernel(const float* __restrict__ in
   }
   red[bl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (bl == 0 && c < C) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (bl == 0 && c < C) out[c] = (accumulate ? out[c] : 0.f) + ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 int launch_pack_dgrad_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s) {
   const int64_t n = (int64_t)Co * Ci * k * k;
   if (k == 1 || k == 3) {
     const int TCI = k == 1 ? 64 : 8;
-    dim3 g((unsigned)cdiv(Ci, TCI), (unsigned)cdiv(Co, 128));
+    dim3 g((unsigned)cdiv(Ci, TCI), (unsigned)cdiv(Co, 32));
     if (dt == DT_F32) hipLaunchKernelGGL(pack_dgrad_weight_tiled_kernel<float>, g, dim3(256), 0, s, w, (float*)out, Co, Ci, k, TCI);
     else hipLaunchKernelGGL(pack_dgrad_weight_tiled_kernel<bf16_t>, g, dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, k, TCI);
   } else if (dt == DT_F32) hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(tr_blocks(n)), dim3(256), 0, s, w, (float*)out, Co, Ci, k);
@@ -628,8 +630,8 @@ int launch_sum_hw(const void* dy, float* out, float* part, int dt, int B, int HW
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
-int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s) {
-  hipLaunchKernelGGL(sum_b_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, in, out, B, C);
+int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s, int accumulate) {
+  hipLaunchKernelGGL(sum_b_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, in, out, B, C, accumulate);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -796,7 +798,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
 size_t gn_backward_scratch_floats(int B, int HW, int C) { return (size_t)B * 64 + (size_t)2 * B * C + (size_t)B * gn_nsplit(B, HW) * C * 4; }
 
 int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
-                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s) {
+                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s, int accumulate) {
   const int vn = dt == DT_F32 ? 4 : 8;
   DDMI_REQUIRE(C % TR_GROUPS == 0 && C % vn == 0, "gn_backward: C must be a multiple of 32 and of the 16-byte vector");
   const int NV = C / vn;
@@ -822,8 +824,8 @@ int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, con
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, ab, gamma, beta, (bf16_t*)dx, HW, C, NV, R, silu);
   }
   HIP_TRY(hipGetLastError());
-  DDMI_TRY(launch_sum_b(dgp, dgamma, B, C, s));
-  DDMI_TRY(launch_sum_b(dbp, dbeta, B, C, s));
+  DDMI_TRY(launch_sum_b(dgp, dgamma, B, C, s, accumulate));
+  DDMI_TRY(launch_sum_b(dbp, dbeta, B, C, s, accumulate));
   return DDMI_OK;
 }
 

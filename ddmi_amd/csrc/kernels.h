@@ -192,12 +192,12 @@ int launch_im2col_t(const void* x, void* out, int dt, int B, int H, int W, int C
 int launch_wgrad_finish(const float* G, float* dw, int Co, int Ci, int kk, int accumulate, hipStream_t s);
 int sum_hw_slices(int B, int HW, int C);
 int launch_sum_hw(const void* dy, float* out, float* part, int dt, int B, int HW, int C, hipStream_t s);   // out [B][C]; part: slices*B*C floats
-int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s);
+int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s, int accumulate = 0);   // accumulate: out += the sum
 int launch_gn_meanrstd(const double* part, float* mr, int B, int HW, int C, float eps, int nsplit, hipStream_t s);
 int gn_nsplit(int B, int HW);   // the split count launch_gn_stats uses (k_groupnorm.hip)
 size_t gn_backward_scratch_floats(int B, int HW, int C);
 int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
-                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s);
+                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s, int accumulate = 0);
 int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch, int dt, int B,
                                      int T, int heads, int d, hipStream_t s);
 int launch_linear_small_backward(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K, int N,
@@ -212,7 +212,8 @@ int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s
 // wgrad as a TN implicit GEMM with transposing LDS reads (bf16, 3x3 / 1x1 stride 1, W in {8,16,32,64}); slab = splits*Co*Ci*k*k floats
 bool wgrad_tn_ok(int dt, int B, int H, int W, int Ci, int Co, int k, int stride, int ups);
 int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k);
-int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s);
+int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s,
+                    int accumulate = 0);
 int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s);
 // fp32 GEMM with strided operands: C[m][n] = bias[n] + sum_r A[m sam + r sar] B[r sbr + n sbn]; slab = sgemm_splits * M * N floats
 int sgemm_splits(int M, int N, int R);

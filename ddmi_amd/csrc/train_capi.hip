@@ -13,6 +13,7 @@ struct ddmi_train {
   size_t ws_bytes = 0;
   float* freq = nullptr;   // sinusoidal-embedding frequency table of the last `dim` asked for (device, lives with the handle)
   int freq_dim = 0;
+  int acc_next = 0;        // ddmi_train_accumulate_next: parameter-gradient outputs of the NEXT backward call are added in place
 };
 
 namespace {
@@ -57,6 +58,12 @@ int ddmi_train_destroy(ddmi_train* h) {
     if (h->freq) (void)hipFree(h->freq);
     delete h;
   }
+  return DDMI_OK;
+}
+
+int ddmi_train_accumulate_next(ddmi_train* h, int mask) {
+  DDMI_REQUIRE(h && mask >= 0 && mask < 8, "train_accumulate_next: bad arguments");
+  h->acc_next = mask;
   return DDMI_OK;
 }
 
@@ -128,6 +135,8 @@ int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const floa
 int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void* dy, void* dx, float* dw, float* dbias,
                         float* demb, int B, int H, int W, int Cin, int Cout, int k, int stride, int ups, void* stream) {
   DDMI_REQUIRE(h && x && w && dy && dw && (k == 1 || k == 3) && (stride == 1 || stride == 2), "train_conv_bwd: bad arguments");
+  const int acc = h->acc_next;   // one-shot: bit 0 dw += , bit 1 dbias +=
+  h->acc_next = 0;
   DDMI_REQUIRE(!(stride == 2 && (ups || k != 3)), "train_conv_bwd: stride 2 is the 3x3 Downsample convolution");
   hipStream_t s = (hipStream_t)stream;
   const int dt = h->dt;
@@ -175,7 +184,7 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
     float* part = (float*)(h->ws + al((size_t)B * Cout * sizeof(float)));
     float* per = demb ? demb : per0;
     DDMI_TRY(launch_sum_hw(dy, per, part, dt, B, Ho * Wo, Cout, s));
-    if (dbias) DDMI_TRY(launch_sum_b(per, dbias, B, Cout, s));
+    if (dbias) DDMI_TRY(launch_sum_b(per, dbias, B, Cout, s, (acc >> 1) & 1));
   }
   // ---- dgrad ------------------------------------------------------------------------------------------------
   if (dx) {
@@ -199,7 +208,7 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
   if (tn) {   // TN implicit GEMM straight from dY and x (k_train.hip): no transposed copies, no im2col image
     Carve c{h};
     c.take(red_bytes);
-    DDMI_TRY(launch_wgrad_tn(dy, x, dw, (float*)c.take(tn_bytes), B, H, W, Cin, Cout, k, s));
+    DDMI_TRY(launch_wgrad_tn(dy, x, dw, (float*)c.take(tn_bytes), B, H, W, Cin, Cout, k, s, acc & 1));
   } else {
     Carve c{h};
     c.take(red_bytes);
@@ -220,7 +229,7 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
       gc.x = A; gc.w = Bm; gc.y_nchw = G;
       if (nb != bc) { plan_wgrad_gemm(&gc, dt); if (gc.splitk > g.splitk) gc.splitk = g.splitk; if (gc.splitk <= 1) gc.splitk_ws = nullptr; }
       DDMI_TRY(launch_conv(gc, dt, s));
-      DDMI_TRY(launch_wgrad_finish(G, dw, Cout, Cin, kk, b0 > 0, s));
+      DDMI_TRY(launch_wgrad_finish(G, dw, Cout, Cin, kk, b0 > 0 || (acc & 1), s));
     }
   }
   return DDMI_OK;
@@ -240,8 +249,10 @@ int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const fl
                       void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream) {
   DDMI_REQUIRE(h && x && gamma && beta && meanrstd && dy && dx && dgamma && dbeta, "train_gn_bwd: null argument");
   hipStream_t s = (hipStream_t)stream;
+  const int acc = h->acc_next;   // one-shot: bit 2 dgamma / dbeta +=
+  h->acc_next = 0;
   DDMI_TRY(reserve(h, gn_backward_scratch_floats(B, HW, C) * sizeof(float), s));
-  return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s);
+  return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s, (acc >> 2) & 1);
 }
 
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream) {

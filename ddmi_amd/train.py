@@ -91,6 +91,19 @@ class ToNCHW(torch.autograd.Function):
         return None, dx
 
 
+FUSE_GRAD_ACCUMULATION = True   # False: every gradient goes back through autograd's AccumulateGrad (tests compare both)
+
+
+def _grad_slot(p):
+    """The tensor a parameter gradient may be accumulated into in place: the parameter's existing fp32 contiguous `.grad`."""
+    if not FUSE_GRAD_ACCUMULATION or p is None or not isinstance(p, torch.Tensor) or not p.is_leaf:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv(nearest_x2?(x), w) + bias + emb[:, :, None, None] + res (ddmi_train_conv_fwd / _bwd)."""
 
@@ -109,6 +122,7 @@ class ConvFn(torch.autograd.Function):
                                                   _p(res_c), y.data_ptr(), B, H, W, Cin, Cout, k, stride, int(ups), _stream()))
         ctx.save_for_backward(x, w)
         ctx.tc, ctx.meta = tc, (B, H, W, Cin, Cout, k, stride, int(ups), bias is not None, emb is not None, res is not None)
+        ctx.params = (w, bias)
         return y
 
     @staticmethod
@@ -117,11 +131,17 @@ class ConvFn(torch.autograd.Function):
         B, H, W, Cin, Cout, k, stride, ups, has_b, has_e, has_r = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        dw = torch.empty_like(w)
-        db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_b else None
+        # parameters that already own a gradient buffer (the flat slab of FlatParams, or a .grad from an earlier backward) get their
+        # gradient ADDED there by the kernel's last stage - no temporary, no separate add kernel - and autograd is handed None
+        gw, gb = _grad_slot(ctx.params[0]), (_grad_slot(ctx.params[1]) if has_b else None)
+        dw = None if gw is not None else torch.empty_like(w)
+        db = None if (gb is not None or not has_b) else torch.empty((Cout,), dtype=torch.float32, device=x.device)
         de = torch.empty((B, Cout), dtype=torch.float32, device=x.device) if has_e else None
-        _lib.check(_lib.lib().ddmi_train_conv_bwd(ctx.tc.h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), dw.data_ptr(), _p(db), _p(de),
-                                                  B, H, W, Cin, Cout, k, stride, ups, _stream()))
+        mask = (1 if gw is not None else 0) | (2 if gb is not None else 0)
+        if mask:
+            _lib.check(_lib.lib().ddmi_train_accumulate_next(ctx.tc.h, mask))
+        _lib.check(_lib.lib().ddmi_train_conv_bwd(ctx.tc.h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), _p(gw if gw is not None else dw),
+                                                  _p(gb if gb is not None else db), _p(de), B, H, W, Cin, Cout, k, stride, ups, _stream()))
         return None, dx, dw, db, de, (dy if has_r else None), None, None
 
 
@@ -136,6 +156,7 @@ class GroupNormFn(torch.autograd.Function):
                                                 Cc, float(eps), int(silu), _stream()))
         ctx.save_for_backward(x, gamma, beta, mr)
         ctx.tc, ctx.silu = tc, int(silu)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -144,9 +165,14 @@ class GroupNormFn(torch.autograd.Function):
         B, H, W, Cc = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        gg, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        fused = gg is not None and gb is not None          # see ConvFn.backward
+        dg, db = (None, None) if fused else (torch.empty_like(gamma), torch.empty_like(beta))
+        if fused:
+            _lib.check(_lib.lib().ddmi_train_accumulate_next(ctx.tc.h, 4))
         _lib.check(_lib.lib().ddmi_train_gn_bwd(ctx.tc.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mr.data_ptr(), dy.data_ptr(),
-                                                dx.data_ptr(), dg.data_ptr(), db.data_ptr(), B, H * W, Cc, ctx.silu, _stream()))
+                                                dx.data_ptr(), (gg if fused else dg).data_ptr(), (gb if fused else db).data_ptr(), B, H * W, Cc,
+                                                ctx.silu, _stream()))
         return None, dx, dg, db, None, None
 
 
@@ -308,7 +334,8 @@ class _Conv(nn.Module):
         return self.weight if self.weight.dim() == 4 else self.weight.unsqueeze(-1)
 
     def run(self, tc, x, emb=None, res=None, stride=1, ups=False):
-        return ConvFn.apply(tc, x, self.w4(), self.bias, emb, res, stride, ups)
+        # the parameter itself (a Conv1d's [Cout, Cin, 1] has the bytes of [Cout, Cin, 1, 1]): ConvFn can then add into its .grad
+        return ConvFn.apply(tc, x, self.weight, self.bias, emb, res, stride, ups)
 
 
 class _Norm(nn.Module):   # GroupNorm32(32, C)

@@ -352,6 +352,10 @@ int ddmi_train_linear_fwd(ddmi_train* h, const float* x, const float* W, const f
                           void* stream);
 int ddmi_train_linear_bwd(ddmi_train* h, const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K,
                           int N, int silu_in, void* stream);
+/* Gradient-accumulation fusion (what accelerate's `accumulate` + torch's AccumulateGrad do for the reference, tools/ldm/image.py:160-170):
+ * the PARAMETER-gradient outputs of the NEXT ddmi_train_conv_bwd / ddmi_train_gn_bwd call on this handle are added to their
+ * destination instead of overwriting it - mask bit 0: dw, bit 1: dbias, bit 2: dgamma and dbeta.  One-shot. */
+int ddmi_train_accumulate_next(ddmi_train* h, int mask);
 /* fp32 GEMM with strided operands, C[m][n] = bias[n] + sum_r A[m*sam + r*sar] * B[r*sbr + n*sbn] (bias may be NULL): the batched
  * ResBlock.emb_layers projection of a training step (forward, input gradient, weight gradient are three orientations of it) */
 int ddmi_train_matmul(ddmi_train* h, const float* A, int64_t sam, int64_t sar, const float* B, int64_t sbr, int64_t sbn, float* C,

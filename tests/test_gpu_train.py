@@ -257,6 +257,25 @@ def test_graph_replay_equals_eager_steps(golden, numerics):
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
+def test_fused_gradient_accumulation_equals_autograd_accumulation(golden):
+    """Conv / GroupNorm parameter gradients added straight into the flat slab by the kernels' last stage (ddmi_train_accumulate_next)
+    == the same gradients returned to autograd and added by AccumulateGrad; two micro-steps, so that a non-zero slab is added to."""
+    t1 = golden.npz("T1_train_step.npz")
+    slabs = []
+    for fused in (True, False):
+        T.FUSE_GRAD_ACCUMULATION = fused
+        try:
+            tr = _toy_trainer(golden, "bf16")
+            for step in range(2):
+                x0, nz = g("T1f", f"x{step}", (2, 64, 8, 8)), g("T1f", f"n{step}", (2, 64, 8, 8))
+                tr.loss_and_backward(x0, (torch.from_numpy(t1["t"]) + 11 * step) % 1000, nz)
+            slabs.append(tr.flat.grad.clone())
+        finally:
+            T.FUSE_GRAD_ACCUMULATION = True
+    assert float(slabs[0].abs().max()) > 0
+    assert torch.equal(slabs[0], slabs[1])
+
+
 def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path):
     """A few steps -> LDMTrainStep.save (the dict LDMTrainer.save writes, tools/ldm/image.py:104-119) -> ImagePipeline.load_checkpoint:
     the inference UNet on the saved online weights equals the training-path forward, the EMA copy is what use_ema picks."""
