@@ -216,6 +216,8 @@ struct WgradTnK {
   const bf16_t* x;    // [B][H][W][Ci]
   float* slab;        // [S][Co][Ci][KK]
   int B, H, W, Co, Ci, S, TR, wshift;
+  int ups;            // x is [B][H/2][W/2][Ci] and the convolution ran on its nearest x2 upsampling (Upsample.conv): halo row (iy, ix)
+                      // is fetched from source pixel (iy >> 1, ix >> 1) - a change of DMA addresses only
 };
 #define WG_YB (128 * 128)                 // bytes of one dY half tile: 128 pixels x 64 co
 #define WG_XROWS 272                      // halo rows rounded up to whole DMA instructions (>= 4 x 66)
@@ -266,23 +268,24 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
     const int ci = ci0 + 8 * dchunk;
     const int hy = r / HWd, hx = r - hy * HWd;
     const bool ok = r < NHR && ci < a.Ci && hx >= PAD && hx < W + PAD;
-    xoff[j] = (((hy - PAD) * W + hx - PAD) * a.Ci + ci) * 2;
+    xoff[j] = a.ups ? ((((hy - PAD) >> 1) * (W >> 1) + ((hx - PAD) >> 1)) * a.Ci + ci) * 2 : (((hy - PAD) * W + hx - PAD) * a.Ci + ci) * 2;
     xhy[j] = ok ? hy - PAD : -(1 << 20);
   }
   auto issue = [&](int t, int stage) {
     const int b = t / tiles_per_sample, ty0 = (t - b * tiles_per_sample) * TR;
     unsigned char* base = wg_smem + stage * WG_STAGE;
     const bf16_t* yg = a.dy + ((int64_t)b * H * W + ty0 * W) * a.Co;
-    const bf16_t* xg = a.x + (int64_t)b * H * W * a.Ci;
+    const int x_px = a.ups ? (H >> 1) * (W >> 1) : H * W;     // pixels of one sample of x
+    const bf16_t* xg = a.x + (int64_t)b * x_px * a.Ci;
     auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yg, 0, (unsigned)(PT * a.Co * 2), 0x00020000);
-    auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (unsigned)(H * W * a.Ci * 2), 0x00020000);
+    auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (unsigned)(x_px * a.Ci * 2), 0x00020000);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gi = wave + 8 * j;
       if (8 * (gi & 15) < PT)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (wg_lds_void*)(base + (gi >> 4) * WG_YB + (gi & 15) * 1024), 16, yoff[j], 0, 0, 0);
     }
-    const int tile_off = ty0 * W * a.Ci * 2;
+    const int tile_off = a.ups ? (ty0 >> 1) * (W >> 1) * a.Ci * 2 : ty0 * W * a.Ci * 2;   // TR is even: ty0 >> 1 is exact
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int gi = wave + 8 * j;
@@ -439,11 +442,13 @@ __global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __
   }
 }
 
+// H, W: the grid the convolution ran on (= dY's; with `ups` the input x is [H/2][W/2])
 bool wgrad_tn_ok(int dt, int B, int H, int W, int Ci, int Co, int k, int stride, int ups) {
-  if (dt != DT_BF16 || stride != 1 || ups || !(k == 1 || k == 3) || Ci % 8 || Co % 8) return false;
+  if (dt != DT_BF16 || stride != 1 || !(k == 1 || k == 3) || Ci % 8 || Co % 8 || (ups && k != 3)) return false;
   if (k == 1) return ((int64_t)B * H * W) % 64 == 0;          // flat pixel list in 64-pixel tiles
   if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
   const int PT = std::min(128, H * W);
+  if (ups && ((PT / W) & 1)) return false;                    // tiles of an even number of rows map onto whole source rows
   return (H * W) % PT == 0 && PT % 32 == 0 && PT % W == 0;
 }
 int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k) {
@@ -458,10 +463,10 @@ int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k) {
 }
 // slab: wgrad_tn_splits(...) * Co * Ci * k*k floats
 int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s,
-                    int accumulate) {
+                    int accumulate, int ups) {
   WgradTnK a{};
   a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
-  a.B = B; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci;
+  a.B = B; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci; a.ups = ups ? 1 : 0;
   a.S = wgrad_tn_splits(B, H, W, Ci, Co, k);
   const int kk = k * k;
   static bool attr_done = false;

@@ -213,7 +213,7 @@ int launch_ema(float* ema, const float* p, int64_t n, float decay, hipStream_t s
 bool wgrad_tn_ok(int dt, int B, int H, int W, int Ci, int Co, int k, int stride, int ups);
 int wgrad_tn_splits(int B, int H, int W, int Ci, int Co, int k);
 int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B, int H, int W, int Ci, int Co, int k, hipStream_t s,
-                    int accumulate = 0);
+                    int accumulate = 0, int ups = 0);   // H, W: dY's grid; ups: x is [H/2][W/2], upsampled x2 by the convolution
 int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, int k, hipStream_t s);
 // fp32 GEMM with strided operands: C[m][n] = bias[n] + sum_r A[m sam + r sar] B[r sbr + n sbn]; slab = sgemm_splits * M * N floats
 int sgemm_splits(int M, int N, int R);

@@ -174,8 +174,8 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
                              (g.splitk > 1 ? al((size_t)g.splitk * Cout * N * sizeof(float)) : 0);
   const size_t red_bytes = al((size_t)B * Cout * sizeof(float)) * (1 + (size_t)sum_hw_slices(B, Ho * Wo, Cout));
   static const bool no_tn = getenv("DDMI_WGRAD_GEMM") != nullptr;   // diagnostics: the im2col + GEMM formulation everywhere
-  const bool tn = !no_tn && wgrad_tn_ok(dt, B, H, W, Cin, Cout, k, stride, ups);
-  const size_t tn_bytes = tn ? al((size_t)wgrad_tn_splits(B, H, W, Cin, Cout, k) * Cout * Cin * kk * sizeof(float)) : 0;
+  const bool tn = !no_tn && wgrad_tn_ok(dt, B, Ho, Wo, Cin, Cout, k, stride, ups);   // stride 1: (Ho, Wo) = the grid the conv ran on
+  const size_t tn_bytes = tn ? al((size_t)wgrad_tn_splits(B, Ho, Wo, Cin, Cout, k) * Cout * Cin * kk * sizeof(float)) : 0;
   DDMI_TRY(reserve(h, std::max(dgrad_bytes, tn ? tn_bytes : wgrad_bytes) + red_bytes, s));
   // ---- bias / embedding gradients ---------------------------------------------------------------------------
   if (dbias || demb) {
@@ -208,7 +208,7 @@ int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void
   if (tn) {   // TN implicit GEMM straight from dY and x (k_train.hip): no transposed copies, no im2col image
     Carve c{h};
     c.take(red_bytes);
-    DDMI_TRY(launch_wgrad_tn(dy, x, dw, (float*)c.take(tn_bytes), B, H, W, Cin, Cout, k, s, acc & 1));
+    DDMI_TRY(launch_wgrad_tn(dy, x, dw, (float*)c.take(tn_bytes), B, Ho, Wo, Cin, Cout, k, s, acc & 1, ups));
   } else {
     Carve c{h};
     c.take(red_bytes);

@@ -36,7 +36,8 @@ def g(tag, key, shape, std=1.0):
                                                      (3, 1, 0, 224, 224, 16),
                                                      # the TN implicit-GEMM wgrad (bf16): several pixel tiles per sample, ragged
                                                      # channel tiles, W = 64 (two rows per tile), 1x1 at 448 channels
-                                                     (3, 1, 0, 96, 160, 32), (3, 1, 0, 72, 40, 64), (1, 1, 0, 224, 448, 16)])
+                                                     (3, 1, 0, 96, 160, 32), (3, 1, 0, 72, 40, 64), (1, 1, 0, 224, 448, 16),
+                                                     (3, 1, 1, 64, 96, 16)])   # Upsample.conv: 16x16 source, 32x32 grid
 def test_conv_forward_backward_vs_torch(numerics, tol, k, stride, ups, cin, cout, hw):
     tc = T.TrainContext(numerics, DEV)
     B = 2
