@@ -225,10 +225,18 @@ int Net::pack_up4_weights() {
 void Net::attach_channel_stats() {
   static const bool off = getenv("DDMI_GN_CHSTAT") && atoi(getenv("DDMI_GN_CHSTAT")) == 0;
   if (off || dt != DT_BF16) return;
+  // producer[t] = the ONE op that writes tensor t when that op is a plain convolution over the whole tensor; -2 = written by
+  // anything else as well (plane-stacked convolutions write slices of one tensor, other op kinds deliver no sums)
   std::vector<int> producer(tensors.size(), -1);
-  for (size_t i = 0; i < ops.size(); ++i)
-    if (ops[i].kind == OP_CONV && ops[i].out >= 0 && !ops[i].out_nchw && ops[i].bmul == 1 && ops[i].out_boff == 0) producer[ops[i].out] = (int)i;
-    else if (ops[i].out >= 0 && ops[i].kind != OP_CONV) producer[ops[i].out] = -1;
+  auto writes = [&](int t, int op, bool plain_conv) {
+    if (t < 0) return;
+    producer[t] = (plain_conv && producer[t] == -1) ? op : -2;
+  };
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const Op& o = ops[i];
+    writes(o.out, (int)i, o.kind == OP_CONV && !o.out_nchw && o.bmul == 1 && o.out_boff == 0 && o.in_boff == 0);
+    writes(o.out2, (int)i, false);
+  }
   const size_t n_ops = ops.size();
   for (size_t i = 0; i < n_ops; ++i) {
     if (ops[i].kind != OP_GN || ops[i].bmul != 1) continue;

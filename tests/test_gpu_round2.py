@@ -342,6 +342,19 @@ torch.cuda.synchronize()
 prof = _lib.profile_collect()
 np.save(sys.argv[1], y.cpu().numpy())
 print('STATS_BYTES', prof['gn_stats']['bytes'], prof['gn_stats']['launches'])
+# the D2C-VAE decoder: other channel counts (128 / 256 / 512), other tile configurations, eps 1e-6
+from ddmi_amd.autoencoder import Autoencoder
+from helpers import AFHQ_DD, AFHQ_EMBED
+vae = Autoencoder(AFHQ_DD, AFHQ_EMBED, numerics='bf16', max_batch=2)
+vae.load_state_dict(named_state('afhq.vae', vae.manifest()))
+z = torch.from_numpy(iw.normal('afhq', 'z2', (2, 64, 64, 64))).cuda()
+vae.decode(z)
+_lib.profile_enable(1)
+planes = vae.decode(z)
+torch.cuda.synchronize()
+prof = _lib.profile_collect()
+np.save(sys.argv[1] + '.plane.npy', planes[2].float().cpu().numpy())
+print('DEC_STATS_BYTES', prof['gn_stats']['bytes'], prof['gn_stats']['launches'])
 """ % (ROOT, ROOT)
     outs = {}
     for mode in ("1", "0"):
@@ -350,7 +363,8 @@ print('STATS_BYTES', prof['gn_stats']['bytes'], prof['gn_stats']['launches'])
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("STATS_BYTES")][0].split()
-        outs[mode] = (np.load(path), float(line[1]), int(line[2]))
+        dline = [ln for ln in r.stdout.splitlines() if ln.startswith("DEC_STATS_BYTES")][0].split()
+        outs[mode] = (np.load(path), float(line[1]), int(line[2]), np.load(path + ".plane.npy"), float(dline[1]))
     on, off = outs["1"], outs["0"]
     assert on[2] == off[2]                       # the same number of GroupNorms
     # B = 16: the 64x64 and 32x32 levels run without split-K and deliver their sums (split-K launches finish in another kernel and
@@ -365,3 +379,11 @@ print('STATS_BYTES', prof['gn_stats']['bytes'], prof['gn_stats']['launches'])
     e_on, e_off = rel_err(torch.from_numpy(on[0]), ref), rel_err(torch.from_numpy(off[0]), ref)
     assert e_on < TOL_BF16 and e_off < TOL_BF16 and e_on < 1.25 * e_off + 1e-3, (e_on, e_off)
     assert rel_err(torch.from_numpy(on[0]), torch.from_numpy(off[0])) < 2e-2
+    # decoder: 256x256 plane of both runs against the fp32 decoder
+    from ddmi_amd.autoencoder import Autoencoder
+    vae32 = Autoencoder(AFHQ_DD, AFHQ_EMBED, numerics="fp32", max_batch=2)
+    vae32.load_state_dict(named_state("afhq.vae", vae32.manifest()))
+    pref = vae32.decode(torch.from_numpy(iw.normal("afhq", "z2", (2, 64, 64, 64))).to(DEV))[2].float().cpu()
+    d_on, d_off = rel_err(torch.from_numpy(on[3]), pref), rel_err(torch.from_numpy(off[3]), pref)
+    assert on[4] < 0.6 * off[4]                  # no split-K at these sizes: nearly every decoder GroupNorm takes the sums
+    assert d_on < TOL_BF16 and d_off < TOL_BF16 and d_on < 1.25 * d_off + 1e-3, (d_on, d_off)
