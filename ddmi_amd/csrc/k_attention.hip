@@ -353,12 +353,20 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
     }
   };
 
-  float m_run[QF], l_run[QF];
-  f32x4 o[QF][NDF];
+  // The softmax denominator rides on the matrix pipe: one more accumulator fragment per query fragment takes P against an
+  // all-ones "V" fragment, so ol[qf][j] = sum over keys of the bf16 P values that also multiply V (every row of the fragment is
+  // the same sum; lane lr reads its own query's).  The loop is VALU-bound at small head dims (d = 32: ~220 VALU issue slots per
+  // 64-key tile and wave against 16 MFMAs), and this replaces 32 v_add + 4 ds_bpermute per tile by 4 MFMAs; the running
+  // rescale `l = l alpha + psum` is the accumulators' own `o *= alpha`.
+  float m_run[QF];
+  f32x4 o[QF][NDF], ol[QF];
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 #pragma unroll
   for (int qf = 0; qf < QF; ++qf) {
     m_run[qf] = -INFINITY;
-    l_run[qf] = 0.f;
+    ol[qf] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
   }
@@ -419,25 +427,23 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run[qf], tmax * sscale);
       const float alpha = __builtin_amdgcn_exp2f(m_run[qf] - m_new);
-      float psum = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qf][f][j], sscale, -m_new));
-          psum += p;
           pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)p;
         }
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
-      l_run[qf] = l_run[qf] * alpha + psum;
       m_run[qf] = m_new;
 #pragma unroll
       for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+      ol[qf][0] *= alpha;   // the other three rows of the fragment hold the same sum and are never read
     }
     // ---- O^T += V^T . P^T, V^T fragments by transposed LDS reads -------------------------------------------
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
 #pragma unroll
       for (int df = 0; df < NDF; ++df) {
         const int coff = ((2 * df + (tp >> 1)) ^ vsw) << 4;
@@ -461,7 +467,7 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   for (int qf = 0; qf < QF; ++qf) {
     const int q_idx = blockIdx.x * (64 * QF) + (wave * QF + qf) * 16 + lr;
     if (!q_ok[qf]) continue;
-    const float inv = 1.0f / l_run[qf];
+    const float inv = 1.0f / ol[qf][0];
     int seg = 0;
     int64_t r = row_of(q_idx, &seg);
     T* op = (T*)(SEG3 ? a.out[seg] : a.out[0]) + r * a.ld_out + h * a.hs_out;
