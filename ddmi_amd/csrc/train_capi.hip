@@ -134,9 +134,9 @@ int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const floa
 
 int ddmi_train_conv_bwd(ddmi_train* h, const void* x, const float* w, const void* dy, void* dx, float* dw, float* dbias,
                         float* demb, int B, int H, int W, int Cin, int Cout, int k, int stride, int ups, void* stream) {
+  const int acc = h ? h->acc_next : 0;   // one-shot: bit 0 dw += , bit 1 dbias += ; consumed even when the call is refused below
+  if (h) h->acc_next = 0;
   DDMI_REQUIRE(h && x && w && dy && dw && (k == 1 || k == 3) && (stride == 1 || stride == 2), "train_conv_bwd: bad arguments");
-  const int acc = h->acc_next;   // one-shot: bit 0 dw += , bit 1 dbias +=
-  h->acc_next = 0;
   DDMI_REQUIRE(!(stride == 2 && (ups || k != 3)), "train_conv_bwd: stride 2 is the 3x3 Downsample convolution");
   hipStream_t s = (hipStream_t)stream;
   const int dt = h->dt;
@@ -247,10 +247,10 @@ int ddmi_train_gn_fwd(ddmi_train* h, const void* x, const float* gamma, const fl
 }
 int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
                       void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream) {
+  const int acc = h ? h->acc_next : 0;   // one-shot: bit 2 dgamma / dbeta += ; consumed even when the call is refused below
+  if (h) h->acc_next = 0;
   DDMI_REQUIRE(h && x && gamma && beta && meanrstd && dy && dx && dgamma && dbeta, "train_gn_bwd: null argument");
   hipStream_t s = (hipStream_t)stream;
-  const int acc = h->acc_next;   // one-shot: bit 2 dgamma / dbeta +=
-  h->acc_next = 0;
   DDMI_TRY(reserve(h, gn_backward_scratch_floats(B, HW, C) * sizeof(float), s));
   return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s, (acc >> 2) & 1);
 }
