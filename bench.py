@@ -286,6 +286,10 @@ def run_afhq(args, rank, local_rank, world, dev):
         "nccl_ranks": nranks,
         "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None),
         "unet_step_mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        # the same on the wall clock and the ALGORITHMIC work: 265.5 GFLOP per sample and UNet step (the parity-form
+        # upsample convolutions execute 21 GFLOP fewer, which the profiled figure above counts) over the timed sampling loop
+        "unet_step_algorithmic_frac": round(265.5e9 * B * args.nfe / (phase_ms["sampling_loop"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+        if phase_ms.get("sampling_loop") else None,
         "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
         "last_step_phase_ms": {k: round(v, 2) for k, v in phase_ms.items()},
         "unet_memory_bytes": pipe.unet.memory(),
