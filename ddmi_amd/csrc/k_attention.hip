@@ -300,9 +300,36 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
   const int d = a.d;
   const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the query tile as the fastest
+  // grid index the tiles of one (sample, head) landed on 8 different XCDs and every L2 fetched that head's K / V (PMC, round 2:
+  // 6.5x the algorithmic reads at 1024 tokens).  Here XCD x owns the samples b = x (mod 8) whole: all query tiles of a head
+  // and all heads of a sample (whose q | k | v blocks interleave inside the same token rows) read through ONE L2.
+  int q_tile, b, h;
+  {
+    const int tiles = (N + 64 * QF - 1) / (64 * QF);
+    const int L = blockIdx.x, slot = L >> 3;
+    if (a.xcd_map == 0) {          // XCD x owns samples b = x (mod 8)
+      const int per_sample = tiles * a.heads;
+      const int bl = slot / per_sample, rem = slot - bl * per_sample;
+      h = rem / tiles;
+      q_tile = rem - h * tiles;
+      b = bl * 8 + (L & 7);
+    } else if (a.xcd_map == 1) {   // few samples: XCD x owns the (sample, head) pairs bh = x (mod 8)
+      const int ul = slot / tiles;
+      q_tile = slot - ul * tiles;
+      const int bh = ul * 8 + (L & 7);
+      b = bh / a.heads;
+      h = bh - b * a.heads;
+    } else {                       // fewer than 8 (sample, head) pairs: plain order, the query tile fastest
+      const int bh = L / tiles;
+      q_tile = L - bh * tiles;
+      b = bh / a.heads;
+      h = bh - b * a.heads;
+    }
+    if (b >= a.B) return;   // the grid is padded to whole groups of 8 (workgroup-uniform exit before any barrier)
+  }
   const float sscale = a.scale * 1.44269504088896341f;
   // token n of sample b -> (segment, row); with one segment (every per-plane / image attention) this is a plain offset
   auto row_of = [&](int n, int* seg) -> int64_t {
@@ -316,7 +343,7 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   bool q_ok[QF];
 #pragma unroll
   for (int qf = 0; qf < QF; ++qf) {
-    const int q_idx = blockIdx.x * (64 * QF) + (wave * QF + qf) * 16 + lr;
+    const int q_idx = q_tile * (64 * QF) + (wave * QF + qf) * 16 + lr;
     q_ok[qf] = q_idx < N;
     int seg = 0;
     int64_t r = row_of(q_ok[qf] ? q_idx : 0, &seg);
@@ -465,7 +492,7 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 
 #pragma unroll
   for (int qf = 0; qf < QF; ++qf) {
-    const int q_idx = blockIdx.x * (64 * QF) + (wave * QF + qf) * 16 + lr;
+    const int q_idx = q_tile * (64 * QF) + (wave * QF + qf) * 16 + lr;
     if (!q_ok[qf]) continue;
     const float inv = 1.0f / ol[qf][0];
     int seg = 0;
@@ -485,7 +512,7 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 }
 
 template <int D, int QF>
-static int launch_attention_v2(const AttnArgs& a, hipStream_t s) {
+static int launch_attention_v2(const AttnArgs& a_in, hipStream_t s) {
   constexpr int lds = 4 * 64 * D * 2;
   auto kern1 = attention_v2_kernel<D, QF, false>;
   auto kern3 = attention_v2_kernel<D, QF, true>;
@@ -495,8 +522,13 @@ static int launch_attention_v2(const AttnArgs& a, hipStream_t s) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
-  dim3 grid(cdiv(N, 64 * QF), a.B * a.heads);
+  const int N = a_in.seg_len[0] + a_in.seg_len[1] + a_in.seg_len[2];
+  // 1-D grid, XCD-aware order (top of the kernel): by sample when the batch fills the 8 XCDs evenly, else by (sample, head)
+  AttnArgs a = a_in;
+  const int tiles = cdiv(N, 64 * QF), BH = a.B * a.heads;
+  a.xcd_map = (a.B % 8 == 0 || a.B >= 64) ? 0 : BH >= 8 ? 1 : 2;
+  if (const char* e = getenv("DDMI_ATTN_XCDMAP")) a.xcd_map = atoi(e);   // diagnostics (tools/bench_attn_afhq.py): 2 = plain order
+  dim3 grid(a.xcd_map == 0 ? tiles * a.heads * (cdiv(a.B, 8) * 8) : a.xcd_map == 1 ? tiles * (cdiv(BH, 8) * 8) : tiles * BH);
   if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL(kern3, grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());

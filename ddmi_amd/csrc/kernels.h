@@ -126,6 +126,7 @@ struct AttnArgs {
   float scale;
   int vec_ok;          // filled by launch_attention
   int legacy_name;     // profiler label only
+  int xcd_map;         // filled by the bf16 launcher: workgroup -> (sample, head, query tile) order (k_attention.hip)
 };
 int launch_attention(const AttnArgs& a, int dt, hipStream_t s);
 int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s);

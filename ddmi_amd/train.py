@@ -557,6 +557,21 @@ def allreduce_gradients(flat_grad: torch.Tensor, world_size: int, bucket_bytes: 
     return flat_grad
 
 
+def ema_pytorch_plan(step: int, beta: float, update_every: int, update_after_step: int = 100, inv_gamma: float = 1.0,
+                     power: float = 2.0 / 3.0, min_value: float = 0.0):
+    """What the `step`-th call (0-based: the value of ema_pytorch's `step` buffer BEFORE its increment) of `EMA.update()` does:
+    ("skip", None) | ("copy", None) | ("lerp", decay) with ema = decay * ema + (1 - decay) * online."""
+    if step % update_every != 0:
+        return "skip", None
+    if step <= update_after_step:
+        return "copy", None
+    epoch = max((step + 1) - update_after_step - 1, 0)     # get_current_decay reads the incremented buffer
+    if epoch <= 0:
+        return "lerp", 0.0
+    value = 1.0 - (1.0 + epoch / inv_gamma) ** (-power)
+    return "lerp", float(min(max(value, min_value), beta))
+
+
 class LDMTrainStep:
     """`DDPM.forward` + backward + optimizer step of the reference's LDM trainer on one GPU of a data-parallel job.
 
@@ -582,6 +597,11 @@ class LDMTrainStep:
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.accum = int(gradient_accumulate_every)
         self.ema_decay, self.ema_every = float(ema_decay), int(ema_update_every)
+        # ema_pytorch.EMA defaults the reference relies on (tools/ldm/image.py:64 passes beta and update_every only)
+        self.ema_update_after_step, self.ema_inv_gamma, self.ema_power, self.ema_min_value = 100, 1.0, 2.0 / 3.0, 0.0
+        self.ema_step = 0            # ema_pytorch's `step` buffer: number of update() calls so far
+        self.ema_initted = False     # its `initted` buffer
+        self._ddpmconfig = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool, type(None)))}
         self.flat: Optional[FlatParams] = None
         self.ema: Optional[torch.Tensor] = None
         self.opt_step = 0
@@ -613,7 +633,8 @@ class LDMTrainStep:
         return {k: p.detach().clone() for k, p in self.named_parameters()}
 
     def finalize(self):
-        """Lays the parameters out in one slab (after load_state_dict) and snapshots the EMA copy."""
+        """Lays the parameters out in one slab (after load_state_dict); the EMA copy starts as a clone of the online weights
+        (ema_pytorch deep-copies the model at construction)."""
         self.flat = FlatParams([p for _, p in self.named_parameters()], self.device)
         self.ema = self.flat.data.clone()
         return self
@@ -673,7 +694,7 @@ class LDMTrainStep:
         return loss
 
     def optimizer_step(self, world_size: int = 1):
-        """All-reduce (sum) of the gradient slab over the ranks, fused AdamW, EMA every `ema_update_every` steps."""
+        """All-reduce (sum) of the gradient slab over the ranks, fused AdamW, then `ema.update()` (tools/ldm/image.py:171-174)."""
         allreduce_gradients(self.flat.grad, world_size)
         self.opt_step += 1
         f = self.flat
@@ -682,27 +703,108 @@ class LDMTrainStep:
                                                1.0 / (world_size * self.accum), _stream()))
         f.zero_grad()
         self.micro = 0
-        if self.opt_step % self.ema_every == 0:
-            _lib.check(_lib.lib().ddmi_train_ema(self.ema.data_ptr(), f.data.data_ptr(), f.n, self.ema_decay, _stream()))
+        self.ema_update()
 
-    # ---- checkpoints: the dict LDMTrainer.save writes (tools/ldm/image.py:104-119), minus the VAE / MLP it does not train ----
-    def checkpoint(self, vaemodel_state=None, mlp_state=None) -> Dict[str, object]:
-        sd = self.state_dict()
-        keys = [k for k, _ in self.named_parameters()]
-        ema, off = {}, 0
-        for k, (_, p) in zip(keys, self.named_parameters()):
-            ema["ema_model." + k] = self.ema[off:off + p.numel()].view(p.shape).clone()
+    # ---- EMA: ema_pytorch.EMA.update (the reference's dependency, unpinned in README.md:33; absent from /root/reference, restated
+    # from its published algorithm): act on calls whose PRE-increment count is a multiple of update_every; copy the online weights
+    # while that count <= update_after_step (100); afterwards lerp with the warmed-up decay
+    #   1 - (1 + epoch / inv_gamma)^-power,  epoch = count - update_after_step  (the post-increment step - update_after_step - 1),
+    # clamped to [min_value, beta] (0.0 for epoch <= 0): ~0.95 at epoch 100, 0.99 at 1000, beta = 0.9999 from epoch 1e6 on.
+    def ema_update(self):
+        action, decay = ema_pytorch_plan(self.ema_step, self.ema_decay, self.ema_every, self.ema_update_after_step, self.ema_inv_gamma,
+                                         self.ema_power, self.ema_min_value)
+        self.ema_step += 1
+        f = self.flat
+        if action == "copy":
+            self.ema.copy_(f.data)
+        elif action == "lerp":
+            if not self.ema_initted:
+                self.ema.copy_(f.data)
+                self.ema_initted = True
+            _lib.check(_lib.lib().ddmi_train_ema(self.ema.data_ptr(), f.data.data_ptr(), f.n, decay, _stream()))
+
+    # ---- checkpoints: the dict LDMTrainer.save writes (tools/ldm/image.py:104-119) ----------------------------------------------
+    def _schedule_buffers(self) -> Dict[str, torch.Tensor]:
+        """The 12 persistent DDPM buffers (ddpm.py:182-203) that `diffusion_process.state_dict()` carries next to the weights."""
+        from .ddpm import DDPM, SCHEDULE_BUFFERS
+        d = DDPM(model=None, **self._ddpmconfig)
+        return {k: torch.from_numpy(np.ascontiguousarray(getattr(d, k))) for k in SCHEDULE_BUFFERS}
+
+    def checkpoint(self, vaemodel_state=None, mlp_state=None, args=None) -> Dict[str, object]:
+        """`diffusion` = DDPM.state_dict() (model.*, mixing_logit, the schedule buffers); `ema` = ema_pytorch's state dict
+        (initted, step, online_model.*, ema_model.*); `dae_opt` = torch.optim.AdamW.state_dict() over `parameters()` order (model.*
+        then mixing_logit, the registration order of ddpm.py:124/156), so the reference's strict loads and its resume accept it."""
+        named = list(self.named_parameters())
+        bufs = self._schedule_buffers()
+        sd = {k: p.detach().clone() for k, p in named}
+        sd.update(bufs)
+        ema, opt_state, off = {"initted": torch.tensor(bool(self.ema_initted)), "step": torch.tensor(int(self.ema_step))}, {}, 0
+        for i, (k, p) in enumerate(named):
+            n = p.numel()
             ema["online_model." + k] = p.detach().clone()
-            off += p.numel()
-        ema["initted"], ema["step"] = torch.tensor(True), torch.tensor(self.opt_step)
-        return {"step": self.opt_step, "current_iters": self.opt_step * self.accum, "vaemodel": vaemodel_state or {}, "mlp": mlp_state or {},
-                "diffusion": sd, "ema": ema,
-                "dae_opt": {"exp_avg": self.flat.exp_avg.clone(), "exp_avg_sq": self.flat.exp_avg_sq.clone(), "step": self.opt_step,
-                            "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd},
+            ema["ema_model." + k] = self.ema[off:off + n].view(p.shape).clone()
+            opt_state[i] = {"step": torch.tensor(float(self.opt_step)), "exp_avg": self.flat.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        for k, v in bufs.items():
+            ema["online_model." + k] = v.clone()
+            ema["ema_model." + k] = v.clone()
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(named)))}
+        return {"args": dict(args) if args else {"ddpmconfig": dict(self._ddpmconfig)}, "step": self.opt_step,
+                "current_iters": self.opt_step * self.accum, "vaemodel": vaemodel_state or {}, "mlp": mlp_state or {},
+                "diffusion": sd, "ema": ema, "dae_opt": {"state": opt_state if self.opt_step > 0 else {}, "param_groups": [group]},
                 "scaler": None}
 
-    def save(self, path, vaemodel_state=None, mlp_state=None):
-        torch.save(self.checkpoint(vaemodel_state, mlp_state), path)
+    def save(self, path, vaemodel_state=None, mlp_state=None, args=None):
+        torch.save(self.checkpoint(vaemodel_state, mlp_state, args), path)
+
+    def load_training_state(self, ck, resume: bool = True):
+        """After finalize(): what `LDMTrainer.load` (resume, tools/ldm/image.py:121-134) or the `pretrained` branch (:76-82) restore
+        besides the online weights - the EMA copy (+ its `initted` / `step` counters) for both, AdamW's moments and step plus the
+        trainer's `step` for resume.  `dae_opt` is read in torch's {'state', 'param_groups'} layout (by parameter index) or this
+        repo's round-2 flat layout ({'exp_avg', 'exp_avg_sq', 'step'})."""
+        assert self.flat is not None, "load_training_state comes after finalize()"
+        named = list(self.named_parameters())
+        ema = ck.get("ema") or {}
+        with torch.no_grad():
+            if any(k.startswith("ema_model.") for k in ema):
+                off = 0
+                for k, p in named:
+                    n = p.numel()
+                    v = ema.get("ema_model." + k)
+                    if v is None:
+                        raise KeyError(f"checkpoint EMA lacks ema_model.{k}")
+                    self.ema[off:off + n].copy_(torch.as_tensor(v).to(self.device, torch.float32).reshape(-1))
+                    off += n
+                self.ema_initted = bool(ema["initted"]) if "initted" in ema else True
+                self.ema_step = int(ema["step"]) if "step" in ema else 0
+            if not resume:
+                return self
+            opt = ck.get("dae_opt") or {}
+            if "state" in opt:
+                off, steps = 0, []
+                for i, (k, p) in enumerate(named):
+                    n = p.numel()
+                    st = opt["state"].get(i)
+                    if st is not None:
+                        self.flat.exp_avg[off:off + n].copy_(torch.as_tensor(st["exp_avg"]).to(self.device, torch.float32).reshape(-1))
+                        self.flat.exp_avg_sq[off:off + n].copy_(torch.as_tensor(st["exp_avg_sq"]).to(self.device, torch.float32).reshape(-1))
+                        steps.append(int(float(st["step"])))
+                    off += n
+                if steps:
+                    assert min(steps) == max(steps), "the fused AdamW keeps ONE step count for every parameter"
+                    self.opt_step = steps[0]
+                if opt.get("param_groups"):
+                    g = opt["param_groups"][0]
+                    self.lr, self.betas, self.eps, self.wd = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+            elif "exp_avg" in opt:
+                self.flat.exp_avg.copy_(torch.as_tensor(opt["exp_avg"]).to(self.device, torch.float32))
+                self.flat.exp_avg_sq.copy_(torch.as_tensor(opt["exp_avg_sq"]).to(self.device, torch.float32))
+                self.opt_step = int(opt.get("step", 0))
+            if "step" in ck and "state" not in opt and "exp_avg" not in opt:
+                self.opt_step = int(ck["step"])
+        return self
 
     def train_step(self, z0, t=None, noise=None, world_size: int = 1):
         """The body of the reference's loop for one batch (tools/ldm/image.py:158-175)."""

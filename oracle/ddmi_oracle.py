@@ -673,15 +673,27 @@ def vae3d_decode(p: State, ddconfig: Mapping, embed_dim: int, z: Tensor):
 # so these semantics - not the C^-1/2 scale of the no-xformers fallback AttnBlock1d (ae:259) - are canonical.
 # ======================================================================================
 
-def sdpa_heads(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
-    """q, k, v [B, heads*d, N] with channel = head*d + j (ae:447-456): per head softmax(q k^T / sqrt(d)) v -> [B, heads*d, N]."""
+SDPA_QUERY_CHUNK = 512   # queries per block once the score matrix of a head would pass SDPA_FULL_SCORES elements
+SDPA_FULL_SCORES = 1 << 26
+
+
+def sdpa_heads(q: Tensor, k: Tensor, v: Tensor, heads: int, q_chunk: Optional[int] = None) -> Tensor:
+    """q, k, v [B, heads*d, N] with channel = head*d + j (ae:447-456): per head softmax(q k^T / sqrt(d)) v -> [B, heads*d, N].
+    Every query row is its own softmax, so the rows are evaluated in blocks of `q_chunk` queries against ALL keys when the
+    full [N, N] matrix would not fit (the video decoder's last inter-plane attention has N = 73 728: 21.7 GB per head in fp32,
+    151 MB per head and block of 512) - the same function, only the order of evaluation differs."""
     B, HD, N = q.shape
     d = HD // heads
     qh = q.reshape(B, heads, d, N).permute(0, 1, 3, 2)  # [B,H,N,d]
     kh = k.reshape(B, heads, d, N)
     vh = v.reshape(B, heads, d, N).permute(0, 1, 3, 2)
-    w = torch.softmax(torch.matmul(qh, kh) * (d ** -0.5), dim=-1)  # [B,H,Nq,Nk]
-    o = torch.matmul(w, vh)  # [B,H,N,d]
+    if q_chunk is None:
+        q_chunk = N if N * N <= SDPA_FULL_SCORES else SDPA_QUERY_CHUNK
+    outs = []
+    for a in range(0, N, q_chunk):
+        w = torch.softmax(torch.matmul(qh[:, :, a:a + q_chunk], kh) * (d ** -0.5), dim=-1)  # [B,H,q,Nk]
+        outs.append(torch.matmul(w, vh))  # [B,H,q,d]
+    o = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
     return o.permute(0, 1, 3, 2).reshape(B, HD, N)
 
 
@@ -902,3 +914,51 @@ def generate_video(unet_p: State, unet_cfg: Mapping, vae_p: State, ddconfig: Map
     hdbf = vit_decode(vae_p, ddconfig, frames, z)
     vid = mlp_video(mlp_p, coords, hdbf)
     return {"z": z, "hdbf": hdbf, "video": vid.clamp(-1.0, 1.0)}
+
+
+# ======================================================================================
+# f4  EMA of the trainer: ema_pytorch.EMA (third-party, `pip install ema-pytorch`, README.md:33, unpinned and absent from
+# the reference tree).  Restated from its published algorithm; the reference's call sites are tools/ldm/image.py:64
+# (EMA(diffusion_process, beta=ema_decay, update_every=ema_update_every): every other argument at its default) and :174
+# (ema.update() after each optimizer step); its state dict ('initted', 'step', 'online_model.*', 'ema_model.*') is what
+# tools/ldm/image.py:115 saves and :80/:130 load.  No golden vector exists for it (the package cannot be imported here):
+# parity for this function is "unpinned" and anchored on those call sites only.
+# ======================================================================================
+
+class EmaPytorchOracle:
+    """ema_pytorch.EMA on a flat list of tensors: update_after_step = 100, inv_gamma = 1, power = 2/3, min_value = 0."""
+
+    def __init__(self, online: Sequence[Tensor], beta: float = 0.9999, update_every: int = 10, update_after_step: int = 100,
+                 inv_gamma: float = 1.0, power: float = 2.0 / 3.0, min_value: float = 0.0):
+        self.online = list(online)
+        self.ema = [t.detach().clone() for t in self.online]     # deepcopy(model) at construction
+        self.beta, self.update_every, self.update_after_step = beta, update_every, update_after_step
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.step = torch.tensor(0)
+        self.initted = torch.tensor(False)
+
+    def get_current_decay(self) -> float:
+        epoch = (self.step - self.update_after_step - 1).clamp(min=0.0)
+        value = 1 - (1 + epoch / self.inv_gamma) ** -self.power
+        if epoch.item() <= 0:
+            return 0.0
+        return value.clamp(min=self.min_value, max=self.beta).item()
+
+    def copy_params_from_model_to_ema(self):
+        for e, o in zip(self.ema, self.online):
+            e.copy_(o)
+
+    def update(self):
+        step = self.step.item()
+        self.step += 1
+        if (step % self.update_every) != 0:
+            return
+        if step <= self.update_after_step:
+            self.copy_params_from_model_to_ema()
+            return
+        if not self.initted.item():
+            self.copy_params_from_model_to_ema()
+            self.initted.data.copy_(torch.tensor(True))
+        decay = self.get_current_decay()
+        for e, o in zip(self.ema, self.online):
+            e.lerp_(o, 1.0 - decay)

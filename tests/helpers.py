@@ -1,4 +1,7 @@
 """Shared helpers for the parity tests (not collected by pytest)."""
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -24,10 +27,56 @@ def to_torch(state):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}
 
 
-def rel_err(a, b):
+def _np64(a):
     a = a.detach().float().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
-    b = b.detach().float().cpu().numpy() if hasattr(b, "detach") else np.asarray(b)
-    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / (np.abs(b).max() + 1e-30))
+    return a.astype(np.float64)
+
+
+def rel_err(a, b):
+    a, b = _np64(a), _np64(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# The L-infinity metric above is relative to the LARGEST reference value: at 4e-2 of the range a systematically wrong
+# low-magnitude channel passes it.  bf16 acceptance therefore carries two scale-free metrics next to it (round-2 verdict, weak #2):
+TOL_BF16_L2 = 1.5e-2     # ||a - b||_2 / ||b||_2 over the whole tensor, per network
+TOL_BF16_COS = 0.999     # cosine between a and b, per channel (axis 1), worst channel
+
+
+def rel_l2(a, b):
+    a, b = _np64(a), _np64(b)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-300))
+
+
+def channel_cosine_min(a, b, axis=1):
+    """min over channels of <a_c, b_c> / (|a_c| |b_c|); a channel that is (numerically) zero in the reference is skipped."""
+    a, b = _np64(a), _np64(b)
+    if a.ndim <= axis:
+        a, b = a.reshape(1, -1), b.reshape(1, -1)
+        axis = 0
+    a = np.moveaxis(a, axis, 0).reshape(a.shape[axis], -1)
+    b = np.moveaxis(b, axis, 0).reshape(b.shape[axis], -1)
+    nb = np.linalg.norm(b, axis=1)
+    keep = nb > 1e-6 * (nb.max() + 1e-300)
+    cos = (a * b).sum(axis=1)[keep] / (np.linalg.norm(a, axis=1)[keep] * nb[keep] + 1e-300)
+    return float(cos.min()) if cos.size else 1.0
+
+
+def bf16_metrics(a, b, axis=1):
+    return {"linf": rel_err(a, b), "rel_l2": rel_l2(a, b), "min_channel_cos": channel_cosine_min(a, b, axis)}
+
+
+def assert_bf16_close(a, b, what="", linf=None, l2=None, cos=None, axis=1):
+    """bf16 acceptance of a network output: L-infinity (of range) AND relative L2 AND the worst per-channel cosine."""
+    m = bf16_metrics(a, b, axis)
+    if os.environ.get("DDMI_METRICS_LOG"):   # the numbers behind the thresholds, kept when a run asks for them
+        with open(os.environ["DDMI_METRICS_LOG"], "a") as f:
+            f.write(json.dumps({"what": what, **m}) + "\n")
+    linf = TOL_BF16 if linf is None else linf
+    l2 = TOL_BF16_L2 if l2 is None else l2
+    cos = TOL_BF16_COS if cos is None else cos
+    assert m["linf"] < linf and m["rel_l2"] < l2 and m["min_channel_cos"] > cos, (what, m)
+    return m
 
 # video (config 5, configs/ldm/skytimelapse.yaml + configs/d2c-vae/skytimelapse.yaml)
 SKY_UNET = dict(in_channels=64, model_channels=256, out_channels=64, attention_resolutions=[8, 4, 2], num_res_blocks=2,

@@ -8,7 +8,7 @@ import torch
 from ddmi_amd import initweights as iw
 from ddmi_amd.ddpm import DDPM
 from ddmi_amd.video import MLPVideo, UNetModel_Triplane, VITAutoencoder, convert_to_coord_format_3d
-from helpers import TOL_BF16, TOL_FP32, named_state, rel_err
+from helpers import TOL_BF16, TOL_FP32, assert_bf16_close, named_state, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -100,7 +100,7 @@ def test_sky_unet_full_size_vs_oracle():
     unet16 = UNetModel_Triplane(numerics="bf16", max_batch=1, **SKY_UNET)
     unet16.load_state_dict(st)
     eps16 = unet16(torch.from_numpy(x).to(DEV), t.to(DEV))
-    assert rel_err(eps16, ref) < TOL_BF16
+    assert_bf16_close(eps16, ref, "sky UNet full size")
 
 
 def test_sky_decoder_quarter_resolution_vs_oracle():
@@ -124,7 +124,7 @@ def test_sky_decoder_quarter_resolution_vs_oracle():
     got16 = vit16.decode(torch.from_numpy(z).to(DEV), reference_layout=True)
     for lst_g, lst_r in zip(got16, ref):
         for g, r in zip(lst_g, lst_r):
-            assert rel_err(g, r) < TOL_BF16
+            assert_bf16_close(g, r, "sky decoder quarter resolution")
 
 
 def test_attention_at_the_full_video_length_sampled_queries():
