@@ -117,6 +117,7 @@ SYMBOLS = {
     "ddmi_hdpe_mlpv": (_I, [_VP, C.POINTER(_VP), C.POINTER(_I), _I, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_mlpv_destroy": (_I, [_VP]),
     "ddmi_op_conv2d": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "ddmi_op_conv2d_skip": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_debug_conv_config": (_I, [_I]),
     "ddmi_op_attention_legacy_hd": (_I, [_VP, _VP, _I, _I, _I, _I, _I]),

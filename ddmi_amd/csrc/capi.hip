@@ -434,6 +434,85 @@ int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, 
   return DDMI_OK;
 }
 
+// conv3x3(x, w, b) + conv1x1(cat(xs1, xs2), ws, bs): a ResBlock's out_layers convolution plus its skip_connection
+// (openaimodel.py:272-275).  bf16: ONE launch, the 1x1 folded into the 3x3 kernel's K loop; fp32: two launches (the parity mode
+// keeps the reference's op order: the skip tensor is the second launch's residual).
+int ddmi_op_conv2d_skip(const float* x, const float* w, const float* bias, const float* xs1, const float* xs2, const float* ws,
+                        const float* bias_s, float* y, int B, int Cin, int H, int W, int Cout, int C2, int C3, int numerics, int splitk) {
+  int dt;
+  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  DDMI_REQUIRE(x && w && bias && xs1 && ws && bias_s && y && C2 > 0 && C3 >= 0 && (C3 == 0 || xs2), "op_conv2d_skip: bad arguments");
+  Scratch sc;
+  const int Cs = C2 + C3, hw = H * W;
+  void *xn, *wp, *yn, *s1, *s2 = nullptr, *w2, *skn = nullptr, *wsk = nullptr;
+  float* bsum = nullptr;
+  DDMI_TRY(sc.get((size_t)B * Cin * hw * dt_size(dt), &xn));
+  DDMI_TRY(sc.get((size_t)Cout * Cin * 9 * dt_size(dt), &wp));
+  DDMI_TRY(sc.get((size_t)B * Cout * hw * dt_size(dt), &yn));
+  DDMI_TRY(sc.get((size_t)B * C2 * hw * dt_size(dt), &s1));
+  if (C3) DDMI_TRY(sc.get((size_t)B * C3 * hw * dt_size(dt), &s2));
+  DDMI_TRY(sc.get((size_t)Cout * Cs * dt_size(dt), &w2));
+  DDMI_TRY(launch_nchw_to_nhwc(x, xn, dt, B, Cin, hw, 0));
+  DDMI_TRY(launch_nchw_to_nhwc(xs1, s1, dt, B, C2, hw, 0));
+  if (C3) DDMI_TRY(launch_nchw_to_nhwc(xs2, s2, dt, B, C3, hw, 0));
+  DDMI_TRY(launch_pack_conv_weight(w, wp, dt, Cout, Cin, 3, 3, 0));
+  DDMI_TRY(launch_pack_conv_weight(ws, w2, dt, Cout, Cs, 1, 1, 0));
+  ConvArgs a{};
+  a.x = xn; a.w = wp; a.y = yn;
+  a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W; a.Cin = Cin; a.Cout = Cout;
+  a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.out_scale = 1.f;
+  if (dt == DT_BF16) {
+    std::vector<float> b1(Cout), b2(Cout);
+    HIP_TRY(hipMemcpy(b1.data(), bias, Cout * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b2.data(), bias_s, Cout * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < Cout; ++i) b1[i] += b2[i];
+    DDMI_TRY(sc.get((size_t)Cout * sizeof(float), (void**)&bsum));
+    HIP_TRY(hipMemcpy(bsum, b1.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
+    a.bias = bsum;
+    a.x2 = s1; a.C2 = C2; a.x3 = s2; a.C3 = C3; a.w2 = w2;
+  } else {   // skip = conv1x1 over the two column blocks of ws, then the residual of the 3x3 launch
+    DDMI_TRY(sc.get((size_t)B * Cout * hw * dt_size(dt), &skn));
+    DDMI_TRY(sc.get((size_t)Cout * Cs * dt_size(dt), &wsk));
+    std::vector<float> hws((size_t)Cout * Cs), ha((size_t)Cout * C2), hb((size_t)Cout * std::max(C3, 1));
+    HIP_TRY(hipMemcpy(hws.data(), ws, hws.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int o = 0; o < Cout; ++o) {
+      std::copy(hws.begin() + (size_t)o * Cs, hws.begin() + (size_t)o * Cs + C2, ha.begin() + (size_t)o * C2);
+      if (C3) std::copy(hws.begin() + (size_t)o * Cs + C2, hws.begin() + (size_t)(o + 1) * Cs, hb.begin() + (size_t)o * C3);
+    }
+    float *da, *db = nullptr;
+    void *pa, *pb = nullptr;
+    DDMI_TRY(sc.get(ha.size() * sizeof(float), (void**)&da));
+    DDMI_TRY(sc.get(ha.size() * dt_size(dt), &pa));
+    HIP_TRY(hipMemcpy(da, ha.data(), ha.size() * sizeof(float), hipMemcpyHostToDevice));
+    DDMI_TRY(launch_pack_conv_weight(da, pa, dt, Cout, C2, 1, 1, 0));
+    ConvArgs k1{};
+    k1.x = s1; k1.w = pa; k1.bias = bias_s; k1.y = skn;
+    k1.B = B; k1.Hin = k1.Hout = H; k1.Win = k1.Wout = W; k1.Cin = C2; k1.Cout = Cout;
+    k1.KH = k1.KW = 1; k1.stride = 1; k1.pad = 0; k1.out_scale = 1.f; k1.splitk = 1;
+    DDMI_TRY(launch_conv(k1, dt, 0));
+    if (C3) {
+      DDMI_TRY(sc.get(hb.size() * sizeof(float), (void**)&db));
+      DDMI_TRY(sc.get(hb.size() * dt_size(dt), &pb));
+      HIP_TRY(hipMemcpy(db, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+      DDMI_TRY(launch_pack_conv_weight(db, pb, dt, Cout, C3, 1, 1, 0));
+      ConvArgs k2 = k1;
+      k2.x = s2; k2.w = pb; k2.bias = nullptr; k2.res = skn; k2.Cin = C3;
+      DDMI_TRY(launch_conv(k2, dt, 0));
+    }
+    a.bias = bias; a.res = skn;
+  }
+  a.splitk = splitk > 0 ? splitk : conv_pick_splitk(a, dt);
+  void* wsl = nullptr;
+  if (a.splitk > 1) {
+    DDMI_TRY(sc.get((size_t)a.splitk * B * hw * Cout * sizeof(float), &wsl));
+    a.splitk_ws = (float*)wsl;
+  }
+  DDMI_TRY(launch_conv(a, dt, 0));
+  DDMI_TRY(launch_nhwc_to_nchw(yn, dt, y, B, Cout, hw, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
 __global__ void fill_hash_kernel(unsigned* p, int64_t n_words, unsigned seed, int bf16) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {

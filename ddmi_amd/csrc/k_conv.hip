@@ -54,6 +54,12 @@ struct ConvK {
   uint64_t x_bytes;                         // activation extent in bytes (per batch entry); may exceed 2 GiB
   unsigned w_bytes;                         // weight extent (per batch entry) for the range check
   int64_t x_bstride, w_bstride, y_bstride;  // element strides for blockIdx.y (batched GEMM mode)
+  // folded 1x1 skip connection (halo kernel, SKIP instantiation): see ConvArgs
+  const void* x2;
+  const void* x3;
+  const void* w2;
+  int C2, C3;
+  unsigned w2_bytes;
 };
 
 template <typename T> struct Tile;
@@ -846,8 +852,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
 //   The halo of block cb+1 is fetched in eight pieces behind the barriers of taps 0..7 of block cb.
 // Loop structure, fragment double-buffering and the swizzle are those of the pipe kernel.
 // =====================================================================================================
+// SKIP instantiation: the ResBlock's 1x1 skip_connection rides on the same accumulators.  The 64-channel blocks of the skip
+// sources x2 (| x3) are appended to the block list as ONE-stage blocks: their halo is staged like any other block's (the border
+// rows are fetched and never read), the single stage reads it at the centre tap's shift and takes its weight stage from
+// w2 [Cout][C2 + C3].  Same loop, same pipeline; skip halos are fetched whole and two blocks ahead (see the refill).
+// What it replaces: a separate 1x1 launch at 0.4-0.6 PFLOP/s that wrote the skip tensor (HBM-bound at 64x64) plus this kernel's
+// epilogue reading it back as the residual.  Split z = 0 carries the skip blocks.
 #define HALO_MAX_ROWS 400  // 6 x 66 = 396 rows at W = 64, rounded up to whole 8-row DMA groups (the tail lanes write zeros)
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool SKIP>
 __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   using T = bf16_t;
   constexpr int BM = 256, NW = WM * WN;
@@ -863,7 +875,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  unsigned long long* const ts = a.ts && tid == 0 && blockIdx.z == 0 ? a.ts + 8 * blockIdx.x : nullptr;
+  unsigned long long* const ts = !SKIP && a.ts && tid == 0 && blockIdx.z == 0 ? a.ts + 8 * blockIdx.x : nullptr;
   if (ts) {
     ts[0] = wall_clock64();
     ts[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) |   // XCC_ID
@@ -890,35 +902,82 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_extent, 0x00020000);
   auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
 
+  // ---- the block list of this workgroup: its split's 64-channel blocks of x (nine stages each), then - SKIP, split 0 - the blocks
+  // of the skip sources (one stage each).  split-K: whole blocks per split (SPS is a multiple of 9)
+  const int cb_begin = (blockIdx.z * a.SPS) / 9;
+  const int cb_end = min(NCB, cb_begin + a.SPS / 9);
+  const int nmain = max(cb_end - cb_begin, 0);
+  int NCB2 = 0, nsk = 0;
+  if constexpr (SKIP) {
+    if (blockIdx.z == 0) {
+      NCB2 = (a.C2 + 63) >> 6;
+      nsk = NCB2 + ((a.C3 + 63) >> 6);
+    }
+  }
+  const int nblk = nmain + nsk, nstage = nmain * 9 + nsk;
+  // block -> (64-channel block inside its source, the source's channel count); scalar
+  auto blk_cbl = [&](int blk) {
+    if (!SKIP || blk < nmain) return cb_begin + blk;
+    const int j = blk - nmain;
+    return j >= NCB2 ? j - NCB2 : j;
+  };
+  auto blk_C = [&](int blk) {
+    if (!SKIP || blk < nmain) return a.Cin;
+    return blk - nmain >= NCB2 ? a.C3 : a.C2;
+  };
+
   // weight rows: lane owns physical slot lane&7 of row (lane>>3) of its 8-row group; one channel offset per lane
   const int coff = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 8;
   const int b_row0 = wave * 8 + (lane >> 3);             // group i adds 8*NW rows (a scalar step)
   const int b_base0 = (n0 * Ktot + coff) * SZ;   // + weight row * Ktot * SZ per load
   // halo group g: 8 halo rows hr = 8g + (lane>>3); the slot swizzle depends on hr, so the channel offset does too
-  auto load_halo_group = [&](int g, int cb, int hbuf) {
+  auto load_halo_group = [&](int g, int blk, int hbuf) {
     const int hr = g * 8 + (lane >> 3);
     int sb = 0, rem = hr;                           // sample block of the tile, halo row inside it
     if (SPT > 1) { sb = hr / HRS; rem = hr - sb * HRS; }
     const int hy = rem / HWd, hx = rem - hy * HWd;
     const int iy = ty0 - 1 + hy, ix = hx - 1;
-    const int ch = cb * 64 + (((lane & 7) ^ ((hr >> 1) & 7)) << 3);
-    const int ok = (hr < NH) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W) & (ch < a.Cin);
+    const int C = blk_C(blk);
+    const int ch = blk_cbl(blk) * 64 + (((lane & 7) ^ ((hr >> 1) & 7)) << 3);
+    const int ok = (hr < NH) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W) & (ch < C);
     // samples past the batch end fall outside the descriptor's extent and read as zeros
-    const unsigned voff = ok ? (unsigned)(((sb * hw + iy * W + ix) * a.Cin + ch) * SZ) : OOB_OFFSET;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
+    const unsigned voff = ok ? (unsigned)(((sb * hw + iy * W + ix) * C + ch) * SZ) : OOB_OFFSET;
+    auto rs = x_rsrc;
+    if constexpr (SKIP) {
+      if (blk >= nmain) {   // a skip source: its descriptor is built here from scalars (rebased like x's at the tile's first sample)
+        const T* base = (const T*)(blk - nmain >= NCB2 ? a.x3 : a.x2) + (int64_t)b_first * hw * C;
+        const uint64_t r = (uint64_t)(a.B - b_first) * hw * C * sizeof(T);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, r > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)r, 0x00020000);
+      }
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
   };
-  auto load_b_stage = [&](int cb, int tap, int bbuf, bool valid) {
-    const int c0 = cb * 64;
-    const int cvalid = valid & (c0 + coff < a.Cin);
-    const int delta = (tap * a.Cin + c0) * SZ;
+  auto load_b_stage = [&](int blk, int tap, int bbuf, bool valid) {
+    int cvalid, rstride, col, base = b_base0;
+    auto rs = w_rsrc;
+    if (!SKIP || blk < nmain) {
+      const int c0 = (cb_begin + blk) * 64;
+      cvalid = valid & (c0 + coff < a.Cin);
+      rstride = Ktot * SZ;
+      col = (tap * a.Cin + c0) * SZ;
+    } else {   // w2 [Cout][C2 + C3]: columns of block j; a ragged last block of x2 must not read x3's columns
+      const int j = blk - nmain, Cs = a.C2 + a.C3;
+      const bool second = j >= NCB2;
+      const int col0 = second ? a.C2 + (j - NCB2) * 64 : j * 64;
+      cvalid = valid & (col0 + coff < (second ? Cs : a.C2));
+      rstride = Cs * SZ;
+      col = col0 * SZ;
+      base = (n0 * Cs + coff) * SZ;
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, a.w2_bytes, 0x00020000);
+    }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int g = i * NW + wave;
       if (g < GB) {
         const int brow = lds_row_chan<TN>(b_row0 + i * 8 * NW);  // LDS row -> weight row of the paired layout
         int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + brow < a.Cout);
-        unsigned voff = ok ? (unsigned)(b_base0 + brow * Ktot * SZ + delta) : OOB_OFFSET;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(BB + bbuf * B_BYTES + g * 1024), 16, voff, 0, 0, 0);
+        unsigned voff = ok ? (unsigned)(base + brow * rstride + col) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(BB + bbuf * B_BYTES + g * 1024), 16, voff, 0, 0, 0);
       }
     }
   };
@@ -962,28 +1021,25 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
   };
 
-  // split-K: whole 64-channel blocks per split (SPS is a multiple of 9)
-  const int cb_begin = (blockIdx.z * a.SPS) / 9;
-  const int cb_end = min(NCB, cb_begin + a.SPS / 9);
-  const int nstage = (cb_end - cb_begin) * 9;
   bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
 
   if (ts) ts[1] = wall_clock64();
-  if (nstage > 0) {
-    for (int g = wave; g < GH; g += NW) load_halo_group(g, cb_begin, 0);
-    load_b_stage(cb_begin, 0, 0, true);
-    load_b_stage(cb_begin, 1, 1, true);
+  if (nstage > 0) {   // (split 0 always has blocks of x, so stages 0 and 1 are taps 0 and 1 of block 0)
+    for (int g = wave; g < GH; g += NW) load_halo_group(g, 0, 0);
+    load_b_stage(0, 0, 0, true);
+    load_b_stage(0, 1, 1, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ts) ts[2] = wall_clock64();
     read_frags(0, 0, 0, 0, xa, wa);
   }
-  // one flat stage loop; (cb, tap, kw, shift, hbuf) are scalar state so nothing per-tap gets unrolled or hoisted
-  int cb = cb_begin, tap = 0, kw = 0, shift = 0, hbuf = 0;
+  // one flat stage loop; (blk, tap, kw, shift, hbuf) are scalar state so nothing per-tap gets unrolled or hoisted
+  int blk = 0, tap = 0, kw = 0, shift = 0, hbuf = 0;
 #pragma unroll 1
   for (int st = 0; st < nstage; ++st) {
     const int bbuf = st & 1;
-    const bool c1 = cb * 64 + 32 < a.Cin;
+    const bool c1 = blk_cbl(blk) * 64 + 32 < blk_C(blk);
+    const bool one_stage = SKIP && blk >= nmain;   // a skip block: centre tap only
     // [A] chunk 0 of this stage on set a, prefetch chunk 1 into set b
     read_frags(hbuf, bbuf, shift, 1, xb, wb);
     mma(xa, wa);
@@ -991,16 +1047,36 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     __builtin_amdgcn_s_barrier();  // next weight stage + halo pieces issued a stage ago have landed; BB[bbuf] is free
     {  // refill right behind the barrier (issuing later - e.g. staggering the two waves of a SIMD - measured 10 % slower:
        // the pieces then land after the next barrier's vmcnt(0)): weight stage st+2 into BB[bbuf], one halo piece
-      int t2 = tap + 2, cb2 = cb;
-      if (t2 >= 9) { t2 -= 9; ++cb2; }
-      load_b_stage(cb2, t2, bbuf, cb2 < cb_end);
+      int t2 = tap + 2, b2 = blk;   // the stage two ahead: taps of this block, then of the next (a skip block is one stage long)
+      if (one_stage) {
+        t2 = 0; b2 = blk + 2;
+      } else if (t2 >= 9) {
+        t2 -= 9; ++b2;
+        if (SKIP && b2 >= nmain) { b2 += t2; t2 = 0; }
+      }
+      load_b_stage(b2, t2, bbuf, b2 < nblk);
+      // halo prefetch.  A nine-stage block fetches its successor's halo in eight pieces behind taps 0..7.  A one-stage block has
+      // no such lead for ITS successor (the stage after the barrier already reads it), so one-stage blocks are fetched TWO blocks
+      // ahead: whole, into the halo buffer this barrier has just released (the current block's chunk-1 reads are retired) - behind
+      // the last barrier of the last nine-stage block and behind the barrier of every one-stage block.
       const int q = tap * NW + wave;
-      if (tap < 8 && q < GH && cb + 1 < cb_end) load_halo_group(q, cb + 1, hbuf ^ 1);
+      if (!one_stage && tap < 8) {
+        if (blk + 1 < nblk && q < GH) load_halo_group(q, blk + 1, hbuf ^ 1);
+      } else if (SKIP && blk + 1 >= nmain && blk + 2 < nblk) {
+        for (int g = wave; g < GH; g += NW) load_halo_group(g, blk + 2, hbuf);
+      }
     }
     // advance the scalar state to the next stage
-    ++tap;
-    if (++kw == 3) { kw = 0; shift += HWd - 2; } else { ++shift; }
-    if (tap == 9) { tap = 0; shift = 0; ++cb; hbuf ^= 1; }
+    if (!one_stage) {
+      ++tap;
+      if (++kw == 3) { kw = 0; shift += HWd - 2; } else { ++shift; }
+      if (tap == 9) {
+        tap = 0; shift = 0; ++blk; hbuf ^= 1;
+        if (SKIP && blk >= nmain) shift = HWd + 1;   // skip blocks are read at the centre tap
+      }
+    } else {
+      ++blk; hbuf ^= 1;
+    }
     // [B] chunk 1 on set b, prefetch chunk 0 of the next stage into set a
     if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, 0, xa, wa);
     if (c1) mma(xb, wb);
@@ -1299,14 +1375,20 @@ static const RingCfg kRing[] = {
     {256, 224, -2},  // 19: halo<224,4,2> 8 waves, per-wave 64x112, 155 KB  (kps -2: halo kernel, 3x3 s1 p1, W in 16..64)
     {256, 128, -2},  // 20: halo<128,4,2> 8 waves, per-wave 64x64,  131 KB
 };
-static bool halo_ok(const ConvArgs& a) {
-  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hout == a.Hin && a.Wout == a.Win)) return false;
-  if (!(a.Win == 8 || a.Win == 16 || a.Win == 32 || a.Win == 64)) return false;
-  const int hw = a.Hin * a.Win;
+bool conv_halo_shape_ok(int H, int W) {
+  if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
+  const int hw = H * W;
   if (hw % 256 == 0) return true;                       // TR whole rows of one sample
   if (hw != 64 && hw != 128) return false;              // whole samples per tile, 64 pixels per wave inside one sample
-  return (256 / hw) * (a.Hin + 2) * (a.Win + 2) <= HALO_MAX_ROWS;
+  return (256 / hw) * (H + 2) * (W + 2) <= HALO_MAX_ROWS;
 }
+static bool halo_ok(const ConvArgs& a) {
+  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hout == a.Hin && a.Wout == a.Win)) return false;
+  return conv_halo_shape_ok(a.Hin, a.Win);
+}
+// a launch with a folded skip connection exists on the halo kernel only: the tuned / heuristic tile when it is one, else the
+// halo configuration that fits Cout
+static int skip_fold_cfg(const ConvArgs& a) { return a.Cout > 128 ? 19 : 20; }
 static const int kHaloFallback = 13;
 static const int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 struct TileCfg { int bm, bn, kps, id; };  // id < 0: fp32 kernel tile
@@ -1369,6 +1451,8 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   DDMI_REQUIRE(wb < 0x80000000ull && (span < 0x7FFFFFFFull || xb < 0x7FFFFFFFull), "conv: tensor exceeds the 2 GiB buffer-descriptor range");
   k.x_bytes = xb;
   k.w_bytes = (unsigned)wb;
+  k.x2 = a.x2; k.x3 = a.C3 > 0 ? a.x3 : nullptr; k.w2 = a.w2; k.C2 = a.x2 ? a.C2 : 0; k.C3 = a.x2 && a.x3 ? a.C3 : 0;
+  k.w2_bytes = (unsigned)((uint64_t)a.Cout * (k.C2 + k.C3) * dt_size(dt));
   *out = k;
   return DDMI_OK;
 }
@@ -1380,6 +1464,7 @@ int conv_pick_splitk(const ConvArgs& a, int dt) {
   if (a.ups == 3) return 1;
   int M = a.B * a.Hout * a.Wout;
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
+  if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   int tiles = cdiv(M, t.bm) * cdiv(a.Cout, t.bn);
   int NS = t.kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(cdiv(a.Cin, 32) * a.KH * a.KW, t.kps);
   if (tiles >= 192 || NS < 16) return 1;
@@ -1391,8 +1476,9 @@ int conv_pick_splitk(const ConvArgs& a, int dt) {
 static void conv_work(const ConvK& k, int batch, int esz, double* flops, double* bytes) {
   // algorithmic work of one launch: 2*M*N*K flops; operands + output once
   const double Kdim = (double)k.KH * k.KW * k.Cin, Mtot = (double)k.M * batch;
-  *flops = 2.0 * Mtot * k.Cout * Kdim;
-  *bytes = esz * ((double)batch * k.B * k.Hin * k.Win * k.Cin + (double)k.Cout * Kdim * (k.w_bstride ? batch : 1) + Mtot * k.Cout);
+  const double Ks = k.x2 ? (double)(k.C2 + k.C3) : 0.0;   // folded skip connection: Ks more K columns, its sources read once
+  *flops = 2.0 * Mtot * k.Cout * (Kdim + Ks);
+  *bytes = esz * ((double)batch * k.B * k.Hin * k.Win * k.Cin + (double)k.Cout * (Kdim + Ks) * (k.w_bstride ? batch : 1) + Mtot * (k.Cout + Ks));
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KPS>
@@ -1530,19 +1616,23 @@ static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
   DDMI_REQUIRE(batch == 1, "halo kernel: no batched-GEMM mode");
   k.tiles_n = cdiv(k.Cout, BN);
   dim3 grid(cdiv(k.M, 256) * k.tiles_n, 1, splitk);
-  auto kern = conv_halo_kernel<BN, WM, WN>;
+  auto kern = conv_halo_kernel<BN, WM, WN, false>;
+  auto kern_skip = conv_halo_kernel<BN, WM, WN, true>;   // + the folded 1x1 skip connection
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_skip), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   {
     double flops, bytes;
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_halo<bf16,256x" + std::to_string(BN) + ">";
-    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    static const std::string name_skip = "conv_halo+skip<bf16,256x" + std::to_string(BN) + ">";
+    PROF_SCOPE(k.x2 ? name_skip.c_str() : name.c_str(), flops, bytes, s);
     k.ts = conv_ts_buffer((int)grid.x);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+    if (k.x2) hipLaunchKernelGGL(kern_skip, grid, dim3(WM * WN * 64), lds, s, k);
+    else hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
   static int ts_launch = 0;
@@ -1600,6 +1690,11 @@ static int check_conv(const ConvArgs& a, int dt) {
     return DDMI_OK;
   }
   DDMI_REQUIRE((a.KH == 1 && a.KW == 1) || (a.KH == 3 && a.KW == 3), "conv: kernel must be 1x1 or 3x3");
+  if (a.x2) {
+    DDMI_REQUIRE(dt == DT_BF16 && halo_ok(a), "conv: a folded skip connection needs a bf16 3x3 / stride 1 shape of the halo kernel");
+    DDMI_REQUIRE(a.w2 && a.C2 > 0 && a.C2 % 8 == 0 && a.C3 >= 0 && a.C3 % 8 == 0 && (a.C3 == 0 || a.x3), "conv: bad skip sources");
+    DDMI_REQUIRE(!a.y_nchw && !a.res, "conv: a folded skip connection replaces the residual");
+  }
   int hin = a.ups == 1 ? 2 * a.Hin : a.Hin, win = a.ups ? 2 * a.Win : a.Win;
   DDMI_REQUIRE(a.Hout == (hin + 2 * a.pad - a.KH) / a.stride + 1 && a.Wout == (win + 2 * a.pad - a.KW) / a.stride + 1,
                "conv: output size mismatch");
@@ -1620,6 +1715,7 @@ int conv_chstat_rows(const ConvArgs& a, int dt) {
   const int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
+  if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   if (t.id < 0) return 0;
   const bool paired = t.kps != -1 || a.order > 2 || (a.order == 0 && a.KH * a.KW == 1);   // ring and halo kernels always are
   const int TM = kRingWave[t.id][0], TN = kRingWave[t.id][1], hw = a.Hout * a.Wout;
@@ -1634,6 +1730,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
+  if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
   // order: 1 tap-major, 2 channel-major, +2 = paired-fragment instantiation of the pipe kernel; 0 = heuristic
@@ -1704,6 +1801,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
   for (int id = 0; id < kNumRing; ++id) {
     const RingCfg& rc = kRing[id];
     if (rc.kps == -2 && !halo_ok(a0)) continue;
+    if (a0.x2 && rc.kps != -2) continue;   // a folded skip connection runs on the halo kernel only
     // prune: tile width must fit Cout without more than ~15 % padding; tile height not larger than 2x the problem
     int padded = cdiv(a0.Cout, rc.bn) * rc.bn;
     if (padded * 100 > a0.Cout * 115 && !(a0.Cout <= 64 && rc.bn == 64)) continue;

@@ -88,9 +88,17 @@ struct ConvArgs {
   int tile_map;       // blockIdx -> tile: 0 = heuristic, -1 = row-major, 1 / 2 = XCD-contiguous m-major / n-major (k_conv.hip)
   float* chstat;      // optional: per-channel (sum, sum of squares) of the stored output per block of conv_chstat_rows() rows,
                       // [M / rows][Cout][2] fp32 - the consumer GroupNorm's statistics without a pass over the tensor
+  // ResBlock skip_connection folded into the K loop (bf16 halo kernel only): y += w2 . [x2 | x3] at the centre tap, i.e. the
+  // 1x1 convolution of openaimodel.py:272-275 (`self.skip_connection(x) + h`) as C2 + C3 more K columns of this 3x3 convolution
+  const void* x2;     // [B, Hout, Wout, C2] NHWC or null
+  const void* x3;     // [B, Hout, Wout, C3] or null: the second source of a channel-concatenated block input
+  const void* w2;     // [Cout][C2 + C3] packed 1x1 weights
+  int C2, C3;
 };
+// the 3x3 / stride 1 shapes the halo kernel (and with it the folded skip connection) serves
+bool conv_halo_shape_ok(int H, int W);
 // bump when the meaning of (cfg, order) changes: plan files written for other tables are ignored (net.hip)
-#define CONV_PLAN_VERSION 2
+#define CONV_PLAN_VERSION 3
 struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // result of conv_autotune (0 = heuristic)
 // times the candidate (configuration, K order, split-K) triples on the real buffers and returns the fastest;
 // `ws`/`ws_bytes`: split-K slab scratch for the trials.  Synchronises; only called at finalize.

@@ -54,6 +54,7 @@ int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW*
     }
     DDMI_TRY(n.make_conv_host(wa, cout, split, 1, &bt->data, &w->cs));
     DDMI_TRY(n.make_conv_host(wb, cout, cin - split, 1, nullptr, &w->cs2));
+    DDMI_TRY(n.make_conv(pre + "skip_connection.weight", pre + "skip_connection.bias", &w->cs_full));
   } else if (cin != cout) {
     DDMI_TRY(n.make_conv(pre + "skip_connection.weight", pre + "skip_connection.bias", &w->cs));
     DDMI_REQUIRE(n.convs[w->cs].K == 1, "only 1x1 skip connections are supported (use_conv=False)");
@@ -66,22 +67,29 @@ int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW*
 int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out) {
   DDMI_REQUIRE(w.cs >= 0 && w.cs2 >= 0, "concat-free ResBlock needs a split skip connection");
   DDMI_REQUIRE(n.tensors[x1].C + n.tensors[x2].C == n.convs[w.c1].Cin, "resblock input channel mismatch");
-  int sk = n.op_conv(x1, w.cs, 1, 0, -1, -1);
-  sk = n.op_conv(x2, w.cs2, 1, 0, sk, -1);
+  const bool fold = w.cs_full >= 0 && n.can_fold_skip(x1, w.c2);   // skip_connection as extra K columns of conv2 (k_conv.hip)
+  int sk = -1;
+  if (!fold) {
+    sk = n.op_conv(x1, w.cs, 1, 0, -1, -1);
+    sk = n.op_conv(x2, w.cs2, 1, 0, sk, -1);
+  }
   int a = n.op_gn(x1, w.gn1, 1, w.eps, x2);
   int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off);
   int b = n.op_gn(h, w.gn2, 1, w.eps);
+  if (fold) return n.op_conv_skip(b, w.c2, x1, x2, w.cs_full, out);
   *out = n.op_conv(b, w.c2, 1, 0, sk, -1);
   return DDMI_OK;
 }
 
 int emit_resblock(Net& n, const ResW& w, int x, int* out) {
   DDMI_REQUIRE(n.tensors[x].C == n.convs[w.c1].Cin, "resblock input channel mismatch");
+  const bool fold = w.cs >= 0 && w.cs2 < 0 && n.convs[w.cs].K == 1 && n.can_fold_skip(x, w.c2);
   int skip = x;
-  if (w.cs >= 0) skip = n.op_conv(x, w.cs, 1, 0, -1, -1);
+  if (w.cs >= 0 && !fold) skip = n.op_conv(x, w.cs, 1, 0, -1, -1);
   int a = n.op_gn(x, w.gn1, 1, w.eps);
   int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off);
   int b = n.op_gn(h, w.gn2, 1, w.eps);
+  if (fold) return n.op_conv_skip(b, w.c2, x, -1, w.cs, out);
   *out = n.op_conv(b, w.c2, 1, 0, skip, -1);
   return DDMI_OK;
 }

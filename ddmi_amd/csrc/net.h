@@ -63,6 +63,11 @@ struct Op {
   // GroupNorm statistics out of the producer's epilogue (plan()): OP_CONV writes per-channel sums of its output into tensor
   // `stat_out`; OP_GN reads the ones of its input(s) instead of running the statistics pass when every producer delivered
   int stat_out = -1, stat_in = -1, stat_in2 = -1;
+  // OP_CONV with the ResBlock's 1x1 skip_connection folded into its K loop (bf16, halo-kernel shapes): the block input(s)
+  // `skip_in` (| `skip_in2`: the second half of a channel-concatenated input), the un-split 1x1 weights `skip_conv`, and the
+  // summed bias of both convolutions
+  int skip_in = -1, skip_in2 = -1, skip_conv = -1;
+  const float* bias_fused = nullptr;
   float scale = 1.f;
   ConvPlan tuned;     // OP_CONV: autotuned launch plan for B == max_batch (cfg 0 = heuristic)
   // tri-plane networks stack the three planes (shared weights) along the batch axis: an op runs on bmul * B samples;
@@ -111,6 +116,9 @@ struct Net {
   int make_gn(const std::string& prefix, int* idx);
   int op_gn(int in, int gn, int silu, float eps, int in2 = -1);  // in2 >= 0: GroupNorm of the channel concat [in | in2]
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
+  // conv3x3(in) + conv1x1([skip_in | skip_in2]) in one launch; false when this network / shape cannot fold (caller emits the two ops)
+  bool can_fold_skip(int in, int conv) const;
+  int op_conv_skip(int in, int conv, int skip_in, int skip_in2, int skip_conv, int* out);
   int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
   int pack_up4_weights();  // parity-form weights of the marked upsample convolutions (called by plan)
   void attach_channel_stats();  // pairs GroupNorm inputs with the convolutions that produce them (called by plan)

@@ -169,6 +169,29 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
   return o.out;
 }
 
+bool Net::can_fold_skip(int in, int conv) const {
+  static const bool off = getenv("DDMI_SKIP_FOLD") && atoi(getenv("DDMI_SKIP_FOLD")) == 0;   // diagnostics: A/B against the separate 1x1 launch
+  const TensorDesc& t = tensors[in];
+  return !off && dt == DT_BF16 && convs[conv].K == 3 && t.bmul == 1 && conv_halo_shape_ok(t.H, t.W);
+}
+
+int Net::op_conv_skip(int in, int conv, int skip_in, int skip_in2, int skip_conv, int* out) {
+  const ConvW &c = convs[conv], &cs = convs[skip_conv];
+  const int Cs = tensors[skip_in].C + (skip_in2 >= 0 ? tensors[skip_in2].C : 0);
+  DDMI_REQUIRE(can_fold_skip(in, conv), "op_conv_skip: shape cannot fold");
+  DDMI_REQUIRE(cs.K == 1 && cs.Cin == Cs && cs.Cout == c.Cout && c.bias && cs.bias, "op_conv_skip: skip weights do not match");
+  std::vector<float> b1(c.Cout), b2(c.Cout);
+  HIP_TRY(hipMemcpy(b1.data(), c.bias, c.Cout * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b2.data(), cs.bias, c.Cout * sizeof(float), hipMemcpyDeviceToHost));
+  for (int i = 0; i < c.Cout; ++i) b1[i] += b2[i];
+  float* bf = nullptr;
+  DDMI_TRY(dev_upload(b1.data(), c.Cout, &bf));
+  *out = op_conv(in, conv, 1, 0, -1, -1);
+  Op& o = ops.back();
+  o.skip_in = skip_in; o.skip_in2 = skip_in2; o.skip_conv = skip_conv; o.bias_fused = bf;
+  return DDMI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   const TensorDesc& ti = n.tensors[o.in];
@@ -188,6 +211,12 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   }
   a->out_scale = o.scale;
   a->splitk = 1;
+  if (o.skip_conv >= 0) {
+    a->x2 = n.tptr(o.skip_in); a->C2 = n.tensors[o.skip_in].C;
+    if (o.skip_in2 >= 0) { a->x3 = n.tptr(o.skip_in2); a->C3 = n.tensors[o.skip_in2].C; }
+    a->w2 = n.convs[o.skip_conv].w;
+    a->bias = o.bias_fused;
+  }
 }
 
 // parity-form weights [4][Cout][4][Cin] of the convolutions op_conv marked (want_up4); every failure is returned
@@ -270,7 +299,7 @@ int Net::plan() {
   };
   for (int i = 0; i < nops; ++i) {
     const Op& o = ops[i];
-    touch(o.in, i, false); touch(o.in2, i, false); touch(o.res, i, false);
+    touch(o.in, i, false); touch(o.in2, i, false); touch(o.res, i, false); touch(o.skip_in, i, false); touch(o.skip_in2, i, false);
     touch(o.out, i, true); touch(o.out2, i, true); touch(o.tmp0, i, true); touch(o.tmp1, i, true); touch(o.tmp2, i, true);
     touch(o.stat_out, i, true); touch(o.stat_in, i, false); touch(o.stat_in2, i, false);
   }
@@ -355,7 +384,7 @@ int Net::plan() {
     float* tws = nullptr;
     HIP_TRY(hipMalloc((void**)&tws, tws_bytes));
     std::map<std::vector<int>, ConvPlan> cache;
-    // plan files: one line per shape "B Hin Win Cin Cout K stride ups cfg order splitk us" after a "v <CONV_PLAN_VERSION>"
+    // plan files: one line per shape "B Hin Win Cin Cout K stride ups skipC cfg order splitk us" after a "v <CONV_PLAN_VERSION>"
     // header (a file written for other kernel tables is ignored).  DDMI_TUNE_FILE = read-write cache (new shapes are
     // appended); DDMI_TUNE_DEFAULT = the read-only plans shipped with the package (ddmi_amd/tuned/), consulted for
     // shapes the cache does not hold.  Timing-based picks differ from run to run; pinned plans make bf16 results
@@ -365,13 +394,13 @@ int Net::plan() {
       if (!f) return;
       int ver = -1;
       if (fscanf(f, " v %d", &ver) == 1 && ver == CONV_PLAN_VERSION) {
-        int v[11];
+        int v[12];
         float us;
-        while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7],
-                      &v[8], &v[9], &v[10], &us) == 12) {
+        while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7],
+                      &v[8], &v[9], &v[10], &v[11], &us) == 13) {
           ConvPlan p;
-          p.cfg = v[8]; p.order = v[9]; p.splitk = v[10]; p.us = us;
-          std::vector<int> key(v, v + 8);
+          p.cfg = v[9]; p.order = v[10]; p.splitk = v[11]; p.us = us;
+          std::vector<int> key(v, v + 9);
           if (overwrite || !cache.count(key)) cache[key] = p;
         }
       }
@@ -388,7 +417,7 @@ int Net::plan() {
       ConvArgs a;
       fill_conv_args(*this, o, max_batch * o.bmul, &a);
       a.y = tptr(o.out);  // timing only: results are overwritten by the real run
-      std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups};
+      std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups, a.x2 ? a.C2 + a.C3 : 0};   // last: folded skip channels
       auto it = cache.find(key);
       if (it == cache.end()) {
         ConvPlan p;

@@ -290,6 +290,14 @@ int ddmi_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W,
 /* F.conv2d(x, w, b, stride, padding=k/2) optionally preceded by nearest x2 upsampling; k in {1,3} */
 int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                    int Cout, int k, int stride, int upsample, int numerics, int splitk);
+/* conv3x3(x, w, bias) + conv1x1(cat([xs1, xs2], 1), ws, bias_s): a ResBlock's last convolution plus its skip_connection
+ * (models/ldm/modules/diffusionmodules/openaimodel.py:272-275, `self.skip_connection(x) + h`; xs2 / C3 = 0 when the block
+ * input is one tensor, two tensors for the `th.cat([h, hs.pop()], dim=1)` input of :787).  In bf16 mode it is ONE launch:
+ * the 1x1 convolution is folded into the 3x3 kernel's K loop (shapes of the halo kernel: W in {8,16,32,64}); fp32 runs the
+ * launches the reference's op order implies.  ws is [Cout, C2 + C3] (the skip_connection weight with its 1x1 dims dropped). */
+int ddmi_op_conv2d_skip(const float* x, const float* w, const float* bias, const float* xs1, const float* xs2, const float* ws,
+                        const float* bias_s, float* y, int B, int Cin, int H, int W, int Cout, int C2, int C3, int numerics,
+                        int splitk);
 /* micro-benchmark of one convolution shape on device-resident pseudo-random data (average ms per launch);
  * force_bm/force_bn = 0 lets the library pick the tile; splitk = 0 lets it pick the split */
 int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, int upsample, int numerics, int splitk,

@@ -29,6 +29,8 @@ for st in "$@"; do
     benchtrain64) timeout 1200 python bench.py --workload train --batch 64 --steps 3 --warmup 1 > gpurun_out/${tag}_bench_train64.json 2> $log ;;
     benchsky)  timeout 1200 python bench.py --workload sky --steps 1 --warmup 0 > gpurun_out/${tag}_bench_sky.json 2> $log ;;
     benchq)    timeout 900 python bench.py --nfe 10 --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchq.json 2> $log ;;
+    r3tests)   timeout 1200 python -m pytest tests/test_gpu_round3.py -q -x > $log 2>&1 ;;
+    benchq0)   DDMI_SKIP_FOLD=0 timeout 900 python bench.py --nfe 10 --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchq0.json 2> $log ;;
     attnbench) timeout 300 python tools/bench_attn_mh.py 128 > $log 2>&1 ;;
     *) echo "unknown stage $st" ;;
   esac
