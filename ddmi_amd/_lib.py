@@ -143,6 +143,7 @@ SYMBOLS = {
     "ddmi_train_linear_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_linear_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_accumulate_next": (_I, [_VP, _I]),
+    "ddmi_train_arena_generation": (_I, [_VP, _VP]),
     "ddmi_train_matmul": (_I, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, _VP, _I, _I, _I, _VP]),
     "ddmi_train_timestep_embedding": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "ddmi_train_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _I, C.c_int64, _VP]),

@@ -445,7 +445,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
 // =====================================================================================================
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int KPS, int NST>
+// ILV: the refill's DMA instructions are issued BETWEEN the MFMA groups of the stage instead of in one burst behind the barrier.
+// A stage of a 1x1 convolution fills 30 KB of LDS for 28 MFMAs per wave: in a burst every wave of the CU queues on the address
+// unit at once and no wave feeds the matrix pipe meanwhile (the 448 -> 1344 qkv conv: MFMA alone 286 us, DMA alone 203, together
+// 489).  The ring is NST deep with counted vmcnt, so a piece issued anywhere inside stage s is in time for stage s + NST - 1.
+template <int BM, int BN, int WM, int WN, int KPS, int NST, bool ILV = false>
 __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   using T = bf16_t;
   constexpr int NT = WM * WN * 64, NW = WM * WN;
@@ -530,6 +534,46 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
   const int r0 = a.chan_major ? a.KW : a.CPT, r1 = a.chan_major ? a.KH : a.KW;
   int d0 = kc_next % r0, d1 = (kc_next / r0) % r1, d2 = kc_next / (r0 * r1);
 
+  // one DMA instruction of chunk c of a stage: piece p < A_PER = activation row group p, else weight row group p - A_PER
+  auto load_piece = [&](unsigned char* sbase, int c, int p) {
+    const int kvalid = kc_next < a.NK;
+    const int q_kw = a.chan_major ? d0 : d1, q_kh = a.chan_major ? d1 : d2, q_ci = a.chan_major ? d2 : d0;
+    const int c0 = q_ci * 32;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      if (i != p) continue;
+      const int a_delta = ((q_kh * a.Win + q_kw) * a.Cin + c0) * SZ;
+      int ih = a_ih0[i] + q_kh, iw = a_iw0[i] + q_kw;
+      int ok = a_ok[i] & kvalid & (c0 + a_coff[i] < a.Cin) & ((unsigned)ih < (unsigned)Hlim) &
+               ((unsigned)iw < (unsigned)Wlim);
+      int off = a_base[i] + a_delta;
+      if (a.ups) off = ((a_pix[i] + (ih >> ush) * a.Win + (iw >> usw)) * a.Cin + c0 + a_coff[i]) * SZ;
+      unsigned voff = ok ? (unsigned)off : OOB_OFFSET;
+      const int g = i * NW + wave;  // wave-uniform
+      unsigned char* dst = g < GA ? sbase + c * (BM * ROWB) + g * 1024 : smem + SCRATCH + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      if (i + A_PER != p) continue;
+      const int b_delta = ((q_kh * a.KW + q_kw) * a.Cin + c0) * SZ;
+      int ok = b_ok[i] & kvalid & (c0 + b_coff[i] < a.Cin);
+      unsigned voff = ok ? (unsigned)(b_base[i] + b_delta) : OOB_OFFSET;
+      const int g = i * NW + wave;
+      unsigned char* dst = g < GB ? sbase + A_BYTES + c * (BN * ROWB) + g * 1024 : smem + SCRATCH + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
+    }
+  };
+  auto advance_walk = [&]() {
+    ++kc_next;
+    if (++d0 == r0) {
+      d0 = 0;
+      if (++d1 == r1) {
+        d1 = 0;
+        ++d2;
+      }
+    }
+  };
   auto load_stage = [&](int buf) {
     unsigned char* sbase = smem + buf * STAGE_BYTES;
 #pragma unroll
@@ -559,14 +603,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
         unsigned char* dst = g < GB ? sbase + A_BYTES + c * (BN * ROWB) + g * 1024 : smem + SCRATCH + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, voff, 0, 0, 0);
       }
-      ++kc_next;
-      if (++d0 == r0) {
-        d0 = 0;
-        if (++d1 == r1) {
-          d1 = 0;
-          ++d2;
-        }
-      }
+      advance_walk();
     }
   };
 
@@ -593,7 +630,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
     else wait_vmcnt<0>();
     if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
     if (ts && s == s_begin) ts[2] = wall_clock64();
-    if (s + NST - 1 < s_end && !(a.dbg & 1)) load_stage(buf == 0 ? NST - 1 : buf - 1);  // refill the released buffer
+    const bool refill = s + NST - 1 < s_end && !(a.dbg & 1);
+    unsigned char* const rbase = smem + (buf == 0 ? NST - 1 : buf - 1) * STAGE_BYTES;   // the released buffer
+    if (!ILV && refill) load_stage(buf == 0 ? NST - 1 : buf - 1);
 
     const unsigned char* sa = smem + buf * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
@@ -612,10 +651,21 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_ring_kernel(ConvK a) {
         wf[j] = *reinterpret_cast<const bf16x8*>(sb + c * (BN * ROWB) + row * ROWB + swz(row, lg) * 16);
       }
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i) {
+        if constexpr (ILV) {   // this fragment row's share of the chunk's DMA pieces, then its MFMAs
+          constexpr int NP = A_PER + B_PER;
+          if (refill) {
+#pragma unroll
+            for (int p = (i * NP) / FM; p < ((i + 1) * NP) / FM; ++p) load_piece(rbase, c, p);
+          }
+          asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        if constexpr (ILV) asm volatile("" ::: "memory");
+      }
+      if (ILV && refill) advance_walk();
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
   }
@@ -1374,6 +1424,9 @@ static const RingCfg kRing[] = {
     {128, 64, -1},   // 18: pipe<128, 64,2,1> 2 waves, per-wave 64x64,   50 KB
     {256, 224, -2},  // 19: halo<224,4,2> 8 waves, per-wave 64x112, 155 KB  (kps -2: halo kernel, 3x3 s1 p1, W in 16..64)
     {256, 128, -2},  // 20: halo<128,4,2> 8 waves, per-wave 64x64,  131 KB
+    {256, 224, 1},   // 21: ring <256,224,4,2,1,4> of 11 with the refill's DMA instructions interleaved with the MFMA groups
+    {128, 224, 1},   // 22: ring <128,224,2,2,1,4> of 12, interleaved
+    {256, 224, 1},   // 23: ring <256,224,4,2,1,5> interleaved, one stage deeper (158 KB)
 };
 bool conv_halo_shape_ok(int H, int W) {
   if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
@@ -1554,13 +1607,13 @@ static unsigned long long* conv_ts_buffer(int n_workgroups) {
   return dev;
 }
 
-template <int BM, int BN, int WM, int WN, int KPS, int NST>
+template <int BM, int BN, int WM, int WN, int KPS, int NST, bool ILV = false>
 static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
   constexpr int lds = NST * KPS * (BM + BN) * 64 + WM * WN * 1024;
   static_assert(lds <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   k.tiles_n = cdiv(k.Cout, BN);
   dim3 grid(cdiv(k.M, BM) * k.tiles_n, batch, splitk);
-  auto kern = conv_ring_kernel<BM, BN, WM, WN, KPS, NST>;
+  auto kern = conv_ring_kernel<BM, BN, WM, WN, KPS, NST, ILV>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1572,7 +1625,7 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
     double flops, bytes;
     conv_work(k, batch, 2, &flops, &bytes);
     static const std::string name = "conv_ring<bf16," + std::to_string(BM) + "x" + std::to_string(BN) + ",k" +
-                                    std::to_string(KPS * 32) + "x" + std::to_string(NST) + ">";
+                                    std::to_string(KPS * 32) + "x" + std::to_string(NST) + (ILV ? ",ilv>" : ">");
     PROF_SCOPE(name.c_str(), flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
@@ -1664,6 +1717,9 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 18: return launch_pipe<128, 64, 2, 1>(k, splitk, batch, s);
       case 19: return launch_halo<224, 4, 2>(k, splitk, batch, s);
       case 20: return launch_halo<128, 4, 2>(k, splitk, batch, s);
+      case 21: return launch_ring<256, 224, 4, 2, 1, 4, true>(k, splitk, batch, s);
+      case 22: return launch_ring<128, 224, 2, 2, 1, 4, true>(k, splitk, batch, s);
+      case 23: return launch_ring<256, 224, 4, 2, 1, 5, true>(k, splitk, batch, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -1703,7 +1759,8 @@ static int check_conv(const ConvArgs& a, int dt) {
 
 // wave tile (rows, channels) of the bf16 configurations kRing[id]
 static const int kRingWave[][2] = {{32, 112}, {32, 112}, {32, 112}, {32, 112}, {64, 64}, {32, 64}, {32, 64}, {32, 32}, {64, 64}, {64, 112}, {64, 112},
-                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64}};
+                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64},
+                                   {64, 112}, {64, 112}, {64, 112}};
 static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave tile per ring configuration");
 
 // Rows per statistics block (the wave tile height) when a launch of `a` with a.chstat set would fill the WHOLE

@@ -147,6 +147,26 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
   const T* xb = (second ? x2 + (int64_t)v * VN - C1 : x + (int64_t)v * VN) + (int64_t)b * HW * ldc;
   T* yb = y + (int64_t)b * HW * C + (int64_t)v * VN;
   int p = p0 + r;
+  // eight 16-byte loads in flight per thread: at one workgroup of 256 threads per (split, sample) and 4 workgroups per CU, four
+  // loads left ~64 KB in flight per CU - about one HBM latency x the CU's share of the bandwidth, no slack (5.0 TB/s measured)
+  typedef __attribute__((ext_vector_type(4))) unsigned int raw16;
+  for (; p + 7 * R < p1; p += 8 * R) {
+    raw16 raw[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const raw16*>(xb + (int64_t)(p + u * R) * ldc));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float t[VN];
+      Vec16<T>::load(reinterpret_cast<const T*>(&raw[u]), t);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        float q = t[j] * sc[j] + sh[j];
+        if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
+        t[j] = q;
+      }
+      Vec16<T>::store(yb + (int64_t)(p + u * R) * C, t);
+    }
+  }
   for (; p + 3 * R < p1; p += 4 * R) {  // four loads in flight per thread (see gn_stats_kernel)
     float t[4][VN];
 #pragma unroll

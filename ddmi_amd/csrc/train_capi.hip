@@ -14,6 +14,7 @@ struct ddmi_train {
   float* freq = nullptr;   // sinusoidal-embedding frequency table of the last `dim` asked for (device, lives with the handle)
   int freq_dim = 0;
   int acc_next = 0;        // ddmi_train_accumulate_next: parameter-gradient outputs of the NEXT backward call are added in place
+  int generation = 0;      // bumped whenever the scratch arena moves: captured hipGraphs hold pointers into the old one
 };
 
 namespace {
@@ -29,7 +30,11 @@ struct Carve {   // sequential carving of the scratch arena, 256-byte aligned
 int reserve(ddmi_train* h, size_t bytes, hipStream_t s) {
   bytes += 4096;
   if (bytes <= h->ws_bytes) return DDMI_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return ddmi_fail(DDMI_ERR_STATE, "training scratch arena would have to grow inside a stream capture: run the shape eagerly once first");
   HIP_TRY(hipStreamSynchronize(s));   // nothing in flight may still use the old arena
+  ++h->generation;                    // graphs captured so far replay into freed memory: the host drops them (ddmi_train_arena_generation)
   if (h->ws) (void)hipFree(h->ws);
   h->ws = nullptr;
   h->ws_bytes = 0;
@@ -58,6 +63,12 @@ int ddmi_train_destroy(ddmi_train* h) {
     if (h->freq) (void)hipFree(h->freq);
     delete h;
   }
+  return DDMI_OK;
+}
+
+int ddmi_train_arena_generation(ddmi_train* h, int* generation) {
+  DDMI_REQUIRE(h && generation, "train_arena_generation: null argument");
+  *generation = h->generation;
   return DDMI_OK;
 }
 

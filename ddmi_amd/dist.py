@@ -67,27 +67,60 @@ def group_size(device) -> int:
     return int(t.item())
 
 
+_SHARED_PLAN_FILES: List[str] = []
+
+
+def _drop_shared_plan_files() -> None:
+    for p in _SHARED_PLAN_FILES:
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+    if os.environ.get("DDMI_TUNE_SHARED") == "1":
+        os.environ.pop("DDMI_TUNE_FILE", None)
+        os.environ.pop("DDMI_TUNE_SHARED", None)
+
+
 def finalize_with_shared_plans(finalize: Callable[[], object], rank: int, world: int) -> Optional[str]:
     """Runs `finalize()` (pipeline.finalize: weight packing + per-shape convolution autotune) on every rank with ONE set of
     convolution plans: rank 0 tunes into a plan file, its text is broadcast, the other ranks finalize from it.  The
     autotuner is timing-based, so two ranks tuning on their own can pick different tiles / split-K for the same shape;
     with shared plans the bf16 results of a sample are bit-identical whichever GPU produced it.  A user-pinned
-    DDMI_TUNE_FILE is respected as is.  Returns the plan file path (None for a single process)."""
-    if world == 1 or not dist.is_initialized() or os.environ.get("DDMI_TUNE_FILE"):
+    DDMI_TUNE_FILE is respected as is.  The per-process plan file this function creates is marked (DDMI_TUNE_SHARED) so that a
+    LATER call in the same process runs the same protocol again (rank 0 tunes the new network's shapes into the file, the
+    others receive the whole text) instead of mistaking the file for a user's; it is removed at exit.  If rank 0's finalize
+    raises, the error text is broadcast and every rank raises - nobody waits in the collective.  Returns the plan file path."""
+    if world == 1 or not dist.is_initialized():
         finalize()
         return os.environ.get("DDMI_TUNE_FILE")
-    import tempfile
-    path = os.path.join(tempfile.gettempdir(), f"ddmi_conv_plans_{os.getpid()}_rank{rank}.txt")
-    text = [None]
-    if rank == 0:
-        os.environ["DDMI_TUNE_FILE"] = path
+    shared = os.environ.get("DDMI_TUNE_SHARED") == "1"
+    if os.environ.get("DDMI_TUNE_FILE") and not shared:
         finalize()
-        text[0] = open(path).read() if os.path.exists(path) else ""
-    dist.broadcast_object_list(text, src=0)
+        return os.environ.get("DDMI_TUNE_FILE")
+    import atexit
+    import tempfile
+    path = os.environ.get("DDMI_TUNE_FILE") if shared else \
+        os.path.join(tempfile.gettempdir(), f"ddmi_conv_plans_{os.getpid()}_rank{rank}.txt")
+    if not shared:
+        _SHARED_PLAN_FILES.append(path)
+        if len(_SHARED_PLAN_FILES) == 1:
+            atexit.register(_drop_shared_plan_files)
+        os.environ["DDMI_TUNE_FILE"], os.environ["DDMI_TUNE_SHARED"] = path, "1"
+    msg = [None, None]   # (plan text, error text)
+    if rank == 0:
+        try:
+            finalize()
+            msg[0] = open(path).read() if os.path.exists(path) else ""
+        except BaseException as e:   # the other ranks are waiting in the broadcast: tell them before re-raising
+            msg[1] = f"{type(e).__name__}: {e}"
+            dist.broadcast_object_list(msg, src=0)
+            raise
+    dist.broadcast_object_list(msg, src=0)
+    if msg[1] is not None:
+        raise RuntimeError(f"rank 0 failed to finalize: {msg[1]}")
     if rank != 0:
         with open(path, "w") as f:
-            f.write(text[0])
-        os.environ["DDMI_TUNE_FILE"] = path
+            f.write(msg[0])
         finalize()
     return path
 

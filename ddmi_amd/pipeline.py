@@ -21,11 +21,12 @@ from .unet import UNetModel
 RNG_MODES = ("philox", "torch", "reference")
 
 
-def _load_checkpoint_into(pipe, path: str, use_ema: bool, vae_strict: bool):
+def _load_checkpoint_into(pipe, path, use_ema: bool, vae_strict: bool):
     """Shared by the three pipelines: see ddmi_amd/checkpoint.py for the file layouts (tools/ldm/image.py:70-88,
-    tools/ldm/video.py:68-83, tools/ldm/occupancy.py:76-94).  Returns 'ldm' or 'stage1'."""
+    tools/ldm/video.py:68-83, tools/ldm/occupancy.py:76-94).  `path` is a file name or the dict `read_checkpoint` returned for
+    it (multi-GB files are unpickled once per process).  Returns 'ldm' or 'stage1'."""
     from . import checkpoint as CK
-    st = CK.sampling_states(CK.read_checkpoint(path), use_ema=use_ema)
+    st = CK.sampling_states(path if isinstance(path, dict) else CK.read_checkpoint(path), use_ema=use_ema)
     pipe.vae.load_state_dict(st["vae"], strict=vae_strict)
     pipe.mlp.load_state_dict(st["mlp"], strict=True)
     if st["diffusion"] is not None:

@@ -608,6 +608,7 @@ class LDMTrainStep:
         self.micro = 0
         self.use_graph = bool(use_graph)     # replay the micro-step as a hipGraph (see _graphed_micro)
         self._graphs: Dict[tuple, object] = {}
+        self._graph_generation = 0
 
     # ---- parameters ----------------------------------------------------------------------------------------------------
     def named_parameters(self):
@@ -659,6 +660,11 @@ class LDMTrainStep:
         growth, kernel attributes: none of that is legal inside a capture); the second records the body on static input
         buffers - the gradients already land in the static flat slab - and replays it; later calls copy the inputs and replay."""
         key = tuple(z0.shape)
+        gen = C.c_int(0)
+        _lib.check(_lib.lib().ddmi_train_arena_generation(self.model.tc.h, C.byref(gen)))
+        if gen.value != self._graph_generation:   # the scratch arena moved (a larger shape ran since): every recorded graph points
+            self._graphs = {k: "warm" for k in self._graphs}   # into freed memory - re-record on the next call of each shape
+            self._graph_generation = gen.value
         g = self._graphs.get(key)
         if g is None:
             self._graphs[key] = "warm"

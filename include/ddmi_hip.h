@@ -364,6 +364,10 @@ int ddmi_train_linear_bwd(ddmi_train* h, const float* x, const float* W, const f
  * the PARAMETER-gradient outputs of the NEXT ddmi_train_conv_bwd / ddmi_train_gn_bwd call on this handle are added to their
  * destination instead of overwriting it - mask bit 0: dw, bit 1: dbias, bit 2: dgamma and dbeta.  One-shot. */
 int ddmi_train_accumulate_next(ddmi_train* h, int mask);
+/* Number of times the handle's scratch arena has been re-allocated (it grows on the first call of a larger shape, never
+ * inside a stream capture: that call fails with DDMI_ERR_STATE).  A hipGraph captured over these entry points holds
+ * pointers into the arena of its time: a caller that replays graphs compares this counter and re-captures when it moved. */
+int ddmi_train_arena_generation(ddmi_train* h, int* generation);
 /* fp32 GEMM with strided operands, C[m][n] = bias[n] + sum_r A[m*sam + r*sar] * B[r*sbr + n*sbn] (bias may be NULL): the batched
  * ResBlock.emb_layers projection of a training step (forward, input gradient, weight gradient are three orientations of it) */
 int ddmi_train_matmul(ddmi_train* h, const float* A, int64_t sam, int64_t sar, const float* B, int64_t sbr, int64_t sbn, float* C,

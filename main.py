@@ -108,7 +108,8 @@ def load_weights(pipe, args, dc, tag):
         pipe.load_named_seed(tag)
         return
     print("Loading Pretrained Models!" if path.endswith("ldm-last.pt") else "Load VAE checkpoints!")
-    T_ck = CK.checkpoint_sampler_config(CK.read_checkpoint(path))
+    ck = CK.read_checkpoint(path)    # once: the dict is handed to load_checkpoint below
+    T_ck = CK.checkpoint_sampler_config(ck)
     if T_ck and T_ck["timesteps"] != pipe.ddpm.num_timesteps:
         cfg = dict(args.ddpmconfig)
         print(f"checkpoint schedule has T={T_ck['timesteps']} (config: {cfg.get('timesteps')}): sampling "
@@ -124,7 +125,7 @@ def load_weights(pipe, args, dc, tag):
     if path.endswith("model-last.pt"):
         print("stage-1 checkpoint: the diffusion model keeps its initialisation (named-seed weights)")
         pipe.load_named_seed(tag)
-    pipe.load_checkpoint(path)
+    pipe.load_checkpoint(ck)
 
 
 def train_main(args, dc, rank, world, dev):
@@ -145,10 +146,14 @@ def train_main(args, dc, rank, world, dev):
     step = LDMTrainStep(args.unetconfig, args.ddpmconfig, numerics=args.numerics, lr=float(getattr(args, "lr", None) or 1e-4),
                         gradient_accumulate_every=int(lc.get("gradient_accumulate_every", 1)), ema_decay=float(lc.get("ema_decay", 0.9999)),
                         ema_update_every=int(lc.get("ema_update_every", 10)), device=dev)
-    vae_state, mlp_state = {}, {}
+    vae_state, mlp_state, ck = {}, {}, None
     path = CK.find_checkpoint(dc.save_pth, resume=bool(getattr(args, "resume", False)), pretrained=bool(args.pretrained))
     if path is not None:   # the reference's start modes: resume / pretrained continue an LDM, otherwise the stage-1 VAE + MLP
         ck = CK.read_checkpoint(path)
+        T_ck = CK.checkpoint_sampler_config(ck)
+        if T_ck and T_ck["timesteps"] != int(args.ddpmconfig.get("timesteps", 1000)):
+            raise SystemExit(f"checkpoint was trained with T={T_ck['timesteps']}, the config says {args.ddpmconfig.get('timesteps')}: "
+                             "continuing it on another schedule is not the reference's resume")
         st = CK.sampling_states(ck, use_ema=False)
         vae_state, mlp_state = st["vae"], st["mlp"]
         if st["diffusion"] is not None:
@@ -159,6 +164,11 @@ def train_main(args, dc, rank, world, dev):
         st = iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in step.model.state_dict().items()])
         step.load_state_dict({"model." + k: v for k, v in st.items()}, strict=False)
     step.finalize()
+    if ck is not None and path.endswith("ldm-last.pt"):
+        # tools/ldm/image.py:76-82 (pretrained: + EMA) and :121-134 (resume: + optimizer moments, step counters): without this the
+        # EMA would restart from the online weights and AdamW's bias correction from step 0
+        step.load_training_state(ck, resume=bool(getattr(args, "resume", False)))
+        print(f"restored EMA (step {step.ema_step})" + (f", AdamW state, optimizer step {step.opt_step}" if getattr(args, "resume", False) else ""))
     lat = None
     if dc.get("latents") and os.path.exists(dc.latents):
         lat = torch.from_numpy(np.load(dc.latents).astype(np.float32))
@@ -175,7 +185,10 @@ def train_main(args, dc, rank, world, dev):
             print(f"iter {it}: Dae loss : {float(loss):.4f}", flush=True)
     if rank == 0:
         os.makedirs(dc.save_pth, exist_ok=True)
-        step.save(os.path.join(dc.save_pth, "ldm-last.pt"), vae_state, mlp_state)
+        plain = lambda d: {k: v for k, v in dict(d or {}).items() if isinstance(v, (int, float, str, bool, list, type(None)))}
+        step.save(os.path.join(dc.save_pth, "ldm-last.pt"), vae_state, mlp_state,
+                  args={"unetconfig": plain(args.unetconfig), "ddpmconfig": plain(args.ddpmconfig), "loss_config": plain(lc),
+                        "lr": step.lr, "embed_dim": int(args.embed_dim)})
         print(f"saved {os.path.join(dc.save_pth, 'ldm-last.pt')} after {step.opt_step} optimizer steps")
 
 

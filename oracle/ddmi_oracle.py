@@ -917,6 +917,30 @@ def generate_video(unet_p: State, unet_cfg: Mapping, vae_p: State, ddconfig: Map
 
 
 # ======================================================================================
+# f4  training loss: DDPM.p_losses (ddpm:383-386 q_sample, :409-447) for the configuration every DDMI yaml uses:
+#     parameterization "eps", loss_type "l2", l_simple_weight 1, original_elbo_weight 0, mixed prediction.
+#     Differentiable: torch autograd of this function w.r.t. the parameter tensors IS the reference's backward pass
+#     (pinned against fixture T1, the real reference's loss and gradients, in tests/test_oracle_golden.py).
+# ======================================================================================
+
+def p_losses(unet_p: State, unet_cfg: Mapping, sched, mixing_logit: Optional[Tensor], x_start: Tensor, t: Tensor, noise: Tensor,
+             model=None) -> Tensor:
+    """loss = mean((noise - mixed(model(q_sample(x_start, t, noise), t)))^2); `unet_p` / `mixing_logit` may require grad.
+    `model(p, cfg, x, t)` defaults to unet_forward (the tri-plane UNet takes unet_triplane_forward)."""
+    x_start, noise = _t(x_start), _t(noise)
+    shape = (-1,) + (1,) * (x_start.ndim - 1)
+    sa = torch.from_numpy(np.asarray(sched["sqrt_alphas_cumprod"], dtype=np.float32))[t].reshape(shape)
+    s1 = torch.from_numpy(np.asarray(sched["sqrt_one_minus_alphas_cumprod"], dtype=np.float32))[t].reshape(shape)
+    x_noisy = sa * x_start + s1 * noise                                              # ddpm:383-386
+    out = (model or unet_forward)(unet_p, unet_cfg, x_noisy, t)
+    if mixing_logit is not None:                                                     # ddpm:469-477 with a per-sample t
+        coeff = torch.sigmoid(mixing_logit)
+        out = (1 - coeff) * (s1 * x_noisy) + coeff * out
+    per_sample = ((noise - out) ** 2).mean(dim=tuple(range(1, x_start.ndim)))       # mse_loss(reduction='none').mean(dim=[1,2,3])
+    return per_sample.mean()                                                         # l_simple_weight 1, original_elbo_weight 0
+
+
+# ======================================================================================
 # f4  EMA of the trainer: ema_pytorch.EMA (third-party, `pip install ema-pytorch`, README.md:33, unpinned and absent from
 # the reference tree).  Restated from its published algorithm; the reference's call sites are tools/ldm/image.py:64
 # (EMA(diffusion_process, beta=ema_decay, update_every=ema_update_every): every other argument at its default) and :174

@@ -34,7 +34,34 @@ slab = torch.arange(10, dtype=torch.float32, device=dev) * (rank + 1)
 allreduce_gradients(slab, world, bucket_bytes=16)          # 4-element buckets: three collectives
 rec["grad_slab"] = slab.tolist()
 os.environ.pop("DDMI_TUNE_FILE", None)
+os.environ.pop("DDMI_TUNE_SHARED", None)
 D.finalize_with_shared_plans(fake_finalize, rank, world)
+
+
+def second_finalize():
+    """A second network finalized later in the same process: rank 0 appends the shapes it had to tune; the other ranks must see
+    the appended text (not tune on their own because the first call left DDMI_TUNE_FILE set)."""
+    p = os.environ.get("DDMI_TUNE_FILE")
+    if rank == 0:
+        with open(p, "a") as f:
+            f.write("second network, tuned by rank 0\n")
+    rec["second_from"] = open(p).read()
+
+
+D.finalize_with_shared_plans(second_finalize, rank, world)
+
+
+def failing_finalize():
+    if rank == 0:
+        raise ValueError("no such weight")
+    rec["finalized_after_failure"] = True
+
+
+try:   # rank 0's error reaches every rank instead of leaving them in the broadcast
+    D.finalize_with_shared_plans(failing_finalize, rank, world)
+    rec["failure"] = None
+except (RuntimeError, ValueError) as e:
+    rec["failure"] = str(e)
 with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
     json.dump(rec, f)
 D.barrier()

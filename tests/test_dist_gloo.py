@@ -65,6 +65,10 @@ def test_self_launch_starts_the_ranks(tmp_path):
         assert rec["world"] == 2 and rec["ranks"] == 2 and rec["rows"] == [0.0, 0.0, 1.0, 1.0] and rec["max"] == 1.0
         # one set of convolution plans for the whole job: every rank finalizes from rank 0's file
         assert rec["finalized_from"] == "v 2\nplans tuned by rank 0\n"
+        # a later finalize in the same process shares again (the first call's plan file is not mistaken for a user's) ...
+        assert rec["second_from"] == "v 2\nplans tuned by rank 0\nsecond network, tuned by rank 0\n"
+        # ... and rank 0's failure is every rank's failure, not a hang in the broadcast
+        assert rec["failure"] and "no such weight" in rec["failure"] and "finalized_after_failure" not in rec
         # the training step's bucketed gradient all-reduce: rank r held (r + 1) * arange(10) -> the sum is 3 * arange(10)
         assert rec["grad_slab"] == [3.0 * i for i in range(10)]
     # a failing rank is the launcher's failure

@@ -83,3 +83,174 @@ def test_attention_block_order_at_odd_batch_sizes(B):
     _lib.init_device(0)
     _lib.check(_lib.lib().ddmi_op_attention_legacy_hd(qkv.to(DEV).data_ptr(), out.data_ptr(), B, heads, d, T, _lib.numerics_code("bf16")))
     assert rel_err(out, ref) < 2e-2
+
+
+# ---------------- training: EMA (ema_pytorch semantics) and resume ---------------------------------------------------
+def _g(tag, key, shape, std=1.0):
+    return torch.from_numpy(iw.normal(tag, key, shape, 0.0, std))
+
+
+def _toy_trainer(golden, numerics="fp32", **kw):
+    from ddmi_amd import train as T
+    cfg = golden.json("configs.json")["TOY_UNET"]
+    tr = T.LDMTrainStep(cfg, dict(timesteps=1000, channels=64), numerics=numerics, lr=1e-4, weight_decay=0.0, device=DEV, **kw)
+    st = {"model." + k: v for k, v in named_state("T1.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+    st["mixing_logit"] = iw.normal("T1", "mixing_logit", (1, 64, 1, 1), 0.0, 0.5)
+    return tr.load_state_dict(st)
+
+
+def test_trainer_ema_follows_ema_pytorch(golden):
+    """`ema.update()` after every optimizer step (tools/ldm/image.py:174) with ema_pytorch's rules: copies while the call count is
+    <= update_after_step, then the warmed-up decay 1 - (1 + epoch)^(-2/3) capped at beta - against the oracle's restatement of
+    that class driven with snapshots of the same online weights."""
+    tr = _toy_trainer(golden, ema_decay=0.9, ema_update_every=2).finalize()
+    tr.ema_update_after_step = 5          # the real default (100) with the same code path, kept short
+    orc = O.EmaPytorchOracle([tr.flat.data.detach().cpu().clone()], beta=0.9, update_every=2, update_after_step=5)
+    x0, nz = _g("T1", "x_start", (2, 64, 8, 8)), _g("T1", "noise", (2, 64, 8, 8))
+    saw_lerp = False
+    for i in range(24):
+        tr.train_step(x0, torch.tensor([3 + 17 * i, 900 - 31 * i]), nz)
+        orc.online[0].copy_(tr.flat.data.detach().cpu())
+        orc.update()
+        assert rel_err(tr.ema, orc.ema[0]) < 1e-6, i
+        assert tr.ema_step == int(orc.step) and tr.ema_initted == bool(orc.initted)
+        saw_lerp |= bool(orc.initted) and not torch.equal(orc.ema[0], orc.online[0])
+    assert saw_lerp                       # the run left the copy phase: the EMA lags the online weights
+    # the decay reached its cap: epoch = 24 - 1 - 5 = 18 -> 1 - 19^(-2/3) = 0.86 < 0.9; at the default beta it would still be warming up
+    from ddmi_amd.train import ema_pytorch_plan
+    assert ema_pytorch_plan(22, 0.9, 2, 5) == ("lerp", pytest.approx(1 - 18 ** (-2 / 3)))
+    assert ema_pytorch_plan(100, 0.9999, 10)[0] == "copy" and ema_pytorch_plan(110, 0.9999, 10)[0] == "lerp"
+
+
+def test_training_resume_restores_ema_optimizer_and_counters(golden, tmp_path):
+    """LDMTrainer.save -> load (resume, tools/ldm/image.py:104-134): a trainer restored from the file continues EXACTLY like the
+    one that wrote it - weights, EMA, AdamW moments and bias-correction step - and the file has the reference's layout:
+    `diffusion` = DDPM.state_dict() incl. the schedule buffers, `dae_opt` loadable by torch.optim.AdamW, ema_pytorch's keys."""
+    import os
+    from ddmi_amd import checkpoint as CK
+    x0, nz = _g("T1", "x_start", (2, 64, 8, 8)), _g("T1", "noise", (2, 64, 8, 8))
+    ts = lambda i: torch.tensor([3 + 17 * i, 900 - 31 * i])
+    a = _toy_trainer(golden, ema_update_every=1).finalize()
+    a.ema_update_after_step = 1
+    for i in range(4):
+        a.train_step(x0, ts(i), nz)
+    path = os.path.join(tmp_path, "ldm-last.pt")
+    a.save(path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)          # plain containers and tensors only
+    assert {"args", "step", "current_iters", "vaemodel", "mlp", "diffusion", "dae_opt", "ema", "scaler"} <= set(ck)
+    assert ck["diffusion"]["betas"].shape == (1000,) and "ema_model.betas" in ck["ema"] and "online_model.mixing_logit" in ck["ema"]
+    assert int(ck["ema"]["step"]) == 4 and bool(ck["ema"]["initted"]) and ck["step"] == 4
+    params = [torch.nn.Parameter(torch.zeros_like(p.detach().cpu())) for _, p in a.named_parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0)
+    opt.load_state_dict(ck["dae_opt"])                                     # the reference's `self.dae_opt.load_state_dict`
+    assert float(opt.state[params[0]]["step"]) == 4.0
+    assert CK.checkpoint_sampler_config(ck) == {"timesteps": 1000}
+    b = _toy_trainer(golden, ema_update_every=1)
+    b.load_state_dict({k: v for k, v in ck["diffusion"].items() if k.startswith("model.") or k == "mixing_logit"}, strict=True).finalize()
+    b.ema_update_after_step = 1
+    b.load_training_state(CK.read_checkpoint(path), resume=True)
+    assert b.opt_step == 4 and b.ema_step == 4 and b.ema_initted
+    assert torch.equal(b.flat.data, a.flat.data) and torch.equal(b.ema, a.ema)
+    assert torch.equal(b.flat.exp_avg, a.flat.exp_avg) and torch.equal(b.flat.exp_avg_sq, a.flat.exp_avg_sq)
+    for i in range(4, 6):
+        a.train_step(x0, ts(i), nz)
+        b.train_step(x0, ts(i), nz)
+    assert torch.equal(b.flat.data, a.flat.data) and torch.equal(b.ema, a.ema)
+    # `pretrained` (tools/ldm/image.py:76-82) restores weights + EMA only: a fresh optimizer
+    c = _toy_trainer(golden, ema_update_every=1)
+    c.load_state_dict({k: v for k, v in ck["diffusion"].items() if k.startswith("model.") or k == "mixing_logit"}, strict=True).finalize()
+    c.load_training_state(ck, resume=False)
+    assert c.opt_step == 0 and float(c.flat.exp_avg.abs().max()) == 0.0 and torch.equal(c.ema.cpu(), torch.cat([ck["ema"]["ema_model." + k].reshape(-1) for k, _ in c.named_parameters()]))
+
+
+# ---------------- training at FULL size ---------------------------------------------------------------------------------
+AFHQ_FULL_GRADS = ["model.input_blocks.0.0.weight", "model.input_blocks.1.0.in_layers.2.weight", "model.input_blocks.1.0.emb_layers.1.weight",
+                   "model.input_blocks.3.0.op.weight", "model.input_blocks.4.0.skip_connection.weight", "model.input_blocks.4.1.norm.weight",
+                   "model.input_blocks.4.1.qkv.weight", "model.input_blocks.4.1.proj_out.weight", "model.middle_block.1.qkv.bias",
+                   "model.output_blocks.2.2.conv.weight", "model.output_blocks.5.0.out_layers.0.bias", "model.output_blocks.11.0.skip_connection.weight",
+                   "model.time_embed.0.weight", "model.out.2.weight", "mixing_logit"]
+
+
+def test_afhq_training_step_full_size_vs_autograd():
+    """The configuration `bench.py --workload train` times - the 519 M-parameter AFHQ UNet on [B,64,64,64] latents - at B = 2:
+    `p_losses` + backward through the C ABI's backward kernels against torch-CPU autograd of the oracle's forward (oracle.p_losses,
+    itself pinned to the real reference's gradients by fixture T1).  fp32 mode: loss and EVERY gradient (norm and sum; fifteen tensors
+    element by element) within 1e-3; bf16 mode: loss within the bf16 tolerance and relative L2 <= 3e-2 per gradient."""
+    import time
+    from ddmi_amd import train as T
+    from helpers import AFHQ_UNET
+    B = 2
+    x0, nz = _g("afhq.train", "x_start", (B, 64, 64, 64)), _g("afhq.train", "noise", (B, 64, 64, 64))
+    t = torch.tensor([37, 811], dtype=torch.int64)
+    tr = T.LDMTrainStep(AFHQ_UNET, dict(timesteps=1000, channels=64), numerics="fp32", device=DEV)
+    st = named_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()])
+    logit_np = iw.normal("afhq.train", "mixing_logit", (1, 64, 1, 1), 0.0, 0.5)
+    # oracle side
+    t0 = time.time()
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in st.items()}
+    logit = torch.from_numpy(logit_np.copy()).requires_grad_(True)
+    loss_ref = O.p_losses(p, AFHQ_UNET, O.make_schedule(1000), logit, x0, t, nz)
+    loss_ref.backward()
+    ref = {"model." + k: v.grad for k, v in p.items()}
+    ref["mixing_logit"] = logit.grad
+    print("oracle: full-size p_losses + autograd at B=2 in %.1f s" % (time.time() - t0))
+    l2max = max(float(g.double().norm()) for g in ref.values())
+
+    def run(tr):
+        full = {"model." + k: v for k, v in st.items()}
+        full["mixing_logit"] = logit_np
+        tr.load_state_dict(full).finalize()
+        loss = tr.loss_and_backward(x0, t, nz)
+        return float(loss), {k: pp.grad.detach().float().cpu() for k, pp in tr.named_parameters()}
+
+    loss32, g32 = run(tr)
+    assert abs(loss32 - float(loss_ref)) < TOL_FP32 * float(loss_ref)
+    assert set(g32) == set(ref)
+    bad = {}
+    for k, r in ref.items():
+        g, rn = g32[k].double(), float(r.double().norm())   # (a float32 norm over 10 M elements is itself only good to ~1e-3)
+        e_norm = abs(float(g.norm()) - rn) / (rn + 1e-3 * l2max)
+        e_sum = abs(float(g.sum()) - float(r.double().sum())) / (rn * np.sqrt(g.numel()) + 1e-3 * l2max)
+        e_l2 = float((g - r.double()).norm()) / (rn + 1e-3 * l2max)   # relative L2, floored for the (analytically) tiny gradients
+        if max(e_norm, e_sum, e_l2) >= TOL_FP32:
+            bad[k] = (e_norm, e_sum, e_l2, rn)
+    assert not bad, (len(bad), sorted(bad.items(), key=lambda kv: -kv[1][2])[:10])
+    for k in AFHQ_FULL_GRADS:
+        assert float((g32[k] - ref[k]).abs().max()) < TOL_FP32 * float(ref[k].abs().max()) + 1e-6 * l2max, k
+    del tr, g32
+    torch.cuda.empty_cache()
+    tr16 = T.LDMTrainStep(AFHQ_UNET, dict(timesteps=1000, channels=64), numerics="bf16", device=DEV)
+    loss16, g16 = run(tr16)
+    assert abs(loss16 - float(loss_ref)) < TOL_BF16 * float(loss_ref)
+    bad = {k: rel_l2(g16[k], r) for k, r in ref.items() if float(r.double().norm()) > 1e-4 * l2max and rel_l2(g16[k], r) > 3e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+@pytest.mark.parametrize("case", [(224, 224, 64, 0), (1344, 1344, 8, 1), (448, 1344, 32, 2)])
+def test_wgrad_rows_are_batch_invariant_at_the_bench_batch(case):
+    """`wgrad_tn_kernel` at the training bench's batch (B = 128: pixel slices over > 2^31 bytes of im2col-equivalent input) against
+    itself at B = 2: the batch is the B = 2 pair repeated 64 times, so dW(128) = 64 dW(2) and dX rows repeat - for a 3x3 conv at 64x64,
+    the 1344-channel Upsample conv and a 1x1 qkv conv."""
+    from ddmi_amd import train as T
+    cin, cout, hw, kind = case
+    tc = T.TrainContext("bf16", DEV)
+    k = 1 if kind == 2 else 3
+    x2 = _g("wgrow", f"x{case}", (2, cin, hw, hw))
+    w = _g("wgrow", f"w{case}", (cout, cin, k, k), 1.0 / math.sqrt(cin * k * k))
+    b = _g("wgrow", f"b{case}", (cout,), 0.1)
+    ho = hw * 2 if kind == 1 else hw
+    dy2 = _g("wgrow", f"dy{case}", (2, cout, ho, ho))
+    outs = []
+    for reps in (1, 64):
+        xd = x2.repeat(reps, 1, 1, 1).permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype).requires_grad_(True)
+        wd, bd = w.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        y = T.ConvFn.apply(tc, xd, wd, bd, None, None, 1, kind == 1)
+        y.backward(dy2.repeat(reps, 1, 1, 1).permute(0, 2, 3, 1).contiguous().to(DEV, tc.dtype))
+        outs.append((wd.grad.float().cpu() / reps, bd.grad.float().cpu() / reps, xd.grad.float().cpu()))
+        del xd, y
+        torch.cuda.empty_cache()
+    (w2, b2, dx2), (w128, b128, dx128) = outs
+    assert rel_l2(w128, w2) < 1e-3 and rel_err(w128, w2) < 2e-3, (rel_l2(w128, w2), rel_err(w128, w2))
+    assert rel_l2(b128, b2) < 1e-3
+    for r in (0, 63, 127):
+        assert rel_err(dx128[r], dx2[r % 2]) < 1e-5, r

@@ -285,6 +285,7 @@ def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path)
     cfgs = golden.json("configs.json")
     tr = _toy_trainer(golden, "fp32")
     tr.ema_every = 1
+    tr.ema_update_after_step = 0   # ema_pytorch copies the online weights for its first update_after_step (100) calls; leave that phase at once
     x0, nz = g("T1", "x_start", (2, 64, 8, 8)), g("T1", "noise", (2, 64, 8, 8))
     for i in range(3):
         tr.train_step(x0, torch.tensor([3 + i, 900 - i]), nz)
@@ -300,7 +301,7 @@ def test_trained_checkpoint_round_trips_into_the_sampling_path(golden, tmp_path)
     pipe.finalize()
     assert rel_err(pipe.unet(xt, t), want) < 1e-5
     assert rel_err(pipe.ddpm.mixing_logit, tr.mixing_logit.detach()) < 1e-7
-    # EMA: decay 0.9999 per step from the initial snapshot - close to, but not, the online weights
+    # EMA (ema_pytorch: copy at call 0, then lerps with the warm-up decays 1 - 2^(-2/3), 1 - 3^(-2/3)): close to, but not, the online weights
     pipe2 = ImagePipeline(cfgs["TOY_UNET"], cfgs["TOY_DD"], cfgs["MLP_CFG"], dict(timesteps=1000, sampling_timesteps=10, channels=64, image_size=8),
                           cfgs["TOY_EMBED"], test_resolution=32, numerics="fp32", max_batch=2, device=DEV)
     pipe2.load_checkpoint(path, use_ema=True)

@@ -153,6 +153,53 @@ def test_attention_at_the_full_video_length_sampled_queries():
     assert rel_err(got, ref) < 4e-2
 
 
+def test_sky_full_size_decode_vs_oracle():
+    """BASELINE config 5's decode at FULL size against the CPU oracle: VITAutoencoder.decode (autoencoder_vit.py:188-202 ->
+    VideoDecoder_light.forward autoencoder_unet.py:1040-1144) at resolution 256 / 16 frames - inter-plane attention over
+    2 560 / 5 120 / 20 480 / 73 728 tokens (:1096-1109; the last one is 8 heads x 64 channels, 11 TFLOP) - then MLPVideo over all
+    16 x 256 x 256 query points.  The oracle evaluates the attention in blocks of 512 queries (oracle.sdpa_heads), so no
+    N x N matrix is ever held.  bf16 mode on all six plane lists and the RGB volume (L-infinity + relative L2 + per-channel
+    cosine); the fp32 parity mode at 1e-3 on the same tensors."""
+    import time
+    from helpers import SKY_DD, SKY_EMBED, SKY_FRAMES
+    from ddmi_amd.video import video_generation_coords
+    from oracle import ddmi_oracle as O
+    vit32 = VITAutoencoder(SKY_DD, SKY_EMBED, SKY_FRAMES, numerics="fp32", max_batch=1)
+    st = named_state("sky.vit", vit32.manifest())
+    mlp32 = MLPVideo(numerics="fp32")
+    mst = named_state("sky.mlpv", mlp32.manifest())
+    z = iw.normal("sky", "z", (1, SKY_EMBED, vit32.seq_len))
+    t0 = time.time()
+    with torch.no_grad():
+        ref = O.vit_decode(O.to_state(st), SKY_DD, SKY_FRAMES, torch.from_numpy(z))          # (xy, yt, xt) plane lists
+        ref_vid = O.mlp_video(O.to_state(mst), O.video_coords(256, SKY_FRAMES), ref)
+    print("oracle: full-size video decode + MLPVideo %.1f s on %d threads" % (time.time() - t0, torch.get_num_threads()))
+    names = ("xy", "yt", "xt")
+
+    def check(vit, mlp, bf16):
+        vit.load_state_dict(st)
+        mlp.load_state_dict(mst)
+        got = vit.decode(torch.from_numpy(z).to(DEV), reference_layout=True)
+        for nm, lst_g, lst_r in zip(names, got, ref):
+            for lvl, (g, r) in enumerate(zip(lst_g, lst_r)):
+                assert tuple(g.shape) == tuple(r.shape)
+                if bf16:
+                    assert_bf16_close(g, r, f"sky decode full size {nm}[{lvl}]")
+                else:
+                    assert rel_err(g, r) < TOL_FP32, (nm, lvl, rel_err(g, r))
+        vid = mlp(video_generation_coords(256, SKY_FRAMES), vit.decode(torch.from_numpy(z).to(DEV)))
+        assert tuple(vid.shape) == (1, 3, SKY_FRAMES, 256, 256)
+        if bf16:
+            assert_bf16_close(vid, ref_vid.reshape(vid.shape), "sky decode + MLPVideo full size")
+        else:
+            assert rel_err(vid, ref_vid.reshape(vid.shape)) < TOL_FP32
+
+    check(vit32, mlp32, False)
+    del vit32
+    torch.cuda.empty_cache()
+    check(VITAutoencoder(SKY_DD, SKY_EMBED, SKY_FRAMES, numerics="bf16", max_batch=1), MLPVideo(numerics="bf16"), True)
+
+
 def test_sky_full_size_decode_and_mlp_run():
     """Full-size VITAutoencoder.decode + MLPVideo in perf mode (B = 1): shapes, finiteness and the value range; the
     arithmetic itself is pinned by the tests above (no CPU oracle can hold this size)."""

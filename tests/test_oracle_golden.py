@@ -245,3 +245,32 @@ def test_same_seed_draw_order_g3(golden, name, T, S, eta):
     assert rel_err(raw.clamp(-1, 1), g3[f"{name}.img"]) < 1e-4
     wrong = O.image_mlp(O.to_state(mst), O.generate_coords(32), planes, O.scale_injection(32), noise=inj.flip(0))
     assert rel_err(wrong, g3[f"{name}.raw"]) > 1e-3     # the ORDER of the 12 draws is pinned, not just their presence
+
+
+def test_oracle_training_step_matches_reference_fixture_t1(golden):
+    """Pins oracle.p_losses + torch autograd (the checker of the full-size training test) to fixture T1 = the REAL reference's
+    `DDPM.p_losses` -> backward on the toy UNet (oracle/gen_golden_train.py): loss and every gradient's (sum, l2), 22 in full."""
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.unet import unet_manifest
+    from oracle import ddmi_oracle as O
+    t1 = golden.npz("T1_train_step.npz")
+    cfg = golden.json("configs.json")["TOY_UNET"]
+    st = iw.fill_state("T1.unet", [(k, tuple(s)) for k, s in unet_manifest(**cfg)])
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in st.items()}
+    logit = torch.from_numpy(iw.normal("T1", "mixing_logit", (1, 64, 1, 1), 0.0, 0.5)).requires_grad_(True)
+    x0 = torch.from_numpy(iw.normal("T1", "x_start", (2, 64, 8, 8)))
+    nz = torch.from_numpy(iw.normal("T1", "noise", (2, 64, 8, 8)))
+    loss = O.p_losses(p, cfg, O.make_schedule(1000), logit, x0, torch.from_numpy(t1["t"]), nz)
+    loss.backward()
+    assert abs(float(loss) - float(t1["loss"])) < 1e-6 * float(t1["loss"])
+    grads = {"model." + k: v.grad for k, v in p.items()}
+    grads["mixing_logit"] = logit.grad
+    l2max = float(t1["all_l2"].max())
+    for k, s_ref, l2_ref in zip(t1["all_keys"], t1["all_sum"], t1["all_l2"]):
+        g = grads[str(k)].double()
+        assert abs(float(g.norm()) - l2_ref) < 1e-4 * l2_ref + 1e-7 * l2max, k
+        assert abs(float(g.sum()) - s_ref) < 1e-4 * l2_ref * np.sqrt(g.numel()) + 1e-7 * l2max, k
+    for k in [k[5:] for k in t1 if k.startswith("grad.")]:
+        ref = t1["grad." + k]
+        assert np.abs(grads[k].numpy() - ref).max() < 1e-4 * np.abs(ref).max() + 1e-7 * l2max, k

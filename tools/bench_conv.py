@@ -18,6 +18,9 @@ UNET_SHAPES = [
     ("2688->1344 k3 @8", 2688, 8, 1344, 3, 1, 0, 2), ("448->1344 k1 @32 (qkv)", 448, 32, 1344, 1, 1, 0, 5),
     ("1344->4032 k1 @8 (qkv)", 1344, 8, 4032, 1, 1, 0, 6), ("224->224 k3 s2 @64", 224, 64, 224, 3, 2, 0, 1),
     ("64->224 k3 @64 (in)", 64, 64, 224, 3, 1, 0, 1), ("224->64 k3 @64 (out)", 224, 64, 64, 3, 1, 0, 1),
+    ("896->2688 k1 @16 (qkv)", 896, 16, 2688, 1, 1, 0, 5), ("448->448 k1 @32 (proj)", 448, 32, 448, 1, 1, 0, 5),
+    ("896->896 k1 @16 (proj)", 896, 16, 896, 1, 1, 0, 5), ("1344->1344 k1 @8 (proj)", 1344, 8, 1344, 1, 1, 0, 6),
+    ("224->224 k1 @64 (skip)", 224, 64, 224, 1, 1, 0, 5),
 ]
 DEC_SHAPES = [("512->512 k3 @64", 512, 64, 512, 3, 1, 0, 10), ("256->256 k3 @128", 256, 128, 256, 3, 1, 0, 5),
               ("128->128 k3 @256", 128, 256, 128, 3, 1, 0, 5), ("512->512 k3 up @64->128", 512, 64, 512, 3, 1, 1, 1)]
