@@ -9,7 +9,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libddmi_hip.so")
 
-PARITY_FP32, PERF_BF16 = 0, 1
+PARITY_FP32, PERF_BF16, PARITY_BF16X3 = 0, 1, 2
 LAYOUT_NCHW_F32, LAYOUT_NHWC_NATIVE = 0, 1
 STEP_ANCESTRAL, STEP_DDIM, STEP_DDIM_LAST = 0, 1, 2
 
@@ -19,7 +19,14 @@ def numerics_code(name) -> int:
         return PARITY_FP32
     if name in (PERF_BF16, "bf16", "perf", "PERF_BF16"):
         return PERF_BF16
-    raise ValueError(f"numerics must be 'fp32' (parity) or 'bf16' (perf), got {name!r}")
+    if name in (PARITY_BF16X3, "bf16x3", "PARITY_BF16X3"):
+        return PARITY_BF16X3
+    raise ValueError(f"numerics must be 'fp32' (parity), 'bf16' (perf) or 'bf16x3' (parity, convolutions as three bf16 products), got {name!r}")
+
+
+def is_fp32_storage(numerics_code_value: int) -> bool:
+    """Activations / planes are fp32 in both parity modes, bf16 in the perf mode."""
+    return numerics_code_value != PERF_BF16
 
 
 class UnetCfg(C.Structure):

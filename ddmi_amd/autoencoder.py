@@ -174,7 +174,7 @@ class Autoencoder:
             planes = [torch.empty((B, oc, p, p), device=z.device, dtype=torch.float32) for p in self.plane_hw]
             layout = _lib.LAYOUT_NCHW_F32
         else:
-            dt = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+            dt = torch.float32 if _lib.is_fp32_storage(self.numerics) else torch.bfloat16
             planes = [torch.empty((B, oc, p, p), device=z.device, dtype=dt, memory_format=torch.channels_last)
                       for p in self.plane_hw]
             layout = _lib.LAYOUT_NHWC_NATIVE

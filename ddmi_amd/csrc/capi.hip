@@ -15,10 +15,14 @@ struct ddmi_mlp3d { Mlp3d m; };
 struct ddmi_decoderv { DecoderV d; };
 struct ddmi_mlpv { MlpV m; };
 
-static int numerics_to_dt(int numerics, int* dt) {
+// DDMI_PARITY_BF16X3: fp32 tensors and fp32 kernels everywhere except the convolutions of the conv networks, which run as three
+// bf16 MFMA products (Net::x3); handles without convolutions (the fused MLPs, the single-op diagnostics) take it as fp32
+static int numerics_to_dt(int numerics, int* dt, bool* x3 = nullptr) {
+  if (x3) *x3 = false;
   if (numerics == DDMI_PARITY_FP32) { *dt = DT_F32; return DDMI_OK; }
   if (numerics == DDMI_PERF_BF16) { *dt = DT_BF16; return DDMI_OK; }
-  return ddmi_fail(DDMI_ERR_INVALID, "numerics must be DDMI_PARITY_FP32 (0) or DDMI_PERF_BF16 (1)");
+  if (numerics == DDMI_PARITY_BF16X3) { *dt = DT_F32; if (x3) *x3 = true; return DDMI_OK; }
+  return ddmi_fail(DDMI_ERR_INVALID, "numerics must be DDMI_PARITY_FP32 (0), DDMI_PERF_BF16 (1) or DDMI_PARITY_BF16X3 (2)");
 }
 
 extern "C" {
@@ -56,11 +60,13 @@ int ddmi_unet_create(const ddmi_unet_cfg* cfg, ddmi_unet** out) {
   DDMI_REQUIRE(cfg && out, "unet_create: null argument");
   DDMI_REQUIRE(cfg->max_batch >= 1, "unet_create: max_batch must be >= 1");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_unet* h = new (std::nothrow) ddmi_unet();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->u.cfg = *cfg;
   h->u.net.dt = dt;
+  h->u.net.x3 = x3;
   h->u.net.max_batch = cfg->max_batch;
   *out = h;
   return DDMI_OK;
@@ -145,11 +151,13 @@ int ddmi_decoder2d_create(const ddmi_decoder2d_cfg* cfg, ddmi_decoder2d** out) {
   DDMI_REQUIRE(cfg && out, "decoder2d_create: null argument");
   DDMI_REQUIRE(cfg->max_batch >= 1, "decoder2d_create: max_batch must be >= 1");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_decoder2d* h = new (std::nothrow) ddmi_decoder2d();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->d.cfg = *cfg;
   h->d.net.dt = dt;
+  h->d.net.x3 = x3;
   h->d.net.max_batch = cfg->max_batch;
   *out = h;
   return DDMI_OK;
@@ -183,7 +191,8 @@ int ddmi_decoder2d_destroy(ddmi_decoder2d* h) {
 int ddmi_mlp2d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp2d** out) {
   DDMI_REQUIRE(cfg && out, "mlp2d_create: null argument");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_mlp2d* h = new (std::nothrow) ddmi_mlp2d();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->m.cfg = *cfg;
@@ -230,13 +239,15 @@ int ddmi_decoder3d_create(const ddmi_decoder2d_cfg* cfg, const int* inter_attn_r
   DDMI_REQUIRE(cfg && out && n_inter >= 0 && n_inter <= 8, "decoder3d_create: bad argument");
   DDMI_REQUIRE(cfg->max_batch >= 1, "decoder3d_create: max_batch must be >= 1");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_decoder3d* h = new (std::nothrow) ddmi_decoder3d();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->d.cfg = *cfg;
   h->d.n_inter = n_inter;
   for (int i = 0; i < n_inter; ++i) h->d.inter_attn_resolutions[i] = inter_attn_resolutions[i];
   h->d.net.dt = dt;
+  h->d.net.x3 = x3;
   h->d.net.max_batch = cfg->max_batch;
   *out = h;
   return DDMI_OK;
@@ -274,11 +285,13 @@ int ddmi_decoderv_create(const ddmi_decoderv_cfg* cfg, ddmi_decoderv** out) {
                    cfg->n_inter <= 8 && cfg->frames >= 1 && cfg->resolution >= 8,
                "decoderv_create: bad configuration");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_decoderv* h = new (std::nothrow) ddmi_decoderv();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->d.cfg = *cfg;
   h->d.net.dt = dt;
+  h->d.net.x3 = x3;
   h->d.net.max_batch = cfg->max_batch;
   *out = h;
   return DDMI_OK;
@@ -311,7 +324,8 @@ int ddmi_decoderv_destroy(ddmi_decoderv* h) {
 int ddmi_mlpv_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlpv** out) {
   DDMI_REQUIRE(cfg && out, "mlpv_create: null argument");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_mlpv* h = new (std::nothrow) ddmi_mlpv();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->m.cfg = *cfg;
@@ -347,7 +361,8 @@ int ddmi_mlpv_destroy(ddmi_mlpv* h) {
 int ddmi_mlp3d_create(const ddmi_mlp2d_cfg* cfg, ddmi_mlp3d** out) {
   DDMI_REQUIRE(cfg && out, "mlp3d_create: null argument");
   int dt;
-  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(cfg->numerics, &dt, &x3));
   ddmi_mlp3d* h = new (std::nothrow) ddmi_mlp3d();
   if (!h) return ddmi_fail(DDMI_ERR_STATE, "out of host memory");
   h->m.cfg = *cfg;
@@ -407,10 +422,38 @@ static int maybe_up4(ConvArgs* a, int dt, Scratch& sc) {
 int ddmi_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                    int k, int stride, int upsample, int numerics, int splitk) {
   int dt;
-  DDMI_TRY(numerics_to_dt(numerics, &dt));
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(numerics, &dt, &x3));
   DDMI_REQUIRE(x && w && y, "op_conv2d: null tensor");
   Scratch sc;
   void *xn, *wp, *yn, *ws = nullptr;
+  if (x3 && Cin % 8 == 0) {   // DDMI_PARITY_BF16X3: split the input, bf16 kernel over K = 3 Cin into fp32 slabs, fp32 finish (net.hip)
+    int hin = upsample == 1 ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
+    int Ho = (hin + 2 * pad - k) / stride + 1, Wo = (win + 2 * pad - k) / stride + 1;
+    void *x3in, *w3;
+    DDMI_TRY(sc.get((size_t)B * Cin * H * W * 4, &xn));
+    DDMI_TRY(sc.get((size_t)B * Cin * H * W * 6, &x3in));
+    DDMI_TRY(sc.get((size_t)Cout * Cin * k * k * 6, &w3));
+    DDMI_TRY(sc.get((size_t)B * Cout * Ho * Wo * 4, &yn));
+    DDMI_TRY(launch_nchw_to_nhwc(x, xn, DT_F32, B, Cin, H * W, 0));
+    DDMI_TRY(launch_split_x3((const float*)xn, x3in, (int64_t)B * H * W, Cin, 0));
+    DDMI_TRY(launch_pack_conv_weight_x3(w, w3, Cout, Cin, k, k, 0));
+    ConvArgs f{};
+    f.x = xn; f.bias = bias; f.y = yn;
+    f.B = B; f.Hin = H; f.Win = W; f.Cin = Cin; f.Hout = Ho; f.Wout = Wo; f.Cout = Cout;
+    f.KH = f.KW = k; f.stride = stride; f.pad = pad; f.ups = upsample; f.out_scale = 1.f;
+    ConvArgs b = f;
+    b.x = x3in; b.w = w3; b.Cin = 3 * Cin; b.bias = nullptr; b.y = nullptr; b.force_ws = 1;
+    b.splitk = splitk > 0 ? splitk : conv_pick_splitk(b, DT_BF16);
+    DDMI_TRY(sc.get((size_t)b.splitk * B * Ho * Wo * Cout * sizeof(float), &ws));
+    b.splitk_ws = (float*)ws;
+    DDMI_TRY(launch_conv(b, DT_BF16, 0));
+    f.splitk = b.splitk; f.splitk_ws = (float*)ws;
+    DDMI_TRY(launch_splitk_finish(f, DT_F32, 0));
+    DDMI_TRY(launch_nhwc_to_nchw(yn, DT_F32, y, B, Cout, Ho * Wo, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    return DDMI_OK;
+  }
   int hin = upsample == 1 ? 2 * H : H, win = upsample ? 2 * W : W, pad = k / 2;
   int Ho = (hin + 2 * pad - k) / stride + 1, Wo = (win + 2 * pad - k) / stride + 1;
   DDMI_TRY(sc.get((size_t)B * Cin * H * W * dt_size(dt), &xn));

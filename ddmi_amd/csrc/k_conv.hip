@@ -1479,7 +1479,7 @@ static TileCfg pick_tile(int M, int Cout, int dt, int cfg = 0) {
 static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   ConvK k{};
   k.x = a.x; k.w = a.w; k.bias = a.bias; k.emb = a.emb; k.res = a.res; k.y = a.y; k.y_nchw = a.y_nchw;
-  k.ws = splitk > 1 ? a.splitk_ws : nullptr;
+  k.ws = (splitk > 1 || a.force_ws) ? a.splitk_ws : nullptr;
   k.chstat = nullptr;   // launch_conv sets it after checking that every wave takes the fast epilogue
   k.B = a.B; k.Hin = a.Hin; k.Win = a.Win; k.Cin = a.Cin; k.Hout = a.Hout; k.Wout = a.Wout; k.Cout = a.Cout;
   k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
@@ -1733,7 +1733,7 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
 
 static int check_conv(const ConvArgs& a, int dt) {
   int eps = dt == DT_F32 ? 4 : 8;
-  DDMI_REQUIRE(a.x && a.w && (a.y || a.y_nchw), "conv: null tensor");
+  DDMI_REQUIRE(a.x && a.w && (a.y || a.y_nchw || (a.force_ws && a.splitk_ws)), "conv: null tensor");
   DDMI_REQUIRE(a.Cin % eps == 0, "conv: Cin must be a multiple of the 16-byte vector");
   DDMI_REQUIRE(a.Cout % 4 == 0, "conv: Cout must be a multiple of 4");
   DDMI_REQUIRE(!a.emb || a.emb_stride % 4 == 0, "conv: emb_stride must be a multiple of 4");
@@ -1783,7 +1783,7 @@ int conv_chstat_rows(const ConvArgs& a, int dt) {
 int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   DDMI_TRY(check_conv(a, dt));
   int splitk = std::max(1, a.splitk);
-  DDMI_REQUIRE(splitk == 1 || a.splitk_ws, "conv: split-K needs a workspace");
+  DDMI_REQUIRE((splitk == 1 && !a.force_ws) || a.splitk_ws, "conv: split-K needs a workspace");
   int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
@@ -1808,7 +1808,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
     k.chstat = a.chstat;
   }
   DDMI_TRY(dispatch(k, t, dt, splitk, a.ups == 3 ? 4 : 1, s));
-  if (splitk > 1) DDMI_TRY(launch_splitk_finish(a, dt, s));
+  if (splitk > 1 && !a.force_ws) DDMI_TRY(launch_splitk_finish(a, dt, s));   // force_ws: the caller finishes (in another dtype)
   return DDMI_OK;
 }
 

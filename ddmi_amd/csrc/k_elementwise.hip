@@ -312,6 +312,62 @@ int launch_pack_conv_weight(const float* w, void* packed, int dt, int Cout, int 
   return DDMI_OK;
 }
 
+// =====================================================================================================
+// bf16x3 numerics (DDMI_PARITY_BF16X3): an fp32 GEMM as THREE bf16 MFMA products with fp32 accumulation.
+//   x = xh + xl,  w = wh + wl   (xh = bf16(x), xl = bf16(x - xh): 16 mantissa bits between them)
+//   x . w  ~  xh.wh + xl.wh + xh.wl          (the dropped xl.wl is 2^-16 of the product)
+// realised with the UNCHANGED bf16 convolution kernels by widening K: activations [xh | xl | xh] (3 C channels per pixel),
+// weights [wh | wh | wl] per tap.  1/16 of the fp32-MFMA cost per product becomes 3/16.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) split_x3_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t npix, int C) {
+  const int cv = C / 4;                                   // float4 vectors per pixel
+  const int64_t n = npix * cv, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t p = i / cv;
+    const int c = (int)(i - p * cv) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + p * C + c);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (bf16_t)f[e];
+      lo[e] = (bf16_t)(f[e] - (float)hi[e]);
+    }
+    bf16_t* o = out + p * 3 * C + c;
+    *reinterpret_cast<bf16x4*>(o) = hi;
+    *reinterpret_cast<bf16x4*>(o + C) = lo;
+    *reinterpret_cast<bf16x4*>(o + 2 * C) = hi;
+  }
+}
+int launch_split_x3(const float* x, void* out, int64_t npix, int C, hipStream_t s) {
+  DDMI_REQUIRE(C % 4 == 0, "split_x3: C must be a multiple of 4");
+  const int64_t n = npix * (C / 4);
+  const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 32);
+  hipLaunchKernelGGL(split_x3_kernel, dim3(blocks), dim3(256), 0, s, x, (bf16_t*)out, npix, C);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+// [Cout][Cin][KH][KW] fp32 -> [Cout][tap][wh(Cin) | wh(Cin) | wl(Cin)] bf16
+__global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int taps) {
+  const int64_t n = (int64_t)Cout * Cin * taps, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int ci = (int)(i % Cin);
+    const int64_t r = i / Cin;
+    const int tap = (int)(r % taps), co = (int)(r / taps);
+    const float v = w[((int64_t)co * Cin + ci) * taps + tap];
+    const bf16_t hi = (bf16_t)v, lo = (bf16_t)(v - (float)hi);
+    bf16_t* o = out + (r * 3) * Cin + ci;
+    o[0] = hi; o[Cin] = hi; o[2 * Cin] = lo;
+  }
+}
+int launch_pack_conv_weight_x3(const float* w, void* packed, int Cout, int Cin, int KH, int KW, hipStream_t s) {
+  const int64_t n = (int64_t)Cout * Cin * KH * KW;
+  const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+  hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)packed, Cout, Cin, KH * KW);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 // parity form of (nearest x2 upsample -> 3x3 conv), see k_conv.hip conv_out_row: packed [Cout][9][Cin] bf16 ->
 // [4][Cout][2*2][Cin] bf16, parity p = 2 dy + dx, tap (a, b) of the 2x2 source neighbourhood = the sum of the 3x3 taps
 // that land on that source pixel: rows dy = 0: a0 <- {kh 0}, a1 <- {1, 2};  dy = 1: a0 <- {0, 1}, a1 <- {2} (same for columns)

@@ -30,6 +30,9 @@ int launch_nchw_to_nhwc(const float* src, void* dst, int dt, int B, int C, int H
 int launch_nhwc_to_nchw(const void* src, int dt, float* dst, int B, int C, int HW, hipStream_t s, int ld = 0, int off = 0);
 int launch_concat(const void* a, int Ca, const void* b, int Cb, void* out, int dt, int64_t npix, hipStream_t s);
 int launch_pack_conv_weight(const float* w_oihw, void* packed, int dt, int Cout, int Cin, int KH, int KW, hipStream_t s);
+// bf16x3 numerics: activations fp32 [npix][C] -> bf16 [npix][xh | xl | xh]; weights fp32 OIHW -> bf16 [Cout][tap][wh | wh | wl]
+int launch_split_x3(const float* x, void* out, int64_t npix, int C, hipStream_t s);
+int launch_pack_conv_weight_x3(const float* w_oihw, void* packed, int Cout, int Cin, int KH, int KW, hipStream_t s);
 // bf16 packed [Cout][9][Cin] -> parity form [4][Cout][4][Cin] of (x2 nearest upsample -> 3x3 conv); ConvArgs.ups = 3
 int launch_pack_conv_up4(const void* packed9, void* out, int Cout, int Cin, hipStream_t s);
 // the same from the raw fp32 [Cout][Cin][3][3] tensor: the tap sums are rounded to bf16 once
@@ -94,6 +97,8 @@ struct ConvArgs {
   const void* x3;     // [B, Hout, Wout, C3] or null: the second source of a channel-concatenated block input
   const void* w2;     // [Cout][C2 + C3] packed 1x1 weights
   int C2, C3;
+  int force_ws;       // write the raw fp32 accumulators to splitk_ws even when splitk == 1 (bias / emb / res / y untouched): the
+                      // bf16x3 mode finishes them in fp32 with launch_splitk_finish(..., DT_F32)
 };
 // the 3x3 / stride 1 shapes the halo kernel (and with it the folded skip connection) serves
 bool conv_halo_shape_ok(int H, int W);

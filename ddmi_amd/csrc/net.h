@@ -24,6 +24,7 @@ struct ConvW {
   void* w = nullptr;      // packed [Cout][taps*Cin], network dtype
   float* bias = nullptr;  // [Cout] fp32 (may be null)
   int Cout = 0, Cin = 0, K = 1;
+  void* w_x3 = nullptr;   // bf16x3 numerics: [Cout][tap][wh | wh | wl] bf16 (launch_pack_conv_weight_x3); w stays null then
   void* w_up4 = nullptr;  // bf16 parity form for a fused x2 upsample (launch_pack_conv_up4), made by plan() when an op
   bool want_up4 = false;  // asked for it (op_conv only marks: it returns a tensor id, not a status)
   std::string wkey;       // state-dict key of the raw fp32 weight (make_conv), valid until finalize drops the host copies
@@ -86,6 +87,9 @@ struct TensorDesc {
 
 struct Net {
   int dt = DT_F32;
+  bool x3 = false;                          // DDMI_PARITY_BF16X3: fp32 tensors, every convolution as three bf16 MFMA products (k_elementwise.hip)
+  void* x3_in = nullptr;                    // [pixels][xh | xl | xh] bf16 image of the current convolution's input
+  size_t x3_in_bytes = 0;
   int max_batch = 1;
   bool finalized = false;
   bool autotune = true;                     // bf16 only; DDMI_AUTOTUNE=0 disables

@@ -73,17 +73,21 @@ int Net::make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, c
   HIP_TRY(hipMalloc((void**)&raw, (size_t)n * sizeof(float)));
   hipError_t e = hipMemcpy(raw, w.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight upload failed"); }
+  // bf16x3: the hi / hi / lo image, three bf16 per weight (a Cin that is not a multiple of 8 keeps the fp32 kernel)
+  const bool as_x3 = x3 && Cin % 8 == 0;
+  const size_t pbytes = as_x3 ? (size_t)n * 3 * 2 : (size_t)n * dt_size(dt);
   void* packed = nullptr;
-  e = hipMalloc(&packed, (size_t)n * dt_size(dt));
+  e = hipMalloc(&packed, pbytes);
   if (e != hipSuccess) { (void)hipFree(raw); return ddmi_fail(DDMI_ERR_HIP, "weight alloc failed"); }
   dev_allocs.push_back(packed);
-  int rc = launch_pack_conv_weight(raw, packed, dt, Cout, Cin, K, K, 0);
+  int rc = as_x3 ? launch_pack_conv_weight_x3(raw, packed, Cout, Cin, K, K, 0) : launch_pack_conv_weight(raw, packed, dt, Cout, Cin, K, K, 0);
   hipError_t e2 = hipDeviceSynchronize();
   (void)hipFree(raw);
   if (rc != DDMI_OK) return rc;
   if (e2 != hipSuccess) return ddmi_fail(DDMI_ERR_HIP, "weight pack failed");
-  weight_bytes += (size_t)n * dt_size(dt);
-  c.w = packed;
+  weight_bytes += pbytes;
+  if (as_x3) c.w_x3 = packed;
+  else c.w = packed;
   if (bias) {
     DDMI_REQUIRE((int)bias->size() == Cout, "bias size mismatch");
     DDMI_TRY(dev_upload(bias->data(), Cout, &c.bias));
@@ -217,6 +221,17 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
     a->w2 = n.convs[o.skip_conv].w;
     a->bias = o.bias_fused;
   }
+}
+
+// bf16x3: the bf16 launch that stands for the fp32 convolution `f` - K widened to 3 Cin over the [xh | xl | xh] image of its
+// input, raw accumulators to the fp32 slab(s); bias / embedding / residual / store happen in launch_splitk_finish(f, DT_F32)
+static ConvArgs x3_launch_args(const ConvArgs& f, const void* x3_in, const void* w_x3, float* ws) {
+  ConvArgs a = f;
+  a.x = x3_in; a.w = w_x3; a.Cin = 3 * f.Cin;
+  a.bias = nullptr; a.emb = nullptr; a.res = nullptr; a.y = nullptr; a.y_nchw = nullptr; a.chstat = nullptr;
+  a.out_scale = 1.f;
+  a.force_ws = 1; a.splitk_ws = ws;
+  return a;
 }
 
 // parity-form weights [4][Cout][4][Cin] of the convolutions op_conv marked (want_up4); every failure is returned
@@ -362,14 +377,22 @@ int Net::plan() {
   }
   // split-K slabs: worst case over batch sizes
   splitk_bytes = 0;
+  const int cdt = x3 ? DT_BF16 : dt;   // the dtype the convolution kernels compute in
   for (const Op& o : ops) {
     if (o.kind != OP_CONV) continue;
+    const bool ox3 = x3 && convs[o.conv].w_x3;
     for (int B = 1; B <= max_batch; ++B) {
       ConvArgs a;
       fill_conv_args(*this, o, B * o.bmul, &a);
-      int sk = conv_pick_splitk(a, dt);
-      if (sk > 1) splitk_bytes = std::max(splitk_bytes, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
+      if (ox3) a = x3_launch_args(a, nullptr, nullptr, nullptr);
+      int sk = conv_pick_splitk(a, ox3 ? DT_BF16 : dt);
+      if (sk > 1 || ox3) splitk_bytes = std::max(splitk_bytes, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
+      if (ox3) x3_in_bytes = std::max(x3_in_bytes, (size_t)a.B * a.Hin * a.Win * a.Cin * 2);
     }
+  }
+  if (x3_in_bytes) {
+    HIP_TRY(hipMalloc(&x3_in, x3_in_bytes));
+    dev_allocs.push_back(x3_in);
   }
   if (splitk_bytes) {
     HIP_TRY(hipMalloc((void**)&splitk_ws, splitk_bytes));
@@ -378,7 +401,7 @@ int Net::plan() {
   // ---- autotune every distinct conv shape at max_batch (bf16 perf mode only) -----------------------------
   const char* env = getenv("DDMI_AUTOTUNE");
   if (env && env[0] == '0') autotune = false;
-  if (autotune && dt == DT_BF16) {
+  if (autotune && cdt == DT_BF16) {
     auto t0 = std::chrono::steady_clock::now();
     size_t tws_bytes = std::max<size_t>(splitk_bytes, (size_t)256 << 20);
     float* tws = nullptr;
@@ -417,11 +440,15 @@ int Net::plan() {
       ConvArgs a;
       fill_conv_args(*this, o, max_batch * o.bmul, &a);
       a.y = tptr(o.out);  // timing only: results are overwritten by the real run
+      if (x3) {
+        if (!convs[o.conv].w_x3) continue;   // stays on the fp32 kernel
+        a = x3_launch_args(a, x3_in, convs[o.conv].w_x3, tws);   // tuned as the bf16 problem it runs as (slab output)
+      }
       std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups, a.x2 ? a.C2 + a.C3 : 0};   // last: folded skip channels
       auto it = cache.find(key);
       if (it == cache.end()) {
         ConvPlan p;
-        rc = conv_autotune(a, dt, tws, tws_bytes, &p);
+        rc = conv_autotune(a, cdt, tws, tws_bytes, &p);
         if (rc != DDMI_OK) break;
         it = cache.emplace(key, p).first;
       }
@@ -457,7 +484,7 @@ int Net::plan() {
     }
     tune_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  if (dt == DT_BF16 && autotune) {
+  if (cdt == DT_BF16 && autotune) {
     // slabs must also cover smaller batches run with the tuned tile and a heuristic split
     size_t need = splitk_bytes;
     for (const Op& o : ops) {
@@ -465,9 +492,11 @@ int Net::plan() {
       for (int B = 1; B < max_batch; ++B) {
         ConvArgs a;
         fill_conv_args(*this, o, B * o.bmul, &a);
+        const bool ox3 = x3 && convs[o.conv].w_x3;
+        if (ox3) a = x3_launch_args(a, nullptr, nullptr, nullptr);
         a.cfg = o.tuned.cfg;
-        int sk = conv_pick_splitk(a, dt);
-        if (sk > 1) need = std::max(need, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
+        int sk = conv_pick_splitk(a, ox3 ? DT_BF16 : dt);
+        if (sk > 1 || ox3) need = std::max(need, (size_t)sk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float));
       }
     }
     if (need > splitk_bytes) {
@@ -541,6 +570,19 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         a.splitk_ws = splitk_ws;
         if (a.splitk > 1)
           DDMI_REQUIRE((size_t)a.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
+        if (x3 && convs[o.conv].w_x3) {
+          // three bf16 products per fp32 product: split the input, run the bf16 kernel over K = 3 Cin into the fp32 slab(s),
+          // finish (+ bias + embedding + residual, store) in fp32
+          DDMI_TRY(launch_split_x3((const float*)a.x, x3_in, (int64_t)a.B * a.Hin * a.Win, a.Cin, s));
+          ConvArgs b = x3_launch_args(a, x3_in, convs[o.conv].w_x3, splitk_ws);
+          if (!(Bnet == max_batch && o.tuned.cfg > 0)) b.splitk = conv_pick_splitk(b, DT_BF16);
+          b.splitk = std::max(1, b.splitk);
+          DDMI_REQUIRE((size_t)b.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
+          DDMI_TRY(launch_conv(b, DT_BF16, s));
+          a.splitk = b.splitk;
+          DDMI_TRY(launch_splitk_finish(a, DT_F32, s));
+          break;
+        }
         if (o.stat_out >= 0) {
           const int rows = conv_chstat_rows(a, dt);
           if (rows > 0) a.chstat = (float*)tptr(o.stat_out);

@@ -119,7 +119,7 @@ class MLP:
         R_h, R_w = coords.shape[2], coords.shape[3]
         N = R_h * R_w
         pts = coords[0].permute(1, 2, 0).reshape(N, 2).to(device=dev, dtype=torch.float32).contiguous()
-        native = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+        native = torch.float32 if _lib.is_fp32_storage(self.numerics) else torch.bfloat16
         planes, layouts = [], set()
         for p in hdbf:
             if p.dtype == native and p.is_contiguous(memory_format=torch.channels_last):

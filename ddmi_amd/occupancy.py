@@ -151,7 +151,7 @@ class Autoencoder3D:
             mk = lambda p: torch.empty((B, oc, p, p), device=x.device, dtype=torch.float32)
             layout = _lib.LAYOUT_NCHW_F32
         else:
-            dt = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+            dt = torch.float32 if _lib.is_fp32_storage(self.numerics) else torch.bfloat16
             mk = lambda p: torch.empty((B, oc, p, p), device=x.device, dtype=dt, memory_format=torch.channels_last)
             layout = _lib.LAYOUT_NHWC_NATIVE
         planes = [[mk(p) for p in self.plane_hw] for _ in range(3)]
@@ -261,7 +261,7 @@ class MLP3D:
         self.finalize(dev.index or 0)
         pts = coords.to(device=dev, dtype=torch.float32).contiguous()
         B, N = pts.shape[0], pts.shape[1]
-        native = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+        native = torch.float32 if _lib.is_fp32_storage(self.numerics) else torch.bfloat16
         flat = [t for lst in hdbf for t in lst]
         if all(t.dtype == native and t.is_contiguous(memory_format=torch.channels_last) for t in flat):
             layout = _lib.LAYOUT_NHWC_NATIVE

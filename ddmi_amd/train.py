@@ -34,7 +34,7 @@ class TrainContext:
 
     def __init__(self, numerics="bf16", device="cuda:0"):
         self.numerics = _lib.numerics_code(numerics)
-        self.dtype = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+        self.dtype = torch.float32 if _lib.is_fp32_storage(self.numerics) else torch.bfloat16
         self.device = torch.device(device)
         _lib.init_device(self.device.index or 0)
         h = C.c_void_p()

@@ -247,7 +247,7 @@ class VITAutoencoder:
             mk = lambda hh, ww: torch.empty((B, oc, hh, ww), device=x.device, dtype=torch.float32)
             layout = _lib.LAYOUT_NCHW_F32
         else:
-            dt = torch.float32 if self.numerics == _lib.PARITY_FP32 else torch.bfloat16
+            dt = torch.float32 if _lib.is_fp32_storage(self.numerics) else torch.bfloat16
             mk = lambda hh, ww: torch.empty((B, oc, hh, ww), device=x.device, dtype=dt, memory_format=torch.channels_last)
             layout = _lib.LAYOUT_NHWC_NATIVE
         planes = [[mk(p, p) for p in self.plane_hw], [mk(T, p) for p in self.plane_hw], [mk(T, p) for p in self.plane_hw]]

@@ -32,13 +32,15 @@ INJECT_TAG = 0xFFFE0000  # philox.h PHILOX_TAG_INJECT
 
 
 # ---------------- G2: BASELINE config 1 -------------------------------------------------------------------------------
+@pytest.mark.parametrize("numerics", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name,T,S,eta", [("ddim", 1000, 10, 0.0), ("anc", 10, 10, 1.0)])
-def test_config1_g2(golden, name, T, S, eta):
+def test_config1_g2(golden, name, T, S, eta, numerics):
     """AFHQ full-width nets on a [1,64,16,16] latent, 10 steps, R = 64 (si = 4), torch.manual_seed(777): the reference's
-    generate() (tools/ldm/image.py:225-249) captured by oracle/gen_golden_g2.py; parity mode < 1e-3."""
+    generate() (tools/ldm/image.py:225-249) captured by oracle/gen_golden_g2.py; both parity modes (fp32 MFMA, and bf16x3 = every
+    convolution as three bf16 MFMA products) < 1e-3."""
     g2 = golden.npz("G2_config1.npz")
     ddpmconfig = dict(timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta, channels=64, image_size=16)
-    pipe = ImagePipeline(AFHQ_UNET, AFHQ_DD, MLP_CFG, ddpmconfig, AFHQ_EMBED, test_resolution=64, numerics="fp32",
+    pipe = ImagePipeline(AFHQ_UNET, AFHQ_DD, MLP_CFG, ddpmconfig, AFHQ_EMBED, test_resolution=64, numerics=numerics,
                          max_batch=1, device=DEV)
     pipe.load_named_seed("afhq").finalize()
     img, z = pipe.generate([0], base_seed=int(g2["seed"]), rng="reference", return_latent=True)

@@ -254,3 +254,67 @@ def test_wgrad_rows_are_batch_invariant_at_the_bench_batch(case):
     assert rel_l2(b128, b2) < 1e-3
     for r in (0, 63, 127):
         assert rel_err(dx128[r], dx2[r % 2]) < 1e-5, r
+
+
+# ---------------- bf16x3: the third numerics mode ------------------------------------------------------------------------
+X3_CONV_CASES = [(2, 64, 8, 8, 224, 3, 1, 0), (1, 224, 16, 16, 224, 3, 1, 0), (2, 96, 8, 8, 192, 3, 2, 0), (2, 64, 8, 8, 64, 3, 1, 1),
+                 (2, 448, 8, 8, 224, 1, 1, 0), (1, 128, 32, 32, 128, 3, 1, 0), (1, 512, 8, 8, 512, 3, 1, 0), (2, 672, 64, 64, 224, 3, 1, 0)]
+
+
+@pytest.mark.parametrize("case", X3_CONV_CASES)
+def test_conv2d_bf16x3_is_fp32_accurate(case):
+    """DDMI_PARITY_BF16X3: x.w as xh.wh + xl.wh + xh.wl on the bf16 MFMA kernels (K widened to 3 Cin), fp32 accumulate and finish:
+    within 1e-4 of torch's fp32 convolution where plain bf16 is at 1e-2 - stride 2, fused upsample, 1x1, split-K, the halo kernel."""
+    B, Cin, H, W, Cout, k, stride, ups = case
+    tag = "convx3%s" % (case,)
+    x = iw.normal(tag, "x", (B, Cin, H, W))
+    w = iw.normal(tag, "w", (Cout, Cin, k, k), 0.0, 1.0 / math.sqrt(Cin * k * k))
+    b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+    xt = torch.from_numpy(x)
+    if ups:
+        xt = F.interpolate(xt, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xt.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride, padding=k // 2)
+    L = _lib.lib()
+    _lib.init_device(0)
+    xd, wd, bd = _dev(x), _dev(w), _dev(b)
+    y = torch.empty(tuple(ref.shape), device=DEV, dtype=torch.float32)
+    for splitk in (0, 2):
+        _lib.check(L.ddmi_op_conv2d(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, Cin, H, W, Cout, k, stride, ups,
+                                    _lib.numerics_code("bf16x3"), splitk))
+        assert rel_err(y, ref) < 1e-4 and rel_l2(y, ref) < 3e-5, (splitk, rel_err(y, ref), rel_l2(y, ref))
+
+
+def test_afhq_networks_full_size_bf16x3_vs_oracle():
+    """The full-size AFHQ UNet, decoder and fused MLP in the bf16x3 mode against the CPU oracle: the north star's 1e-3."""
+    from ddmi_amd.autoencoder import Autoencoder
+    from ddmi_amd.coords import generation_coords
+    from ddmi_amd.mlp import MLP
+    from ddmi_amd.unet import UNetModel
+    from helpers import AFHQ_DD, AFHQ_EMBED, AFHQ_UNET, MLP_CFG
+    unet = UNetModel(**AFHQ_UNET, numerics="bf16x3", max_batch=2)
+    st = named_state("afhq.unet", unet.manifest())
+    unet.load_state_dict(st)
+    x = iw.normal("afhq", "x", (1, 64, 64, 64))
+    t = torch.tensor([437], dtype=torch.int64)
+    ref = O.unet_forward(O.to_state(st), AFHQ_UNET, torch.from_numpy(x), t)
+    eps = unet(torch.from_numpy(x).to(DEV), t.to(DEV))
+    assert rel_err(eps, ref) < TOL_FP32 and rel_l2(eps, ref) < TOL_FP32, (rel_err(eps, ref), rel_l2(eps, ref))
+    xx = torch.from_numpy(np.concatenate([x, x])).to(DEV)        # B = 2 = max_batch: the autotuned plans
+    eps2 = unet(xx, t.expand(2).contiguous().to(DEV))
+    assert rel_err(eps2[1:2], ref) < TOL_FP32
+    del unet
+    torch.cuda.empty_cache()
+    z = iw.normal("afhq", "z", (1, 64, 64, 64))
+    vae = Autoencoder(AFHQ_DD, AFHQ_EMBED, numerics="bf16x3", max_batch=1)
+    vst = named_state("afhq.vae", vae.manifest())
+    vae.load_state_dict(vst)
+    ref_planes = O.vae_decode(O.to_state(vst), AFHQ_DD, torch.from_numpy(z))
+    planes = vae.decode(torch.from_numpy(z).to(DEV))
+    for p, r in zip(planes, ref_planes):
+        assert rel_err(p, r) < TOL_FP32 and rel_l2(p, r) < TOL_FP32
+    mlp = MLP(**MLP_CFG, numerics="bf16x3")
+    mst = named_state("afhq.mlp", mlp.manifest())
+    mlp.load_state_dict(mst)
+    ref_rgb = O.image_mlp(O.to_state(mst), O.generate_coords(256), ref_planes, 1.0)
+    rgb = mlp(generation_coords(256), hdbf=planes, si=1.0)
+    assert rel_err(rgb, ref_rgb) < TOL_FP32

@@ -35,6 +35,7 @@ for st in "$@"; do
     convvar)   timeout 900 python -m pytest tests/test_gpu_ops.py -q -k "every_bf16_variant" > $log 2>&1 ;;
     skyfull)   DDMI_METRICS_LOG=gpurun_out/${tag}_metrics.jsonl timeout 1500 python -m pytest tests/test_gpu_video.py -q -x -s -k "full_size_decode_vs_oracle" > $log 2>&1 ;;
     r3train)   timeout 1500 python -m pytest tests/test_gpu_round3.py -q -x -s -k "training or wgrad or ema or resume" > $log 2>&1 ;;
+    benchfull) timeout 2400 python bench.py --steps 2 --warmup 1 > gpurun_out/${tag}_bench_n1_b512.json 2> $log ;;
     attnbench) timeout 300 python tools/bench_attn_mh.py 128 > $log 2>&1 ;;
     *) echo "unknown stage $st" ;;
   esac
