@@ -903,9 +903,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
 // Loop structure, fragment double-buffering and the swizzle are those of the pipe kernel.
 // =====================================================================================================
 // SKIP instantiation: the ResBlock's 1x1 skip_connection rides on the same accumulators.  The 64-channel blocks of the skip
-// sources x2 (| x3) are appended to the block list as ONE-stage blocks: their halo is staged like any other block's (the border
-// rows are fetched and never read), the single stage reads it at the centre tap's shift and takes its weight stage from
-// w2 [Cout][C2 + C3].  Same loop, same pipeline; skip halos are fetched whole and two blocks ahead (see the refill).
+// sources x2 (| x3) are appended to the block list as ONE-stage blocks: their A tile is the tile's 256 centre pixels as plain rows
+// in a halo buffer (32 DMA groups instead of the halo's 50), the single stage takes its weight stage from w2 [Cout][C2 + C3].
+// Same loop, same pipeline; skip tiles are fetched whole and two blocks ahead (see the refill).
 // What it replaces: a separate 1x1 launch at 0.4-0.6 PFLOP/s that wrote the skip tensor (HBM-bound at 64x64) plus this kernel's
 // epilogue reading it back as the residual.  Split z = 0 carries the skip blocks.
 #define HALO_MAX_ROWS 400  // 6 x 66 = 396 rows at W = 64, rounded up to whole 8-row DMA groups (the tail lanes write zeros)
@@ -957,11 +957,18 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int cb_begin = (blockIdx.z * a.SPS) / 9;
   const int cb_end = min(NCB, cb_begin + a.SPS / 9);
   const int nmain = max(cb_end - cb_begin, 0);
+  // The skip arguments are read from the kernarg segment WHERE THEY ARE USED (laundered pointer, scalar loads that hit the constant
+  // cache): as ordinary kernel arguments they would occupy a dozen SGPRs for the whole 3x3 loop, which has none to spare.
+  auto skip_arg = [&](auto proto, size_t off) {
+    const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *reinterpret_cast<const decltype(proto)*>(kp + off);
+  };
   int NCB2 = 0, nsk = 0;
   if constexpr (SKIP) {
     if (blockIdx.z == 0) {
-      NCB2 = (a.C2 + 63) >> 6;
-      nsk = NCB2 + ((a.C3 + 63) >> 6);
+      NCB2 = (skip_arg(int(0), offsetof(ConvK, C2)) + 63) >> 6;
+      nsk = NCB2 + ((skip_arg(int(0), offsetof(ConvK, C3)) + 63) >> 6);
     }
   }
   const int nblk = nmain + nsk, nstage = nmain * 9 + nsk;
@@ -973,7 +980,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   };
   auto blk_C = [&](int blk) {
     if (!SKIP || blk < nmain) return a.Cin;
-    return blk - nmain >= NCB2 ? a.C3 : a.C2;
+    return skip_arg(int(0), blk - nmain >= NCB2 ? offsetof(ConvK, C3) : offsetof(ConvK, C2));
   };
 
   // weight rows: lane owns physical slot lane&7 of row (lane>>3) of its 8-row group; one channel offset per lane
@@ -983,24 +990,31 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   // halo group g: 8 halo rows hr = 8g + (lane>>3); the slot swizzle depends on hr, so the channel offset does too
   auto load_halo_group = [&](int g, int blk, int hbuf) {
     const int hr = g * 8 + (lane >> 3);
+    const int C = blk_C(blk);
+    const int ch = blk_cbl(blk) * 64 + (((lane & 7) ^ ((hr >> 1) & 7)) << 3);
+    if constexpr (SKIP) {
+      if (blk >= nmain) {
+        // a skip block is read at the centre tap only: its A tile is the tile's 256 pixels as plain rows (row = tile-local pixel,
+        // 32 groups instead of the halo's 50), the tile's pixels being contiguous in memory.  The source's descriptor is built
+        // here from scalars (rebased like x's at the tile's first sample).
+        const T* base = (const T*)skip_arg((const void*)nullptr, blk - nmain >= NCB2 ? offsetof(ConvK, x3) : offsetof(ConvK, x2)) +
+                        (int64_t)b_first * hw * C;
+        const uint64_t r = (uint64_t)(a.B - b_first) * hw * C * sizeof(T);
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, r > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)r, 0x00020000);
+        const int ok = (hr < BM) & (m0 + hr < a.M) & (ch < C);
+        const unsigned voff = ok ? (unsigned)(((m0 - b_first * hw + hr) * C + ch) * SZ) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
+        return;
+      }
+    }
     int sb = 0, rem = hr;                           // sample block of the tile, halo row inside it
     if (SPT > 1) { sb = hr / HRS; rem = hr - sb * HRS; }
     const int hy = rem / HWd, hx = rem - hy * HWd;
     const int iy = ty0 - 1 + hy, ix = hx - 1;
-    const int C = blk_C(blk);
-    const int ch = blk_cbl(blk) * 64 + (((lane & 7) ^ ((hr >> 1) & 7)) << 3);
     const int ok = (hr < NH) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W) & (ch < C);
     // samples past the batch end fall outside the descriptor's extent and read as zeros
     const unsigned voff = ok ? (unsigned)(((sb * hw + iy * W + ix) * C + ch) * SZ) : OOB_OFFSET;
-    auto rs = x_rsrc;
-    if constexpr (SKIP) {
-      if (blk >= nmain) {   // a skip source: its descriptor is built here from scalars (rebased like x's at the tile's first sample)
-        const T* base = (const T*)(blk - nmain >= NCB2 ? a.x3 : a.x2) + (int64_t)b_first * hw * C;
-        const uint64_t r = (uint64_t)(a.B - b_first) * hw * C * sizeof(T);
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, r > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)r, 0x00020000);
-      }
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(HB + hbuf * H_BYTES + g * 1024), 16, voff, 0, 0, 0);
   };
   auto load_b_stage = [&](int blk, int tap, int bbuf, bool valid) {
     int cvalid, rstride, col, base = b_base0;
@@ -1011,14 +1025,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       rstride = Ktot * SZ;
       col = (tap * a.Cin + c0) * SZ;
     } else {   // w2 [Cout][C2 + C3]: columns of block j; a ragged last block of x2 must not read x3's columns
-      const int j = blk - nmain, Cs = a.C2 + a.C3;
+      const int C2 = skip_arg(int(0), offsetof(ConvK, C2));
+      const int j = blk - nmain, Cs = C2 + skip_arg(int(0), offsetof(ConvK, C3));
       const bool second = j >= NCB2;
-      const int col0 = second ? a.C2 + (j - NCB2) * 64 : j * 64;
-      cvalid = valid & (col0 + coff < (second ? Cs : a.C2));
+      const int col0 = second ? C2 + (j - NCB2) * 64 : j * 64;
+      cvalid = valid & (col0 + coff < (second ? Cs : C2));
       rstride = Cs * SZ;
       col = col0 * SZ;
       base = (n0 * Cs + coff) * SZ;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, a.w2_bytes, 0x00020000);
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)skip_arg((const void*)nullptr, offsetof(ConvK, w2)), 0,
+                                             skip_arg(unsigned(0), offsetof(ConvK, w2_bytes)), 0x00020000);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
@@ -1045,12 +1061,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int woff0 = (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
   // `shift` = kh*(W+2) + kw moves every A fragment to the tap's halo row; it stays a loop-carried scalar so the
   // per-fragment swizzle (5 VALU) is recomputed per stage instead of being hoisted into ~70 loop-invariant VGPRs
-  auto read_frags = [&](int hbuf, int bbuf, int shift, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+  // `plain` (a skip block's tile): row = tile-local pixel wm*TM + 16 i + lr, no border; lr is recovered from woff0 (no new register)
+  auto read_frags = [&](int hbuf, int bbuf, int shift, bool plain, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
     const unsigned char* ph = HB + hbuf * H_BYTES;
-    const int vb = hr00 + shift;
+    const int vb = (SKIP && plain) ? wm * TM - wn * TN + (woff0 >> 7) : hr00 + shift;
+    const int rj = (SKIP && plain) ? 0 : 2;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      int hr = vb + i * 16 + ((i * 16) / W) * 2;
+      int hr = vb + i * 16 + ((i * 16) / W) * rj;
       xf[i] = *reinterpret_cast<const bf16x8*>(ph + ((hr * ROWB + ((lg ^ ((hr >> 1) & 7)) << 4)) ^ (c << 6)));
     }
     const unsigned char* pw = BB + bbuf * B_BYTES + (woff0 ^ (c << 6));
@@ -1081,7 +1099,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ts) ts[2] = wall_clock64();
-    read_frags(0, 0, 0, 0, xa, wa);
+    read_frags(0, 0, 0, false, 0, xa, wa);
   }
   // one flat stage loop; (blk, tap, kw, shift, hbuf) are scalar state so nothing per-tap gets unrolled or hoisted
   int blk = 0, tap = 0, kw = 0, shift = 0, hbuf = 0;
@@ -1091,7 +1109,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     const bool c1 = blk_cbl(blk) * 64 + 32 < blk_C(blk);
     const bool one_stage = SKIP && blk >= nmain;   // a skip block: centre tap only
     // [A] chunk 0 of this stage on set a, prefetch chunk 1 into set b
-    read_frags(hbuf, bbuf, shift, 1, xb, wb);
+    read_frags(hbuf, bbuf, shift, one_stage, 1, xb, wb);
     mma(xa, wa);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // next weight stage + halo pieces issued a stage ago have landed; BB[bbuf] is free
@@ -1111,24 +1129,21 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       // the last barrier of the last nine-stage block and behind the barrier of every one-stage block.
       const int q = tap * NW + wave;
       if (!one_stage && tap < 8) {
-        if (blk + 1 < nblk && q < GH) load_halo_group(q, blk + 1, hbuf ^ 1);
+        if (blk + 1 < nblk && q < ((SKIP && blk + 1 >= nmain) ? BM / 8 : GH)) load_halo_group(q, blk + 1, hbuf ^ 1);
       } else if (SKIP && blk + 1 >= nmain && blk + 2 < nblk) {
-        for (int g = wave; g < GH; g += NW) load_halo_group(g, blk + 2, hbuf);
+        for (int g = wave; g < BM / 8; g += NW) load_halo_group(g, blk + 2, hbuf);
       }
     }
     // advance the scalar state to the next stage
     if (!one_stage) {
       ++tap;
       if (++kw == 3) { kw = 0; shift += HWd - 2; } else { ++shift; }
-      if (tap == 9) {
-        tap = 0; shift = 0; ++blk; hbuf ^= 1;
-        if (SKIP && blk >= nmain) shift = HWd + 1;   // skip blocks are read at the centre tap
-      }
+      if (tap == 9) { tap = 0; shift = 0; ++blk; hbuf ^= 1; }
     } else {
       ++blk; hbuf ^= 1;
     }
     // [B] chunk 1 on set b, prefetch chunk 0 of the next stage into set a
-    if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, 0, xa, wa);
+    if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, SKIP && blk >= nmain, 0, xa, wa);
     if (c1) mma(xb, wb);
   }
   if (ts) ts[3] = wall_clock64();

@@ -174,7 +174,11 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
 }
 
 bool Net::can_fold_skip(int in, int conv) const {
-  static const bool off = getenv("DDMI_SKIP_FOLD") && atoi(getenv("DDMI_SKIP_FOLD")) == 0;   // diagnostics: A/B against the separate 1x1 launch
+  // OFF by default: measured on one box (B = 512, same process order, round 3) the folded launch is SLOWER than conv2 + the separate
+  // 1x1 launches (41.9 vs 30.1 ms of a 139 ms UNet step; 32.5 vs ~29.5 for the variant that staged the skip sources as halos):
+  // a one-tap stage fills 60 KB of LDS for the MFMAs a 3x3 stage runs on 34 KB, and the extra scalar state of the second block
+  // list spills 44 SGPRs in the stage loop.  DDMI_SKIP_FOLD=1 enables it (kept: parity-tested through ddmi_op_conv2d_skip).
+  static const bool off = !(getenv("DDMI_SKIP_FOLD") && atoi(getenv("DDMI_SKIP_FOLD")) == 1);
   const TensorDesc& t = tensors[in];
   return !off && dt == DT_BF16 && convs[conv].K == 3 && t.bmul == 1 && conv_halo_shape_ok(t.H, t.W);
 }

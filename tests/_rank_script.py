@@ -42,6 +42,9 @@ def second_finalize():
     """A second network finalized later in the same process: rank 0 appends the shapes it had to tune; the other ranks must see
     the appended text (not tune on their own because the first call left DDMI_TUNE_FILE set)."""
     p = os.environ.get("DDMI_TUNE_FILE")
+    if p is None:      # a single process shares nothing: no plan file is forced on it
+        rec["second_from"] = None
+        return
     if rank == 0:
         with open(p, "a") as f:
             f.write("second network, tuned by rank 0\n")

