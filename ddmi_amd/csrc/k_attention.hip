@@ -287,7 +287,14 @@ template <int D> __device__ __forceinline__ int att_vswz(int key) {
   else return 2 * (key & 7);
 }
 
-template <int D, int QF, bool SEG3>
+// LAZY (q pre-scaled: the softmax scale x log2 e is folded into the q rows of the qkv projection at finalize, so a score IS the
+// base-2 exponent): the loop is VALU-bound (d = 32: ~7 VALU slots per score against 0.6 MFMA), so the per-score work is cut to the
+// exponential itself.  The score accumulators start at -m_ref, the query's REFERENCE maximum, so the MFMA result is already
+// s - m_ref and p = exp2(that) needs no multiply and no subtract.  m_ref is only moved when some score of the wave exceeds it by
+// more than 2^6 (wave-uniform branch, rare after the first tiles: p <= 64 stays well inside bf16 / fp32 range; the final division
+// by the denominator - accumulated with the same p - makes any reference equally exact), and the cross-lane maximum, the
+// rescale of the output accumulators and the extra subtract are paid only then.
+template <int D, int QF, bool SEG3, bool LAZY = false>
 __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   using T = bf16_t;
   constexpr int KT = 64, RB = D * 2, TILE = KT * RB;
@@ -409,6 +416,10 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   if (ntiles > 1) load_tile(1);
   __syncthreads();
 
+  if constexpr (LAZY) {
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) m_run[qf] = 0.f;   // the reference before the first tile (which always takes the rescale path)
+  }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int buf = kt & 1;
     const unsigned char* kb = ks + buf * TILE;
@@ -419,7 +430,10 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
     for (int f = 0; f < 4; ++f) {
       const int row = 16 * f + lr;
 #pragma unroll
-      for (int qf = 0; qf < QF; ++qf) sc[qf][f] = f32x4{0, 0, 0, 0};
+      for (int qf = 0; qf < QF; ++qf) {
+        const float init = LAZY ? -m_run[qf] : 0.f;
+        sc[qf][f] = f32x4{init, init, init, init};
+      }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
         bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * RB + att_swz<D>(row, 4 * kk + lg) * 16);
@@ -436,6 +450,57 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
     // ---- online softmax (base 2, scale folded into the exponent) -----------------------------------------
     const bool tail = (kt + 1) * KT > N;
     bf16x8 pf[QF][2];
+    if constexpr (LAZY) {
+      if (tail) {  // wave-uniform: only the last tile pays for the key-range masks
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (kt * KT + 16 * f + 4 * lg + j >= N) sc[qf][f][j] = -INFINITY;
+      }
+      float lmax[QF];
+      bool grow = kt == 0;
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) {
+        float t = sc[qf][0][0];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
+        lmax[qf] = t;
+        grow |= t > 6.0f;
+      }
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // move the reference of every query of the wave to its true running maximum
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          float t = lmax[qf];
+          t = fmaxf(t, __shfl_xor(t, 16));
+          t = fmaxf(t, __shfl_xor(t, 32));
+          t = fmaxf(t, kt == 0 ? -1e30f : 0.f);       // never lower the reference (a masked / very negative tile keeps it)
+          if (kt == 0) {
+            // nothing accumulated yet: no rescale (and no exp2 of a possibly huge difference)
+          } else {
+            const float alpha = __builtin_amdgcn_exp2f(-t);
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+            ol[qf][0] *= alpha;
+          }
+          m_run[qf] += t;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
+        }
+      }
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)__builtin_amdgcn_exp2f(sc[qf][f][j]);
+    } else {
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
       float tmax = -INFINITY;
@@ -465,6 +530,7 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 #pragma unroll
       for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
       ol[qf][0] *= alpha;   // the other three rows of the fragment hold the same sum and are never read
+    }
     }
     // ---- O^T += V^T . P^T, V^T fragments by transposed LDS reads -------------------------------------------
 #pragma unroll
@@ -516,10 +582,14 @@ static int launch_attention_v2(const AttnArgs& a_in, hipStream_t s) {
   constexpr int lds = 4 * 64 * D * 2;
   auto kern1 = attention_v2_kernel<D, QF, false>;
   auto kern3 = attention_v2_kernel<D, QF, true>;
+  auto kern1l = attention_v2_kernel<D, QF, false, true>;
+  auto kern3l = attention_v2_kernel<D, QF, true, true>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1l), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3l), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int N = a_in.seg_len[0] + a_in.seg_len[1] + a_in.seg_len[2];
@@ -529,8 +599,10 @@ static int launch_attention_v2(const AttnArgs& a_in, hipStream_t s) {
   a.xcd_map = (a.B % 8 == 0 || a.B >= 64) ? 0 : BH >= 8 ? 1 : 2;
   if (const char* e = getenv("DDMI_ATTN_XCDMAP")) a.xcd_map = atoi(e);   // diagnostics (tools/bench_attn_afhq.py): 2 = plain order
   dim3 grid(a.xcd_map == 0 ? tiles * a.heads * (cdiv(a.B, 8) * 8) : a.xcd_map == 1 ? tiles * (cdiv(BH, 8) * 8) : tiles * BH);
-  if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(kern3, grid, dim3(256), lds, s, a);
+  static const bool no_lazy = getenv("DDMI_ATTN_LAZY") && atoi(getenv("DDMI_ATTN_LAZY")) == 0;   // diagnostics: the eager-maximum loop
+  const bool lazy = a.q_prescaled && !no_lazy;
+  if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(lazy ? kern1l : kern1, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(lazy ? kern3l : kern3, grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -557,6 +629,10 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   AttnArgs a = a_in;
   const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
   DDMI_REQUIRE(a.B > 0 && N > 0 && a.heads > 0 && a.d > 0 && a.d <= 512, "attention: bad shape (head dim must be <= 512)");
+  if (a.q_prescaled) {   // the producer of q folded scale x log2 e into it: every bf16 kernel's base-2 exponent is the score itself
+    DDMI_REQUIRE(dt == DT_BF16, "attention: pre-scaled q is a bf16-mode arrangement");
+    a.scale = 0.69314718055994531f;   // x log2 e = 1
+  }
   DDMI_REQUIRE(a.qkv[0] && a.out[0], "attention: null tensor");
   const int vn = dt == DT_BF16 ? 8 : 4;
   // 16-byte vector loads / 8-16-byte stores need every row, head and q/k/v block to start on a vector boundary

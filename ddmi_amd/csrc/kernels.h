@@ -102,6 +102,8 @@ struct ConvArgs {
 };
 // the 3x3 / stride 1 shapes the halo kernel (and with it the folded skip connection) serves
 bool conv_halo_shape_ok(int H, int W);
+// whether a bf16 network may fold the softmax scale into its qkv projection for head dim d (the shapes attention_v2_kernel serves)
+inline bool attention_prescale_ok(int dt, int d) { return dt == DT_BF16 && d % 8 == 0 && d <= 128; }
 // bump when the meaning of (cfg, order) changes: plan files written for other tables are ignored (net.hip)
 #define CONV_PLAN_VERSION 3
 struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // result of conv_autotune (0 = heuristic)
@@ -139,6 +141,8 @@ struct AttnArgs {
   float scale;
   int vec_ok;          // filled by launch_attention
   int legacy_name;     // profiler label only
+  int q_prescaled;     // q already carries softmax scale x log2 e (folded into the qkv projection's q rows, bf16 networks): see
+                       // attention_v2_kernel LAZY
   int xcd_map;         // filled by the bf16 launcher: workgroup -> (sample, head, query tile) order (k_attention.hip)
 };
 int launch_attention(const AttnArgs& a, int dt, hipStream_t s);

@@ -25,7 +25,8 @@ int unet_finalize(UNet& u);
 // weight bundles of the blocks shared by the image and video networks (created once, emitted per tensor)
 struct ResW { int gn1 = -1, c1 = -1, gn2 = -1, c2 = -1, cs = -1, cs2 = -1, emb_off = -1; float eps = 1e-5f;
               int cs_full = -1; };   // cs_full: the un-split 1x1 skip_connection (folded into c2's launch where the shape allows)
-struct AttnW { int gn = -1, cqkv = -1, cp = -1, heads = 1, head_dim = 0, legacy = 0; float eps = 1e-5f, scale = 1.f; };
+struct AttnW { int gn = -1, cqkv = -1, cp = -1, heads = 1, head_dim = 0, legacy = 0; float eps = 1e-5f, scale = 1.f;
+               int q_prescaled = 0; };   // the projection's q rows carry scale x log2 e (bf16 networks, k_attention.hip LAZY)
 // split > 0: the input will be the channel concat of a `split`-channel tensor and another one (emit_resblock_cat)
 int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split = 0);
 int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out);

@@ -106,13 +106,32 @@ int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w) {
   DDMI_REQUIRE(u.cfg.num_head_channels > 0 && ch % u.cfg.num_head_channels == 0, "channels must be a multiple of num_head_channels");
   w->eps = 1e-5f;
   DDMI_TRY(n.make_gn(pre + "norm.", &w->gn));
-  DDMI_TRY(n.make_conv(pre + "qkv.weight", pre + "qkv.bias", &w->cqkv));
-  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
-  DDMI_REQUIRE(n.convs[w->cqkv].Cout == 3 * ch && n.convs[w->cqkv].Cin == ch, "qkv shape mismatch at " + pre);
   w->head_dim = u.cfg.num_head_channels;
   w->heads = ch / w->head_dim;
   w->legacy = 1;
   w->scale = 1.0f / std::sqrt((float)w->head_dim);  // (d^-1/4 q) . (d^-1/4 k), openaimodel.py:413-416
+  w->q_prescaled = attention_prescale_ok(n.dt, w->head_dim) ? 1 : 0;
+  if (w->q_prescaled) {
+    // bf16 network: softmax scale x log2 e folded into the q rows of the projection (QKVAttentionLegacy layout: per head
+    // [q | k | v] blocks of head_dim rows, openaimodel.py:406-408), in fp32 before the one rounding to bf16 - the attention kernel's
+    // base-2 exponent is then the score itself (k_attention.hip, LAZY)
+    const HostTensor* wt = n.find(pre + "qkv.weight");
+    const HostTensor* bt = n.find(pre + "qkv.bias");
+    if (!wt || !bt) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + pre + "qkv.*'");
+    DDMI_REQUIRE(wt->numel() == (int64_t)3 * ch * ch && bt->numel() == 3 * ch, "qkv shape mismatch at " + pre);
+    std::vector<float> ws = wt->data, bs = bt->data;
+    const float f = w->scale * 1.44269504088896341f;
+    for (int h = 0; h < w->heads; ++h)
+      for (int r = h * 3 * w->head_dim; r < h * 3 * w->head_dim + w->head_dim; ++r) {
+        for (int c = 0; c < ch; ++c) ws[(size_t)r * ch + c] *= f;
+        bs[r] *= f;
+      }
+    DDMI_TRY(n.make_conv_host(ws, 3 * ch, ch, 1, &bs, &w->cqkv));
+  } else {
+    DDMI_TRY(n.make_conv(pre + "qkv.weight", pre + "qkv.bias", &w->cqkv));
+  }
+  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
+  DDMI_REQUIRE(n.convs[w->cqkv].Cout == 3 * ch && n.convs[w->cqkv].Cin == ch, "qkv shape mismatch at " + pre);
   return DDMI_OK;
 }
 
@@ -126,7 +145,7 @@ int emit_attn_single(Net& n, const AttnW& w, int x, int* out) {
   o.in = qkv;
   o.out = n.new_tensor(w.heads * w.head_dim, t.H, t.W, -1, t.bmul);
   o.bmul = t.bmul;
-  o.heads = w.heads; o.head_dim = w.head_dim; o.legacy_layout = w.legacy; o.scale = w.scale;
+  o.heads = w.heads; o.head_dim = w.head_dim; o.legacy_layout = w.legacy; o.scale = w.scale; o.q_prescaled = w.q_prescaled;
   n.ops.push_back(o);
   *out = n.op_conv(o.out, w.cp, 1, 0, x, -1);
   return DDMI_OK;
@@ -151,7 +170,7 @@ int emit_attn_joint(Net& n, const AttnW& w, int xy, int tp, int* out_xy, int* ou
   o.in = q_xy; o.in2 = q_tp;
   o.out = n.new_tensor(w.heads * w.head_dim, txy.H, txy.W, -1, 1);
   o.out2 = n.new_tensor(w.heads * w.head_dim, tt.H, tt.W, -1, 2);
-  o.heads = w.heads; o.head_dim = w.head_dim; o.legacy_layout = w.legacy; o.scale = w.scale;
+  o.heads = w.heads; o.head_dim = w.head_dim; o.legacy_layout = w.legacy; o.scale = w.scale; o.q_prescaled = w.q_prescaled;
   n.ops.push_back(o);
   *out_xy = n.op_conv(o.out, w.cp, 1, 0, xy, -1);
   *out_tp = n.op_conv(o.out2, w.cp, 1, 0, tp, -1);
@@ -173,13 +192,19 @@ int make_qkv_attn(Net& n, const std::string& pre, int ch, int heads, bool expand
     wcat.insert(wcat.end(), wt->data.begin(), wt->data.end());
     bcat.insert(bcat.end(), bt->data.begin(), bt->data.end());
   }
-  DDMI_TRY(n.make_conv_host(wcat, 3 * cq, ch, 1, &bcat, &w->cqkv));
-  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
-  DDMI_REQUIRE(n.convs[w->cp].Cin == cq && n.convs[w->cp].Cout == ch, "proj_out shape mismatch at " + pre);
   w->heads = heads;
   w->head_dim = cq / heads;
   w->legacy = 0;
   w->scale = 1.0f / std::sqrt((float)w->head_dim);  // xformers.ops.memory_efficient_attention default scale
+  w->q_prescaled = attention_prescale_ok(n.dt, w->head_dim) ? 1 : 0;
+  if (w->q_prescaled) {   // rows [0, cq) are q: softmax scale x log2 e folded in (see make_unet_attnblock)
+    const float f = w->scale * 1.44269504088896341f;
+    for (size_t i = 0; i < (size_t)cq * ch; ++i) wcat[i] *= f;
+    for (int i = 0; i < cq; ++i) bcat[i] *= f;
+  }
+  DDMI_TRY(n.make_conv_host(wcat, 3 * cq, ch, 1, &bcat, &w->cqkv));
+  DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
+  DDMI_REQUIRE(n.convs[w->cp].Cin == cq && n.convs[w->cp].Cout == ch, "proj_out shape mismatch at " + pre);
   return DDMI_OK;
 }
 

@@ -55,6 +55,7 @@ struct Op {
   int emb_off = -1;
   int heads = 0;
   int head_dim = 0;    // OP_ATTN_MH
+  int q_prescaled = 0;    // OP_ATTN_MH: q already carries softmax scale x log2 e (AttnW::q_prescaled)
   int legacy_layout = 0;  // OP_ATTN_MH: per-head [q|k|v] channel interleave (QKVAttentionLegacy) instead of [q heads|k heads|v heads]
   int seq_len = 0;     // OP_SEG_IN / OP_SEG_OUT: L of the external [B, C, L] tensor
   int out_nchw = 0;   // OP_CONV: write fp32 NCHW to external output slot `ext`
