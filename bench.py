@@ -114,13 +114,13 @@ def _profile_entry(glob_pat, live_name):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", glob_pat)))   # r1_..., r2_...: the newest round wins
     if not files or not live_name:
         return None
-    m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)>", live_name)
-    m2 = re.match(r"conv_(pipe|halo)<bf16,(\d+)x(\d+)>", live_name)
+    m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)(,ilv)?>", live_name)
+    m2 = re.match(r"conv_(pipe|halo|halo\+skip)<bf16,(\d+)x(\d+)>", live_name)
     if m:
-        bm, bn, kk, nst = (int(v) for v in m.groups())
-        pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}>")
-    elif m2 and m2.group(1) == "halo":  # conv_halo_kernel<BN, WM, WN>: BM is fixed at 256
-        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, ")
+        bm, bn, kk, nst = (int(v) for v in m.groups()[:4])
+        pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}, {'true' if m.group(5) else 'false'}>")
+    elif m2 and m2.group(1).startswith("halo"):  # conv_halo_kernel<BN, WM, WN, SKIP>: BM is fixed at 256
+        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}>")
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
