@@ -136,6 +136,7 @@ SYMBOLS = {
     "ddmi_mcubes_count": (_I, [C.POINTER(McubesGrid), _VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _VP]),
     "ddmi_mcubes_emit": (_I, [C.POINTER(McubesGrid), _VP, _VP, _VP, _I, C.c_double, _VP]),
     "ddmi_image_to_u8": (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_fused_bias_act": (_I, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int64, _I, _I, _I, C.c_float, C.c_float, _I, _VP]),
     # training (include/ddmi_hip.h "Training")
     "ddmi_train_create": (_I, [_I, C.POINTER(_VP)]),
     "ddmi_train_destroy": (_I, [_VP]),

@@ -554,3 +554,55 @@ int launch_planes_channels(const void* planes, void* chans, int dt, int Bn, int 
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
+
+// =====================================================================================================
+// fused_bias_act: the reference's one compiled operator (models/d2c_vae/op/fused_bias_act.cpp:4-20, kernel
+// fused_bias_act_kernel.cu:19-49: StyleGAN2's bias + activation + gain with its gradient modes), as a standalone op so
+// that models/d2c_vae/op imports on ROCm without nvcc.  On the generation path it is fused into the MLP kernels; this
+// entry point serves the reference's own module code (FusedLeakyReLU and its double-backward).
+//   z = x + bias[(i / step_b) % size_b]          (bias optional)
+//   act 1 (linear): grad 0, 1 -> z;  grad 2 -> 0
+//   act 3 (lrelu) : grad 0 -> z > 0 ? z : alpha z;   grad 1 -> ref > 0 ? z : alpha z  (ref = the forward's output);   grad 2 -> 0
+//   out = y * scale.     Any other (act, grad) pair behaves as (1, 0), as the reference's `default:` label does.
+// Arithmetic in the tensor's own type rounded per operation like the reference's scalar_t code: fp32 in fp32; bf16 / fp16
+// through fp32 with one rounding at the end (the reference computes half in half: differences are one ulp of the narrow type).
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) fused_bias_act_kernel(const T* __restrict__ x, const T* __restrict__ bias, const T* __restrict__ ref,
+                                                             T* __restrict__ y, int64_t n, int64_t step_b, int size_b, int mode, float alpha,
+                                                             float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float z = (float)x[i];
+    if (bias) z += (float)bias[(i / step_b) % size_b];
+    float v;
+    switch (mode) {
+      case 12: case 32: v = 0.f; break;
+      case 30: v = z > 0.f ? z : z * alpha; break;
+      case 31: v = (ref ? (float)ref[i] : 0.f) > 0.f ? z : z * alpha; break;
+      default: v = z; break;
+    }
+    y[i] = (T)(v * scale);
+  }
+}
+
+extern "C" int ddmi_fused_bias_act(const void* x, const void* bias, const void* refer, void* y, int64_t size_x, int64_t step_b, int size_b,
+                                   int act, int grad, float alpha, float scale, int dtype, void* stream) {
+  DDMI_REQUIRE(x && y && size_x >= 0 && step_b >= 1, "fused_bias_act: bad arguments");
+  DDMI_REQUIRE(bias == nullptr || size_b >= 1, "fused_bias_act: bias without a size");
+  if (size_x == 0) return DDMI_OK;
+  const int blocks = (int)std::min<int64_t>(cdiv64(size_x, 256), 256 * 32);
+  const int mode = act * 10 + grad;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(fused_bias_act_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)bias, (const float*)refer,
+                               (float*)y, size_x, step_b, size_b, mode, alpha, scale); break;
+    case 1: hipLaunchKernelGGL(fused_bias_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)refer,
+                               (bf16_t*)y, size_x, step_b, size_b, mode, alpha, scale); break;
+    case 2: hipLaunchKernelGGL(fused_bias_act_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, (const _Float16*)bias,
+                               (const _Float16*)refer, (_Float16*)y, size_x, step_b, size_b, mode, alpha, scale); break;
+    default: return ddmi_fail(DDMI_ERR_INVALID, "fused_bias_act: dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

@@ -287,6 +287,15 @@ int ddmi_mcubes_emit(const ddmi_mcubes_grid* grid, const void* workspace, double
  * exactly as torch / numpy do, so the bytes equal the reference's `(fake_img * 255).astype(np.uint8)`. */
 int ddmi_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, void* stream);
 
+/* The reference's compiled operator `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)`
+ * (models/d2c_vae/op/fused_bias_act.cpp:4-20 -> fused_bias_act_kernel.cu:19-49): out = act'(x + bias[(i / step_b) % size_b]) * scale
+ * with act 1 = linear, 3 = leaky ReLU(alpha) and grad 0 = value, 1 = gradient gated by the sign of `refer` (the forward's output),
+ * 2 = zeros; bias / refer may be null (the reference passes empty tensors); step_b = product of the dims after the channel dim,
+ * size_b = channels; dtype 0 fp32, 1 bf16, 2 fp16 (one type for all four tensors).  Device pointers, asynchronous on `stream`.
+ * `ddmi_amd/fused_act.py` wraps it as the module object the reference's fused_act.py builds with torch's JIT loader. */
+int ddmi_fused_bias_act(const void* x, const void* bias, const void* refer, void* y, int64_t size_x, int64_t step_b, int size_b,
+                        int act, int grad, float alpha, float scale, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Diagnostic single-op entry points (used by the parity tests; reference-layout tensors in, reference-layout
  * tensors out; they allocate temporaries and synchronise - not for the hot path).

@@ -318,3 +318,59 @@ def test_afhq_networks_full_size_bf16x3_vs_oracle():
     ref_rgb = O.image_mlp(O.to_state(mst), O.generate_coords(256), ref_planes, 1.0)
     rgb = mlp(generation_coords(256), hdbf=planes, si=1.0)
     assert rel_err(rgb, ref_rgb) < TOL_FP32
+
+
+# ---------------- the reference's compiled operator as a standalone HIP op -----------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_fused_bias_act_matches_the_reference_kernel_semantics(dtype):
+    """`fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)` (op/fused_bias_act.cpp:4-20, fused_bias_act_kernel.cu:19-49)
+    on 2-D, 4-D and 5-D inputs (bias along dim 1), every (act, grad) pair of the kernel's switch, empty bias / refer - against the
+    switch restated with torch ops (oracle.fused_lrelu is the (3, 0) case pinned by fixture M1)."""
+    from ddmi_amd.fused_act import fused
+    g = torch.Generator().manual_seed(11)
+    tol = {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    for shape in [(3, 256), (2, 66, 5, 7), (1, 8, 3, 4, 5)]:
+        x = torch.randn(shape, generator=g)
+        b = torch.randn(shape[1], generator=g)
+        ref = torch.randn(shape, generator=g)
+        xd, bd, rd = (t.to(DEV, dtype) for t in (x, b, ref))
+        x, b, ref = xd.float().cpu(), bd.float().cpu(), rd.float().cpu()          # the values the kernel sees
+        z = x + b.view(1, -1, *([1] * (len(shape) - 2)))
+        empty = xd.new_empty(0)
+        want = {(3, 0): torch.where(z > 0, z, 0.2 * z), (3, 1): torch.where(ref > 0, z, 0.2 * z), (3, 2): torch.zeros_like(z),
+                (1, 0): z, (1, 1): z, (1, 2): torch.zeros_like(z), (7, 0): z}
+        for (act, grad), w in want.items():
+            got = fused.fused_bias_act(xd, bd, rd if grad == 1 else empty, act, grad, 0.2, 2 ** 0.5)
+            assert got.dtype == dtype and got.shape == xd.shape
+            assert rel_err(got.float(), w * 2 ** 0.5) < tol, (shape, act, grad)
+        nob = fused.fused_bias_act(xd, empty, empty, 3, 0, 0.2, 1.0)
+        assert rel_err(nob.float(), torch.where(x > 0, x, 0.2 * x)) < tol
+        if len(shape) == 2:   # the oracle's restatement is written for the MLP's [points, channels] activations
+            assert rel_err(fused.fused_bias_act(xd, bd, empty, 3, 0, 0.2, 2 ** 0.5).float(), O.fused_lrelu(x, b)) < tol
+
+
+def test_fused_leaky_relu_module_and_its_gradients():
+    """`FusedLeakyReLU` / `fused_leaky_relu` (op/fused_act.py:61-99) on the HIP op: value, first derivatives w.r.t. input and bias and
+    the double backward (gradient of a gradient penalty) against torch autograd of leaky_relu(x + b) * sqrt 2."""
+    from ddmi_amd.fused_act import FusedLeakyReLU
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 16, 6, 5), generator=g).to(DEV).requires_grad_(True)
+    m = FusedLeakyReLU(16).to(DEV)
+    with torch.no_grad():
+        m.bias.copy_(torch.randn(16, generator=g))
+    xr = x.detach().clone().requires_grad_(True)
+    br = m.bias.detach().clone().requires_grad_(True)
+    y = m(x)
+    yr = F.leaky_relu(xr + br.view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    assert rel_err(y, yr) < 1e-6
+    w = torch.randn(tuple(y.shape), generator=g).to(DEV)
+    (gx,) = torch.autograd.grad((y * w).sum(), x, create_graph=True)
+    (gxr,) = torch.autograd.grad((yr * w).sum(), xr, create_graph=True)
+    assert rel_err(gx, gxr) < 1e-6
+    (gx ** 2).sum().backward()          # a gradient penalty: needs the op's double backward
+    (gxr ** 2).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 1e-5
+    y2 = m(x.detach())
+    y2.sum().backward()
+    F.leaky_relu(xr.detach() + br.view(1, -1, 1, 1), 0.2).mul(2 ** 0.5).sum().backward()
+    assert rel_err(m.bias.grad, br.grad) < 1e-5
