@@ -101,17 +101,51 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x
 // grid (nsplit, B); block = NV * R threads like the stats kernel: every thread owns ONE 16-byte channel vector for all
 // its pixels, so its scale/shift live in registers (no per-element index math, no LDS in the streaming loop).
 struct GnSegs { int nseg, nsplit[3], total_hw; };
-template <typename T>
+// Statistics straight from the producers' epilogues (ConvArgs::chstat: per row block of `rows` pixels and channel (sum, sumsq)
+// in fp32).  Round 2 reduced them in a launch of their own (gn_chstat_finish_kernel: 61 launches of ~35 us per UNet evaluation =
+// 1.5 % of a step, mostly launch latency: 59 MB at most); here every workgroup of the apply pass reduces its SAMPLE's blocks itself
+// before it starts streaming (64 blocks x C channels = 115 KB at 64x64: ~3 us of a > 100 us workgroup; the splits of a sample
+// repeat it - L2 hits).  Fixed order, fp64: deterministic.
+struct GnChstat { const float* cs1; const float* cs2; int rows1, rows2; };
+template <typename T, bool CHSTAT>
 __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, T* __restrict__ y,
                                 const double* __restrict__ part,
                                 GnSegs sg, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                float eps, int silu, int HW, int C, int NV, int R) {
+                                float eps, int silu, int HW, int C, int NV, int R, GnChstat ch) {
   constexpr int VN = Vec16<T>::N;
   __shared__ float mr[GN_GROUPS * 2];  // mean, rstd per group
   int b = blockIdx.y;
   int tid = threadIdx.x;
   int cpg = C / GN_GROUPS;
-  if (tid < GN_GROUPS) {
+  if constexpr (CHSTAT) {
+    extern __shared__ double cred[];   // [2 C]: (sum, sumsq) per channel over the sample
+    for (int i = tid; i < 2 * C; i += blockDim.x) {
+      const int c = i >> 1;
+      const bool second = ch.cs2 != nullptr && c >= C1;
+      const int ldc = ch.cs2 == nullptr ? C : (second ? C - C1 : C1), nblk = HW / (second ? ch.rows2 : ch.rows1);
+      const float* p = (second ? ch.cs2 : ch.cs1) + ((int64_t)b * nblk * ldc) * 2 + (i - (second ? 2 * C1 : 0));
+      double acc = 0.0;
+      int k = 0;
+      for (; k + 3 < nblk; k += 4) {   // four loads in flight; the adds stay in block order
+        const float v0 = p[(int64_t)k * ldc * 2], v1 = p[(int64_t)(k + 1) * ldc * 2], v2 = p[(int64_t)(k + 2) * ldc * 2],
+                    v3 = p[(int64_t)(k + 3) * ldc * 2];
+        acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+      }
+      for (; k < nblk; ++k) acc += (double)p[(int64_t)k * ldc * 2];
+      cred[i] = acc;
+    }
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s1 += cred[2 * c]; s2 += cred[2 * c + 1]; }
+      double cnt = (double)HW * cpg;
+      double m = s1 / cnt;
+      double var = s2 / cnt - m * m;
+      if (var < 0) var = 0;
+      mr[tid * 2] = (float)m;
+      mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  } else if (tid < GN_GROUPS) {
     double s1 = 0.0, s2 = 0.0;
     // statistics run over every segment of the sample (the video path normalises xy | xt | yt tokens jointly)
     for (int sgi = 0; sgi < sg.nseg; ++sgi) {
@@ -289,12 +323,32 @@ int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const f
     }
   }
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * dt_size(dt), s);
+  GnChstat none{};
   if (dt == DT_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (const float*)x2, C1, (float*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R);
+    hipLaunchKernelGGL((gn_apply_kernel<float, false>), g, dim3(threads), 0, s, (const float*)x, (const float*)x2, C1, (float*)y, stats, sg, gamma,
+                       beta, eps, silu, HW, C, NV, R, none);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma,
+                       beta, eps, silu, HW, C, NV, R, none);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+// GroupNorm apply with the statistics taken from the producers' channel-statistics buffers (bf16 networks; see gn_apply_kernel)
+int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, const float* cs2, int rows2, const float* gamma,
+                           const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2, int C1) {
+  DDMI_REQUIRE(cs1 && rows1 > 0 && HW % rows1 == 0 && (cs2 == nullptr || (rows2 > 0 && HW % rows2 == 0 && C1 > 0 && C1 < C)),
+               "groupnorm: bad channel-statistics buffers");
+  DDMI_REQUIRE(C % GN_GROUPS == 0 && C % 8 == 0, "groupnorm: C must be a multiple of 32");
+  const int NV = C / 8, R = std::max(1, 256 / NV);
+  const int threads = std::max(64, cdiv(NV * R, 64) * 64);
+  dim3 g(gn_splits(B, HW), B);
+  GnSegs sg{};
+  sg.nseg = 1; sg.nsplit[0] = (int)g.x; sg.total_hw = HW;
+  GnChstat ch{cs1, cs2, rows1, rows2};
+  PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * 2 + 8.0 * B * C * (HW / rows1), s);
+  hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), g, dim3(threads), (size_t)2 * C * sizeof(double), s, (const bf16_t*)x, (const bf16_t*)x2, C1,
+                     (bf16_t*)y, (const double*)nullptr, sg, gamma, beta, eps, silu, HW, C, NV, R, ch);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

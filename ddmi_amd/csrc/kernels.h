@@ -63,6 +63,9 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
 // as launch_gn_stats with one segment.
 int launch_gn_chstat_finish(const float* cs1, int rows1, const float* cs2, int rows2, int C1, double* stats, int B, int HW, int C,
                             hipStream_t s);
+// apply pass that reduces the producers' channel statistics itself (no finish launch); bf16 tensors
+int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, const float* cs2, int rows2, const float* gamma,
+                           const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2 = nullptr, int C1 = 0);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1,
                     const void* x2 = nullptr, int C1 = 0);

@@ -542,6 +542,13 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         const void* x2 = o.in2 >= 0 ? tptr(o.in2) : nullptr;
         DDMI_REQUIRE(g.C == C, "groupnorm channel mismatch");
         double* st = gn_stats;
+        static const bool fused_finish = !(getenv("DDMI_GN_FINISH_PASS") && atoi(getenv("DDMI_GN_FINISH_PASS")) == 1);   // diagnostics: the round-2 finish launch
+        if (fused_finish && o.stat_in >= 0 && stat_rows[o.in] > 0 && (o.in2 < 0 || (o.stat_in2 >= 0 && stat_rows[o.in2] > 0))) {
+          DDMI_TRY(launch_gn_apply_chstat(tptr(o.in), tptr(o.out), (const float*)tptr(o.stat_in), stat_rows[o.in],
+                                          o.in2 >= 0 ? (const float*)tptr(o.stat_in2) : nullptr, o.in2 >= 0 ? stat_rows[o.in2] : 0, g.gamma, g.beta,
+                                          o.eps, o.silu, B, t.H * t.W, C, s, x2, t.C));
+          break;
+        }
         if (o.stat_in >= 0 && stat_rows[o.in] > 0 && (o.in2 < 0 || (o.stat_in2 >= 0 && stat_rows[o.in2] > 0)))
           DDMI_TRY(launch_gn_chstat_finish((const float*)tptr(o.stat_in), stat_rows[o.in], o.in2 >= 0 ? (const float*)tptr(o.stat_in2) : nullptr,
                                            o.in2 >= 0 ? stat_rows[o.in2] : 0, t.C, st, B, t.H * t.W, C, s));
