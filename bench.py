@@ -630,7 +630,7 @@ def main():
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
-    ap.add_argument("--parity-batch", type=int, default=64, help="samples per batch of the bf16x3 parity-mode leg of parity_check")
+    ap.add_argument("--parity-batch", type=int, default=128, help="samples per batch of the bf16x3 parity-mode leg of parity_check")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="afhq: skip the one-step shapenet / sky / train legs behind the headline run")
     ap.add_argument("--seed", type=int, default=777)

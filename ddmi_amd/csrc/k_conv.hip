@@ -60,6 +60,9 @@ struct ConvK {
   const void* w2;
   int C2, C3;
   unsigned w2_bytes;
+  // bf16x3 numerics: the bf16 kernels finish in fp32 themselves - fp32 NHWC output and fp32 residual (general epilogue)
+  float* y32;
+  const float* res32;
 };
 
 template <typename T> struct Tile;
@@ -194,12 +197,27 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV]
       }
     }
   }
+  if (a.res32) {
+    const float* p = a.res32 + (int64_t)m * a.Cout + n;
+#pragma unroll
+    for (int q = 0; q < NV; q += 4) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(p + q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q + e] += t[e];
+    }
+  }
 #pragma unroll
   for (int e = 0; e < NV; ++e) v[e] *= a.out_scale;
   if (a.y_nchw) {
     int r = m - b * hw;
 #pragma unroll
     for (int e = 0; e < NV; ++e) a.y_nchw[((int64_t)b * a.Cout + n + e) * hw + r] = v[e];
+    return;
+  }
+  if (a.y32) {
+    float* p = a.y32 + conv_out_row(a, m, b, hw) * a.Cout + n;
+#pragma unroll
+    for (int q = 0; q < NV; q += 4) *reinterpret_cast<f32x4*>(p + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
     return;
   }
   T* p = yg + conv_out_row(a, m, b, hw) * a.Cout + n;
@@ -386,7 +404,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
   if (a.dbg & 8) return;
   if constexpr (PAIRED && sizeof(T) == 2 && (FM == 2 || FM == 4)) {
     // wave-uniform test (m_base, n_base and the kernel arguments are): FM * 16 is 32 or 64, a power of two
-    if (!(a.dbg & 16) && a.ws == nullptr && a.y_nchw == nullptr && n_base + FN * 16 <= a.Cout &&
+    if (!(a.dbg & 16) && a.ws == nullptr && a.y_nchw == nullptr && a.y32 == nullptr && n_base + FN * 16 <= a.Cout &&
         (a.emb == nullptr || (hw & (FM * 16 - 1)) == 0)) {
       conv_epilogue_fast<FM, FN>(a, acc, m_base, n_base, lr, lg, hw);
       return;
@@ -1521,6 +1539,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.w_bytes = (unsigned)wb;
   k.x2 = a.x2; k.x3 = a.C3 > 0 ? a.x3 : nullptr; k.w2 = a.w2; k.C2 = a.x2 ? a.C2 : 0; k.C3 = a.x2 && a.x3 ? a.C3 : 0;
   k.w2_bytes = (unsigned)((uint64_t)a.Cout * (k.C2 + k.C3) * dt_size(dt));
+  k.y32 = a.y32; k.res32 = a.res32;
   *out = k;
   return DDMI_OK;
 }
@@ -1748,7 +1767,8 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
 
 static int check_conv(const ConvArgs& a, int dt) {
   int eps = dt == DT_F32 ? 4 : 8;
-  DDMI_REQUIRE(a.x && a.w && (a.y || a.y_nchw || (a.force_ws && a.splitk_ws)), "conv: null tensor");
+  DDMI_REQUIRE(a.x && a.w && (a.y || a.y_nchw || a.y32 || (a.force_ws && a.splitk_ws)), "conv: null tensor");
+  DDMI_REQUIRE(!(a.y32 || a.res32) || (dt == DT_BF16 && a.splitk <= 1 && a.ups != 3 && !a.res), "conv: fp32 output is the bf16 kernels' one-launch (no split-K) finish");
   DDMI_REQUIRE(a.Cin % eps == 0, "conv: Cin must be a multiple of the 16-byte vector");
   DDMI_REQUIRE(a.Cout % 4 == 0, "conv: Cout must be a multiple of 4");
   DDMI_REQUIRE(!a.emb || a.emb_stride % 4 == 0, "conv: emb_stride must be a multiple of 4");

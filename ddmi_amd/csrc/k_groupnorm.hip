@@ -111,7 +111,7 @@ template <typename T, bool CHSTAT>
 __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, T* __restrict__ y,
                                 const double* __restrict__ part,
                                 GnSegs sg, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                float eps, int silu, int HW, int C, int NV, int R, GnChstat ch) {
+                                float eps, int silu, int HW, int C, int NV, int R, GnChstat ch, int x3_out) {
   constexpr int VN = Vec16<T>::N;
   __shared__ float mr[GN_GROUPS * 2];  // mean, rstd per group
   int b = blockIdx.y;
@@ -180,6 +180,25 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
   const int ldc = x2 == nullptr ? C : (second ? C - C1 : C1);
   const T* xb = (second ? x2 + (int64_t)v * VN - C1 : x + (int64_t)v * VN) + (int64_t)b * HW * ldc;
   T* yb = y + (int64_t)b * HW * C + (int64_t)v * VN;
+  // x3_out (bf16x3 numerics, fp32 input): the output is written as the [xh | xl | xh] bf16 image the consumer convolution reads
+  // (k_elementwise.hip split_x3_kernel) - 6 bytes per element instead of an fp32 tensor plus a split pass over it
+  bf16_t* y3 = reinterpret_cast<bf16_t*>(y) + (int64_t)b * HW * 3 * C + (int64_t)v * VN;
+  auto store_out = [&](int pix, const float* t) {
+    if (sizeof(T) == 4 && x3_out) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16_t)t[e];
+        lo[e] = (bf16_t)(t[e] - (float)hi[e]);
+      }
+      bf16_t* o = y3 + (int64_t)pix * 3 * C;
+      *reinterpret_cast<bf16x4*>(o) = hi;
+      *reinterpret_cast<bf16x4*>(o + C) = lo;
+      *reinterpret_cast<bf16x4*>(o + 2 * C) = hi;
+    } else {
+      Vec16<T>::store(yb + (int64_t)pix * C, t);
+    }
+  };
   int p = p0 + r;
   // eight 16-byte loads in flight per thread: at one workgroup of 256 threads per (split, sample) and 4 workgroups per CU, four
   // loads left ~64 KB in flight per CU - about one HBM latency x the CU's share of the bandwidth, no slack (5.0 TB/s measured)
@@ -198,7 +217,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
         if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
         t[j] = q;
       }
-      Vec16<T>::store(yb + (int64_t)(p + u * R) * C, t);
+      store_out(p + u * R, t);
     }
   }
   for (; p + 3 * R < p1; p += 4 * R) {  // four loads in flight per thread (see gn_stats_kernel)
@@ -213,7 +232,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
         if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
         t[u][j] = q;
       }
-      Vec16<T>::store(yb + (int64_t)(p + u * R) * C, t[u]);
+      store_out(p + u * R, t[u]);
     }
   }
   for (; p < p1; p += R) {
@@ -225,7 +244,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
       if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
       t[j] = q;
     }
-    Vec16<T>::store(yb + (int64_t)p * C, t);
+    store_out(p, t);
   }
 }
 
@@ -304,7 +323,8 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
 
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw, int nseg, const void* x2,
-                    int C1) {
+                    int C1, int x3_out) {
+  DDMI_REQUIRE(!x3_out || dt == DT_F32, "groupnorm: the [xh | xl | xh] output belongs to the fp32 (bf16x3) networks");
   int vn = dt == DT_F32 ? 4 : 8;
   int NV = C / vn;
   int R = std::max(1, 256 / NV);
@@ -326,10 +346,10 @@ int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const f
   GnChstat none{};
   if (dt == DT_F32)
     hipLaunchKernelGGL((gn_apply_kernel<float, false>), g, dim3(threads), 0, s, (const float*)x, (const float*)x2, C1, (float*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R, none);
+                       beta, eps, silu, HW, C, NV, R, none, x3_out);
   else
     hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R, none);
+                       beta, eps, silu, HW, C, NV, R, none, 0);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -348,7 +368,7 @@ int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, 
   GnChstat ch{cs1, cs2, rows1, rows2};
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * 2 + 8.0 * B * C * (HW / rows1), s);
   hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), g, dim3(threads), (size_t)2 * C * sizeof(double), s, (const bf16_t*)x, (const bf16_t*)x2, C1,
-                     (bf16_t*)y, (const double*)nullptr, sg, gamma, beta, eps, silu, HW, C, NV, R, ch);
+                     (bf16_t*)y, (const double*)nullptr, sg, gamma, beta, eps, silu, HW, C, NV, R, ch, 0);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

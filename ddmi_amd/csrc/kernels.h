@@ -68,7 +68,7 @@ int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, 
                            const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2 = nullptr, int C1 = 0);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1,
-                    const void* x2 = nullptr, int C1 = 0);
+                    const void* x2 = nullptr, int C1 = 0, int x3_out = 0);   // x3_out: fp32 in, [xh | xl | xh] bf16 image out (bf16x3 numerics)
 
 // ---- implicit-GEMM convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 upsample) ------
 struct ConvArgs {
@@ -100,6 +100,8 @@ struct ConvArgs {
   const void* x3;     // [B, Hout, Wout, C3] or null: the second source of a channel-concatenated block input
   const void* w2;     // [Cout][C2 + C3] packed 1x1 weights
   int C2, C3;
+  float* y32;         // bf16 kernels only, no split-K: fp32 NHWC output [B, Hout, Wout, Cout] (with bias / emb / res32 added in fp32)
+  const float* res32; // fp32 residual for y32 / y_nchw outputs
   int force_ws;       // write the raw fp32 accumulators to splitk_ws even when splitk == 1 (bias / emb / res / y untouched): the
                       // bf16x3 mode finishes them in fp32 with launch_splitk_finish(..., DT_F32)
 };

@@ -84,6 +84,7 @@ struct TensorDesc {
   size_t off = 0;       // byte offset in the arena (for max batch)
   int dt_override = -1; // -1: network dtype
   int bmul = 1;         // samples held = bmul * B
+  bool x3img = false;   // bf16x3 numerics: held as the [xh | xl | xh] bf16 image (6 bytes per element) its consumer convolutions read
 };
 
 struct Net {
@@ -126,6 +127,7 @@ struct Net {
   int op_conv_skip(int in, int conv, int skip_in, int skip_in2, int skip_conv, int* out);
   int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
   int pack_up4_weights();  // parity-form weights of the marked upsample convolutions (called by plan)
+  void mark_x3_images();         // bf16x3: GroupNorm outputs consumed only by x3 convolutions are produced as x3 images (called by plan)
   void attach_channel_stats();  // pairs GroupNorm inputs with the convolutions that produce them (called by plan)
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }

@@ -51,7 +51,24 @@ int Net::new_tensor(int C, int H, int W, int dt_override, int bmul) {
 size_t Net::tbytes(int id, int B) const {
   const TensorDesc& t = tensors[id];
   int d = t.dt_override >= 0 ? t.dt_override : dt;
+  if (t.x3img) return (size_t)B * t.bmul * t.elems * 6;   // three bf16 per element
   return (size_t)B * t.bmul * t.elems * dt_size(d);
+}
+
+// bf16x3: a GroupNorm whose output is read ONLY as the input of x3 convolutions writes the [xh | xl | xh] image directly (the apply
+// pass's store), so those convolutions skip their split pass and no fp32 copy of the normalised tensor exists
+void Net::mark_x3_images() {
+  static const bool off = getenv("DDMI_X3_FUSED_SPLIT") && atoi(getenv("DDMI_X3_FUSED_SPLIT")) == 0;
+  if (!x3 || off) return;
+  std::vector<int> uses(tensors.size(), 0), conv_uses(tensors.size(), 0);
+  auto use = [&](int t) { if (t >= 0) ++uses[t]; };
+  for (const Op& o : ops) {
+    use(o.in); use(o.in2); use(o.res); use(o.skip_in); use(o.skip_in2); use(o.stat_in); use(o.stat_in2);
+    if (o.kind == OP_CONV && o.in >= 0 && convs[o.conv].w_x3 && o.in_boff == 0 && o.bmul == 1) ++conv_uses[o.in];
+  }
+  for (Op& o : ops)
+    if (o.kind == OP_GN && o.bmul == 1 && o.out >= 0 && uses[o.out] > 0 && uses[o.out] == conv_uses[o.out] && tensors[o.out].C % 8 == 0)
+      tensors[o.out].x3img = true;
 }
 
 int Net::dev_upload(const float* src, int64_t n, float** out) {
@@ -308,6 +325,7 @@ void Net::attach_channel_stats() {
 int Net::plan() {
   DDMI_TRY(pack_up4_weights());
   attach_channel_stats();
+  mark_x3_images();
   const int nops = (int)ops.size();
   auto touch = [&](int id, int i, bool write) {
     if (id < 0) return;
@@ -555,7 +573,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         else
           DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, C, s, 0, 1, x2, t.C));
         DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, C, s, nullptr,
-                                 1, x2, t.C));
+                                 1, x2, t.C, tensors[o.out].x3img ? 1 : 0));
         break;
       }
       case OP_CONV: {
@@ -584,10 +602,18 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         if (x3 && convs[o.conv].w_x3) {
           // three bf16 products per fp32 product: split the input, run the bf16 kernel over K = 3 Cin into the fp32 slab(s),
           // finish (+ bias + embedding + residual, store) in fp32
-          DDMI_TRY(launch_split_x3((const float*)a.x, x3_in, (int64_t)a.B * a.Hin * a.Win, a.Cin, s));
-          ConvArgs b = x3_launch_args(a, x3_in, convs[o.conv].w_x3, splitk_ws);
+          const bool pre_split = tensors[o.in].x3img;   // its GroupNorm wrote the [xh | xl | xh] image already
+          if (!pre_split) DDMI_TRY(launch_split_x3((const float*)a.x, x3_in, (int64_t)a.B * a.Hin * a.Win, a.Cin, s));
+          ConvArgs b = x3_launch_args(a, pre_split ? a.x : x3_in, convs[o.conv].w_x3, splitk_ws);
           if (!(Bnet == max_batch && o.tuned.cfg > 0)) b.splitk = conv_pick_splitk(b, DT_BF16);
           b.splitk = std::max(1, b.splitk);
+          if (b.splitk == 1) {   // one launch: the bf16 kernel's (general) epilogue adds bias / embedding / fp32 residual and stores fp32
+            b.force_ws = 0; b.splitk_ws = nullptr;
+            b.bias = a.bias; b.emb = a.emb; b.emb_stride = a.emb_stride; b.emb_mod = a.emb_mod; b.out_scale = a.out_scale;
+            b.res32 = (const float*)a.res; b.y32 = (float*)a.y; b.y_nchw = a.y_nchw;
+            DDMI_TRY(launch_conv(b, DT_BF16, s));
+            break;
+          }
           DDMI_REQUIRE((size_t)b.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
           DDMI_TRY(launch_conv(b, DT_BF16, s));
           a.splitk = b.splitk;
