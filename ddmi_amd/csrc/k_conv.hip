@@ -368,7 +368,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
       v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
       return v;
     };
-    float* d = a.chstat + (int64_t)(m_base / (FM * 16)) * a.Cout * 2;
+    // block index: row blocks in output order; the parity form of an upsample conv (up4) computes SOURCE rows per parity, and a
+    // sample's 4 hw / rows blocks are laid out [sample][parity][source row block] - any order inside a sample serves the sums
+    int64_t blk = m_base / (FM * 16);
+    if (a.up4) {
+      const int bs = m_base / hw, per = hw / (FM * 16);
+      blk = ((int64_t)bs * 4 + blockIdx.y) * per + (m_base - bs * hw) / (FM * 16);
+    }
+    float* d = a.chstat + blk * a.Cout * 2;
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
       float o[16];
@@ -1803,14 +1810,15 @@ static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave ti
 int conv_chstat_rows(const ConvArgs& a, int dt) {
   static const bool off = getenv("DDMI_GN_CHSTAT") && atoi(getenv("DDMI_GN_CHSTAT")) == 0;
   static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
-  if (off || dbg || dt != DT_BF16 || a.splitk > 1 || a.y_nchw || a.ups == 3 || !a.y) return 0;
+  if (off || dbg || dt != DT_BF16 || a.splitk > 1 || a.y_nchw || !a.y) return 0;
   const int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   if (t.id < 0) return 0;
   const bool paired = t.kps != -1 || a.order > 2 || (a.order == 0 && a.KH * a.KW == 1);   // ring and halo kernels always are
-  const int TM = kRingWave[t.id][0], TN = kRingWave[t.id][1], hw = a.Hout * a.Wout;
+  const int TM = kRingWave[t.id][0], TN = kRingWave[t.id][1];
+  const int hw = a.ups == 3 ? a.Hin * a.Win : a.Hout * a.Wout;   // parity-form upsample: the kernel's rows are source pixels
   if (!paired || a.Cout % TN || hw % TM || M % TM) return 0;
   return TM;
 }

@@ -91,6 +91,13 @@ int ddmi_train_to_nchw(ddmi_train* h, const void* x_nhwc, float* y_nchw, int B, 
 // 1.2 vs 0.85 PFLOP/s); the inference networks reach it through the autotuner, the stateless training ops ask for it here.
 // launch_conv falls back by itself when the shape is not halo-eligible.
 static void prefer_halo(ConvArgs* c, int dt) {
+  if (dt == DT_BF16 && c->KH == 1 && c->Cout % 112 == 0 && (int64_t)c->B * c->Hout * c->Wout >= 256 * 64) {
+    // 1x1 (qkv / proj / skip, forward and dgrad): the pipe kernel equals or beats the heuristic's ring tile on every such shape
+    // (profiles/r3_conv1x1_variants_b512.txt: 992 vs 1 072 us, 789 vs 830, 408 vs 434, 339 vs 355)
+    c->cfg = 14;   // pipe<256,224,4,2>
+    c->order = 3;  // paired fragments
+    return;
+  }
   if (dt != DT_BF16 || c->KH != 3 || c->stride != 1 || c->ups != 0) return;
   const int p224 = cdiv(c->Cout, 224) * 224, p128 = cdiv(c->Cout, 128) * 128;
   if (p224 * 100 <= c->Cout * 115) c->cfg = 20;        // halo<224,4,2>
