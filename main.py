@@ -129,7 +129,7 @@ def load_weights(pipe, args, dc, tag):
 
 
 def train_main(args, dc, rank, world, dev):
-    """`data.mode: train` (image domain): the LDM trainer's loop (tools/ldm/image.py:136-178) on LATENTS - the VAE encoder that
+    """`data.mode: train` (image and occupancy domains): the LDM trainer's loop (tools/ldm/image.py:136-178, tools/ldm/occupancy.py:139-180) on LATENTS - the VAE encoder that
     produces them from images is outside this path.  Latents come from `data.latents` (an .npy of [N,C,H,W] fp32, e.g.
     `vaemodel.encode(y).sample()` dumped by the reference) or, without one, are synthetic N(0,1).  One process per GPU; every
     rank draws its own batches and the gradient slab is all-reduced over RCCL each optimizer step.  Writes `ldm-last.pt` in the
@@ -138,8 +138,10 @@ def train_main(args, dc, rank, world, dev):
     import torch
     from ddmi_amd import checkpoint as CK
     from ddmi_amd.train import LDMTrainStep
-    if args.domain != "image":
-        raise SystemExit("mode: train is implemented for the image domain")
+    # image (tools/ldm/image.py:136-178) and occupancy (tools/ldm/occupancy.py:139-180: the same step on z = cat(z_xy, z_xz, z_yz), a
+    # [B,192,16,16] latent through the same 2-D UNetModel).  The video trainer's UNetModel_Triplane has no backward here.
+    if args.domain not in ("image", "occupancy"):
+        raise SystemExit("mode: train is implemented for the image and occupancy domains")
     lc = args.loss_config or {}
     B = int(dc.get("batch_size", dc.test_batch_size))
     steps = int(os.environ.get("DDMI_TRAIN_STEPS", dc.get("train_steps", 100)))
@@ -161,7 +163,7 @@ def train_main(args, dc, rank, world, dev):
             print("Loading Models from previous training!" if getattr(args, "resume", False) else "Loading Pretrained Models!")
     if path is None or not path.endswith("ldm-last.pt"):
         from ddmi_amd import initweights as iw   # a fresh diffusion model: named-seed init (deterministic across ranks)
-        st = iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in step.model.state_dict().items()])
+        st = iw.fill_state(("afhq" if args.domain == "image" else "shapenet") + ".unet", [(k, tuple(p.shape)) for k, p in step.model.state_dict().items()])
         step.load_state_dict({"model." + k: v for k, v in st.items()}, strict=False)
     step.finalize()
     if ck is not None and path.endswith("ldm-last.pt"):
