@@ -243,7 +243,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV]
 // DDMI_CONV_TS on the 448->1344 1x1 conv, its epilogue took 4.2 us of a 24 us tile BEFORE any store was issued.  Here the
 // per-channel constant (bias + the sample's embedding row) is loaded once per wave, the residual rows of fragment row
 // i+1 are in flight while row i is converted and stored, and there is one 64-bit address per fragment row.
-template <int FM, int FN>
+template <int FM, int FN, bool STATS = true>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
                                                    int lg, int hw) {
   using T = bf16_t;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
   // GroupNorm statistics of the consumer, gathered here so that no separate pass has to read the tensor back: per channel the
   // sum and the sum of squares of the values AS STORED (bf16-rounded) over this wave's 16 FM rows, fp32 (<= 64 terms each),
   // written per row block; launch_gn_chstat_finish adds the blocks of a sample in fp64 in a fixed order (deterministic).
-  const bool st = a.chstat != nullptr;
+  const bool st = STATS && a.chstat != nullptr;
   float s1p[NPAIR > 0 ? NPAIR : 1][8], s2p[NPAIR > 0 ? NPAIR : 1][8], s1o[4], s2o[4];
 #pragma unroll
   for (int p = 0; p < (NPAIR > 0 ? NPAIR : 1); ++p)
@@ -916,6 +916,158 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
 }
 
 // =====================================================================================================
+// bf16 production kernel v4 ("gemm"): PERSISTENT 1x1 convolution (qkv / proj_out / skip_connection: 19 % of a UNet step at
+// 0.6-0.9 PFLOP/s on the kernels above).  A 256 x 224 tile of a K = 448 GEMM lives 21 us, of which only ~15 are its K loop:
+// index setup 0.7 + first stages landing 3.2 + epilogue 2.8 + store acknowledgement 0.5 + workgroup turnover 0.55 (DDMI_CONV_TS,
+// round 1) add, because a tile's prologue cannot start before the previous workgroup has left the CU.  The two persistent
+// attempts of round 1 (on the general ring / pipe kernels) lost to the registers of the tile transition; a 1x1-ONLY kernel has
+// almost none: no taps, no padding, no upsampling, one per-lane offset per operand (row * K + slot) and two scalars per tile.
+//   * one workgroup per CU walks a contiguous range of tiles (n fastest: the six N tiles of a qkv M tile re-read its A rows
+//     from L2 back to back);
+//   * ONE flat stage loop over (tile, 64-channel block) with the pipe kernel's structure (two LDS buffers, software-pipelined
+//     fragments, one barrier per stage): the DMA of stage g + 2 - which may belong to the NEXT tile - is issued behind the
+//     barrier of stage g, so a tile's first stages land under the previous tile's last MFMAs and its epilogue;
+//   * the epilogue (conv_epilogue_fast: bias / embedding / residual / GroupNorm statistics as before) runs on the accumulators
+//     right after the tile's last stage; its stores drain under the next tile's first MFMA chunk.
+// Requirements (else the launch falls back to the pipe kernel): bf16, 1x1, stride 1, no split-K, Cout % 224 == 0, NHWC output.
+// =====================================================================================================
+template <int BN, int WM, int WN, bool STATS>
+__global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
+  using T = bf16_t;
+  constexpr int BM = 256, NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int GA = BM / 8, GB = BN / 8;
+  constexpr int A_PER = GA / NW, B_PER = (GB + NW - 1) / NW;
+  static_assert(GA % NW == 0 && NW % 2 == 0 && (TM / 2) % 8 == 0 && (TN / 2) % 8 == 0, "bad tile");
+  constexpr int ROWB = 128, SZ = 2;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int K = a.Cin, NS = (K + 63) >> 6;
+  const int tiles_n = a.tiles_n, tiles_m = (a.M + BM - 1) / BM, T_all = tiles_m * tiles_n;
+  // Tile order.  Workgroups are dealt to the 8 XCDs round-robin (w % 8); XCD x owns the contiguous eighth [r0, r1) of the tile list
+  // and its workgroups take tiles r0 + q, r0 + q + Sx, ... (q = w / 8, Sx = workgroups on this XCD): at any time the XCD's CUs sit on
+  // ~32 CONSECUTIVE tiles - the n tiles of a few m tiles (m-major list) or the m tiles of one n tile (n-major, tile_map 2: weights
+  // larger than activations) - so the shared operand is fetched into that L2 once, as under the hardware's own dispatch order.
+  // (A first version gave every workgroup a contiguous range, n fastest: each CU then re-read its own A tile 12 times with 31 other
+  // CUs' tiles between the reads - 14.7 MB per XCD against a 4 MB L2 - and the 896 -> 2688 qkv ran 13 % SLOWER than the pipe kernel.)
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, Sx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int r0 = (int)((int64_t)xcd * T_all / 8), r1 = (int)((int64_t)(xcd + 1) * T_all / 8);
+  const int t0 = r0 + q;
+  const int ntile = t0 < r1 ? (r1 - t0 + Sx - 1) / Sx : 0;
+  const int G = ntile * NS;   // stages of this workgroup
+  const int hw = a.Hout * a.Wout;
+  const bool n_major = a.tile_map == 2;
+  auto tile_mn = [&](int t, int* tm, int* tn) {
+    if (n_major) { *tn = t / tiles_m; *tm = t - *tn * tiles_m; }
+    else { *tm = t / tiles_n; *tn = t - *tm * tiles_n; }
+  };
+
+  // per-lane constants (the pipe kernel's): physical slot lane&7 of row lane>>3 of an 8-row group; logical slot -> channel offset
+  const int coff = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 8;
+  const int row0 = wave * 8 + (lane >> 3);            // group i adds 8 * NW rows (a scalar step)
+  const int a_lane = (row0 * K + coff) * SZ;          // + (i * 8 * NW) * K * SZ   (+ 128 per 64-channel block), tile-relative
+  int b_lane[B_PER];                                  // weight row of the paired layout for this lane's row of group i
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) b_lane[i] = (lds_row_chan<TN>(row0 + i * 8 * NW) * K + coff) * SZ;
+  auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  // ---- load cursor: (tile, 64-channel block) of the next stage to fetch ----------------------------------------------
+  int lt = t0, lkb = 0;
+  auto load_stage = [&](int buf) {
+    unsigned char* sbase = smem + buf * STAGE_BYTES;
+    int tm, tn;
+    tile_mn(lt, &tm, &tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    // the activation descriptor is rebased at the tile's first row (tensors may exceed 2 GiB); rows past M fall outside its
+    // extent and read as zeros
+    const uint64_t rem = (uint64_t)(a.M - m0) * K * SZ;
+    auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.x + (int64_t)m0 * K), 0, rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)rem,
+                                                    0x00020000);
+    const int cok = lkb * 64 + coff < K;
+    const int kbyte = lkb * 128;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const unsigned voff = cok ? (unsigned)(a_lane + i * (8 * NW) * K * SZ + kbyte) : OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int g = i * NW + wave;
+      if (g < GB) {
+        int bl = b_lane[i];
+        const unsigned voff = cok ? (unsigned)(bl + n0 * K * SZ + kbyte) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(sbase + A_BYTES + g * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+    if (++lkb == NS) { lkb = 0; lt += Sx; }
+  };
+
+  const int lr = lane & 15, lg = lane >> 4;
+  const int xoff0 = (wm * TM + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
+  const int woff0 = A_BYTES + (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
+  auto read_frags = [&](int buf, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+    const unsigned char* px = smem + buf * STAGE_BYTES + (xoff0 ^ (c << 6));
+    const unsigned char* pw = smem + buf * STAGE_BYTES + (woff0 ^ (c << 6));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(px + i * 2048);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+  };
+  bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
+
+  if (G > 0) {
+    load_stage(0);
+    if (G > 1) load_stage(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, xa, wa);
+  }
+  int ct = t0, ckb = 0, buf = 0;   // compute cursor
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    const bool c1 = ckb * 64 + 32 < K;
+    read_frags(buf, 1, xb, wb);
+    mma(xa, wa);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g + 2 < G) load_stage(buf);
+    const bool last = ckb + 1 == NS;
+    if (!last && g + 1 < G) read_frags(buf ^ 1, 0, xa, wa);
+    if (c1) mma(xb, wb);
+    if (last) {   // the tile is complete: epilogue on the accumulators, then start the next tile's first chunk
+      int tm, tn;
+      tile_mn(ct, &tm, &tn);
+      conv_epilogue_fast<FM, FN, STATS>(a, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lg, hw);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (g + 1 < G) read_frags(buf ^ 1, 0, xa, wa);
+      ckb = 0; ct += Sx;
+    } else {
+      ++ckb;
+    }
+    buf ^= 1;
+  }
+}
+
+// =====================================================================================================
 // bf16 production kernel v3 ("halo") for 3x3 / stride 1 / pad 1 convolutions on W in {8, 16, 32, 64}.
 //
 // PMC counters of the pipe kernel: 456 MB fetched per launch against 70 MB of algorithmic reads - the nine taps re-read
@@ -1467,6 +1619,7 @@ static const RingCfg kRing[] = {
     {256, 224, 1},   // 21: ring <256,224,4,2,1,4> of 11 with the refill's DMA instructions interleaved with the MFMA groups
     {128, 224, 1},   // 22: ring <128,224,2,2,1,4> of 12, interleaved
     {256, 224, 1},   // 23: ring <256,224,4,2,1,5> interleaved, one stage deeper (158 KB)
+    {256, 224, -3},  // 24: gemm1x1<224,4,2> PERSISTENT 1x1 kernel, 8 waves, per-wave 64x112, 120 KB  (kps -3; other shapes fall back to 13)
 };
 bool conv_halo_shape_ok(int H, int W) {
   if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
@@ -1559,6 +1712,7 @@ int conv_pick_splitk(const ConvArgs& a, int dt) {
   int M = a.B * a.Hout * a.Wout;
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
+  if (t.kps == -3) return 1;   // the persistent 1x1 kernel has no split-K
   int tiles = cdiv(M, t.bm) * cdiv(a.Cout, t.bn);
   int NS = t.kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(cdiv(a.Cin, 32) * a.KH * a.KW, t.kps);
   if (tiles >= 192 || NS < 16) return 1;
@@ -1703,6 +1857,45 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
   return DDMI_OK;
 }
 
+// shapes the persistent 1x1 kernel (configuration 24) serves; anything else asked of it runs on the pipe kernel (13)
+static bool gemm1x1_ok(const ConvArgs& a) {
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.ups && a.splitk <= 1 && !a.force_ws && a.Cout % 224 == 0 && a.y_nchw == nullptr &&
+         a.y32 == nullptr && a.x2 == nullptr && a.Cin % 8 == 0 && a.y != nullptr;
+}
+static const int kGemmFallback = 13;
+template <int BN, int WM, int WN>
+static int launch_gemm1x1(ConvK k, hipStream_t s) {
+  constexpr int lds = 2 * (256 + BN) * 128;
+  static_assert(lds <= 160 * 1024, "gemm tile does not fit the 160 KiB LDS");
+  k.tiles_n = cdiv(k.Cout, BN);
+  const int tiles = cdiv(k.M, 256) * k.tiles_n;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  dim3 grid(std::min(tiles, n_cu));   // one workgroup per CU walks its share of the tiles
+  auto kern = conv_gemm1x1_kernel<BN, WM, WN, false>;
+  auto kern_st = conv_gemm1x1_kernel<BN, WM, WN, true>;   // + the consumer GroupNorm's statistics out of the epilogue
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_st), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  {
+    double flops, bytes;
+    conv_work(k, 1, 2, &flops, &bytes);
+    static const std::string name = "conv_gemm1x1<bf16,256x" + std::to_string(BN) + ",persistent>";
+    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    if (k.chstat) hipLaunchKernelGGL(kern_st, grid, dim3(WM * WN * 64), lds, s, k);
+    else hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <int BN, int WM, int WN>
 static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
   constexpr int lds = 2 * HALO_MAX_ROWS * 128 + 2 * BN * 128;
@@ -1761,6 +1954,7 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 21: return launch_ring<256, 224, 4, 2, 1, 4, true>(k, splitk, batch, s);
       case 22: return launch_ring<128, 224, 2, 2, 1, 4, true>(k, splitk, batch, s);
       case 23: return launch_ring<256, 224, 4, 2, 1, 5, true>(k, splitk, batch, s);
+      case 24: return launch_gemm1x1<224, 4, 2>(k, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -1802,7 +1996,7 @@ static int check_conv(const ConvArgs& a, int dt) {
 // wave tile (rows, channels) of the bf16 configurations kRing[id]
 static const int kRingWave[][2] = {{32, 112}, {32, 112}, {32, 112}, {32, 112}, {64, 64}, {32, 64}, {32, 64}, {32, 32}, {64, 64}, {64, 112}, {64, 112},
                                    {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64},
-                                   {64, 112}, {64, 112}, {64, 112}};
+                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}};
 static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave tile per ring configuration");
 
 // Rows per statistics block (the wave tile height) when a launch of `a` with a.chstat set would fill the WHOLE
@@ -1815,6 +2009,7 @@ int conv_chstat_rows(const ConvArgs& a, int dt) {
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
+  if (t.kps == -3 && !gemm1x1_ok(a)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
   if (t.id < 0) return 0;
   const bool paired = t.kps != -1 || a.order > 2 || (a.order == 0 && a.KH * a.KW == 1);   // ring and halo kernels always are
   const int TM = kRingWave[t.id][0], TN = kRingWave[t.id][1];
@@ -1831,6 +2026,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
+  if (t.kps == -3 && !gemm1x1_ok(a)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
   // order: 1 tap-major, 2 channel-major, +2 = paired-fragment instantiation of the pipe kernel; 0 = heuristic
@@ -1902,6 +2098,11 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     const RingCfg& rc = kRing[id];
     if (rc.kps == -2 && !halo_ok(a0)) continue;
     if (a0.x2 && rc.kps != -2) continue;   // a folded skip connection runs on the halo kernel only
+    if (rc.kps == -3) {
+      ConvArgs probe = a0;
+      probe.splitk = 1;
+      if (!gemm1x1_ok(probe)) continue;
+    }
     // prune: tile width must fit Cout without more than ~15 % padding; tile height not larger than 2x the problem
     int padded = cdiv(a0.Cout, rc.bn) * rc.bn;
     if (padded * 100 > a0.Cout * 115 && !(a0.Cout <= 64 && rc.bn == 64)) continue;
@@ -1911,6 +2112,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     for (int sk : kSplits) {
       if (sk > 1 && (a0.ups == 3 || tiles * (sk - 1) >= 512 || NS / sk < 4)) continue;
       if (rc.kps == -2 && sk > cdiv(a0.Cin, 64)) continue;
+      if (rc.kps == -3 && sk > 1) continue;
       if ((size_t)sk * M * a0.Cout * sizeof(float) > ws_bytes && sk > 1) continue;
       const int n_walk = (a0.KH * a0.KW > 1 && rc.kps != -2) ? 2 : 1;
       for (int order = 1; order <= (rc.kps == -1 ? n_walk + 2 : n_walk); ++order) {  // pipe: + the paired instantiation

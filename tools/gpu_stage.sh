@@ -31,7 +31,7 @@ for st in "$@"; do
     benchq)    timeout 900 python bench.py --nfe 10 --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchq.json 2> $log ;;
     r3tests)   timeout 1200 python -m pytest tests/test_gpu_round3.py -q -x > $log 2>&1 ;;
     benchq0)   DDMI_SKIP_FOLD=1 timeout 900 python bench.py --nfe 10 --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchq0.json 2> $log ;;
-    conv1x1)   timeout 600 python tools/bench_conv.py --batch 512 --only " k1 " --cfgs 11,21,23,13,12,22 > $log 2>&1 ;;
+    conv1x1)   timeout 600 python tools/bench_conv.py --batch 512 --only " k1 " --cfgs 13,24,21 > $log 2>&1 ;;
     convvar)   timeout 900 python -m pytest tests/test_gpu_ops.py -q -k "every_bf16_variant" > $log 2>&1 ;;
     skyfull)   DDMI_METRICS_LOG=gpurun_out/${tag}_metrics.jsonl timeout 1500 python -m pytest tests/test_gpu_video.py -q -x -s -k "full_size_decode_vs_oracle" > $log 2>&1 ;;
     r3train)   timeout 1500 python -m pytest tests/test_gpu_round3.py -q -x -s -k "training or wgrad or ema or resume" > $log 2>&1 ;;
