@@ -243,9 +243,11 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK& a, float (&v)[NV]
 // DDMI_CONV_TS on the 448->1344 1x1 conv, its epilogue took 4.2 us of a 24 us tile BEFORE any store was issued.  Here the
 // per-channel constant (bias + the sample's embedding row) is loaded once per wave, the residual rows of fragment row
 // i+1 are in flight while row i is converted and stored, and there is one 64-bit address per fragment row.
-template <int FM, int FN, bool STATS = true>
+// BIAS_LDS (persistent 1x1 kernel): the bias vector sits in LDS (`bias_lds`, indexed by output channel) - a global load in the
+// epilogue would queue behind the next tile's LDS-DMA (vmcnt retires in order) and stall it for an L2 round trip per tile
+template <int FM, int FN, bool STATS = true, bool BIAS_LDS = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
-                                                   int lg, int hw) {
+                                                   int lg, int hw, const float* bias_lds = nullptr) {
   using T = bf16_t;
   constexpr int NPAIR = FN / 2;
   constexpr bool ODD = (FN & 1) != 0;
@@ -258,7 +260,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
   f32x4 cb[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) cb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (a.bias) {
+  if constexpr (BIAS_LDS) {
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      cb[2 * p] = *reinterpret_cast<const f32x4*>(bias_lds + n_pair + 32 * p);
+      cb[2 * p + 1] = *reinterpret_cast<const f32x4*>(bias_lds + n_pair + 32 * p + 4);
+    }
+    if constexpr (ODD) cb[FN - 1] = *reinterpret_cast<const f32x4*>(bias_lds + n_odd);
+  } else if (a.bias) {
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
       cb[2 * p] = *reinterpret_cast<const f32x4*>(a.bias + n_pair + 32 * p);
@@ -942,11 +951,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   constexpr int ROWB = 128, SZ = 2;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);   // [Cout] (zeros when the convolution has no bias)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int K = a.Cin, NS = (K + 63) >> 6;
+  for (int i = tid; i < a.Cout; i += NW * 64) bias_lds[i] = a.bias ? a.bias[i] : 0.f;   // visible after the first barrier below
   const int tiles_n = a.tiles_n, tiles_m = (a.M + BM - 1) / BM, T_all = tiles_m * tiles_n;
   // Tile order.  Workgroups are dealt to the 8 XCDs round-robin (w % 8); XCD x owns the contiguous eighth [r0, r1) of the tile list
   // and its workgroups take tiles r0 + q, r0 + q + Sx, ... (q = w / 8, Sx = workgroups on this XCD): at any time the XCD's CUs sit on
@@ -954,8 +965,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   // larger than activations) - so the shared operand is fetched into that L2 once, as under the hardware's own dispatch order.
   // (A first version gave every workgroup a contiguous range, n fastest: each CU then re-read its own A tile 12 times with 31 other
   // CUs' tiles between the reads - 14.7 MB per XCD against a 4 MB L2 - and the 896 -> 2688 qkv ran 13 % SLOWER than the pipe kernel.)
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, Sx = ((int)gridDim.x - xcd + 7) >> 3;
-  const int r0 = (int)((int64_t)xcd * T_all / 8), r1 = (int)((int64_t)(xcd + 1) * T_all / 8);
+  const int NX = gridDim.x >= 8 ? 8 : (int)gridDim.x;   // (a grid of fewer than 8 workgroups: as many groups as workgroups)
+  const int xcd = blockIdx.x % NX, q = blockIdx.x / NX, Sx = ((int)gridDim.x - xcd + NX - 1) / NX;
+  const int r0 = (int)((int64_t)xcd * T_all / NX), r1 = (int)((int64_t)(xcd + 1) * T_all / NX);
   const int t0 = r0 + q;
   const int ntile = t0 < r1 ? (r1 - t0 + Sx - 1) / Sx : 0;
   const int G = ntile * NS;   // stages of this workgroup
@@ -1053,7 +1065,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
     if (last) {   // the tile is complete: epilogue on the accumulators, then start the next tile's first chunk
       int tm, tn;
       tile_mn(ct, &tm, &tn);
-      conv_epilogue_fast<FM, FN, STATS>(a, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lg, hw);
+      conv_epilogue_fast<FM, FN, STATS, true>(a, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lg, hw, bias_lds);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1865,8 +1877,9 @@ static bool gemm1x1_ok(const ConvArgs& a) {
 static const int kGemmFallback = 13;
 template <int BN, int WM, int WN>
 static int launch_gemm1x1(ConvK k, hipStream_t s) {
-  constexpr int lds = 2 * (256 + BN) * 128;
-  static_assert(lds <= 160 * 1024, "gemm tile does not fit the 160 KiB LDS");
+  constexpr int lds_tiles = 2 * (256 + BN) * 128;
+  const int lds = lds_tiles + k.Cout * 4;   // + the bias vector
+  DDMI_REQUIRE(lds <= 160 * 1024, "gemm1x1: Cout too large for the bias in LDS");
   k.tiles_n = cdiv(k.Cout, BN);
   const int tiles = cdiv(k.M, 256) * k.tiles_n;
   static int n_cu = 0;
@@ -1880,8 +1893,8 @@ static int launch_gemm1x1(ConvK k, hipStream_t s) {
   auto kern_st = conv_gemm1x1_kernel<BN, WM, WN, true>;   // + the consumer GroupNorm's statistics out of the epilogue
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_st), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_st), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   {
@@ -2099,6 +2112,8 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     if (rc.kps == -2 && !halo_ok(a0)) continue;
     if (a0.x2 && rc.kps != -2) continue;   // a folded skip connection runs on the halo kernel only
     if (rc.kps == -3) {
+      static const bool no_gemm = getenv("DDMI_NO_GEMM1X1") != nullptr;   // diagnostics: A/B against the pipe / ring kernels
+      if (no_gemm) continue;
       ConvArgs probe = a0;
       probe.splitk = 1;
       if (!gemm1x1_ok(probe)) continue;

@@ -36,6 +36,7 @@ for st in "$@"; do
     skyfull)   DDMI_METRICS_LOG=gpurun_out/${tag}_metrics.jsonl timeout 1500 python -m pytest tests/test_gpu_video.py -q -x -s -k "full_size_decode_vs_oracle" > $log 2>&1 ;;
     r3train)   timeout 1500 python -m pytest tests/test_gpu_round3.py -q -x -s -k "training or wgrad or ema or resume" > $log 2>&1 ;;
     benchfull) timeout 2400 python bench.py --steps 2 --warmup 1 > gpurun_out/${tag}_bench_n1_b512.json 2> $log ;;
+    benchqt)   DDMI_TUNE_DEFAULT=/nonexistent DDMI_TUNE_FILE=$PWD/gpurun_out/${tag}_plans.txt timeout 900 python bench.py --nfe 10 --steps 1 --warmup 1 --no-ddim --no-parity-check --no-cpu-baseline > gpurun_out/${tag}_benchqt.json 2> $log ;;
     attnbench) timeout 300 python tools/bench_attn_mh.py 128 > $log 2>&1 ;;
     *) echo "unknown stage $st" ;;
   esac
