@@ -940,18 +940,23 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
 //     right after the tile's last stage; its stores drain under the next tile's first MFMA chunk.
 // Requirements (else the launch falls back to the pipe kernel): bf16, 1x1, stride 1, no split-K, Cout % 224 == 0, NHWC output.
 // =====================================================================================================
-template <int BN, int WM, int WN, bool STATS>
+// NA = activation slots in LDS.  NA = 2: A and B of stage g + 2 are fetched together behind the barrier of stage g.  NA = 3 (when
+// the bias vector leaves room): the ACTIVATION tile - the operand that comes from HBM - is fetched one stage further ahead than the
+// weights (L2): behind barrier g go B(g + 2) and then A(g + 3), and the wait before barrier g + 1 is `vmcnt(A_PER)`: everything but
+// the four youngest instructions, i.e. A(g + 3) stays in flight across the barrier (every wave issues exactly A_PER activation
+// pieces per stage, so the immediate is wave-independent whatever its share of the weight rows).
+template <int BN, int WM, int WN, bool STATS, int NA>
 __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   using T = bf16_t;
   constexpr int BM = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int GA = BM / 8, GB = BN / 8;
   constexpr int A_PER = GA / NW, B_PER = (GB + NW - 1) / NW;
-  static_assert(GA % NW == 0 && NW % 2 == 0 && (TM / 2) % 8 == 0 && (TN / 2) % 8 == 0, "bad tile");
+  static_assert(GA % NW == 0 && NW % 2 == 0 && (TM / 2) % 8 == 0 && (TN / 2) % 8 == 0 && (NA == 2 || NA == 3), "bad tile");
   constexpr int ROWB = 128, SZ = 2;
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, B_BASE = NA * A_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);   // [Cout] (zeros when the convolution has no bias)
+  float* const bias_lds = reinterpret_cast<float*>(smem + B_BASE + 2 * B_BYTES);   // [Cout] (zeros when the convolution has no bias)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -987,43 +992,50 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   for (int i = 0; i < B_PER; ++i) b_lane[i] = (lds_row_chan<TN>(row0 + i * 8 * NW) * K + coff) * SZ;
   auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
-  // ---- load cursor: (tile, 64-channel block) of the next stage to fetch ----------------------------------------------
-  int lt = t0, lkb = 0;
-  auto load_stage = [&](int buf) {
-    unsigned char* sbase = smem + buf * STAGE_BYTES;
+  // ---- load cursors: (tile, 64-channel block) of the next activation / weight stage to fetch -----------------------------
+  int lta = t0, lka = 0, ltb = t0, lkb = 0;
+  auto load_a = [&](int slot) {
     int tm, tn;
-    tile_mn(lt, &tm, &tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    tile_mn(lta, &tm, &tn);
+    const int m0 = tm * BM;
     // the activation descriptor is rebased at the tile's first row (tensors may exceed 2 GiB); rows past M fall outside its
     // extent and read as zeros
     const uint64_t rem = (uint64_t)(a.M - m0) * K * SZ;
     auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.x + (int64_t)m0 * K), 0, rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)rem,
                                                     0x00020000);
-    const int cok = lkb * 64 + coff < K;
-    const int kbyte = lkb * 128;
+    const int cok = lka * 64 + coff < K;
+    const int kbyte = lka * 128;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const unsigned voff = cok ? (unsigned)(a_lane + i * (8 * NW) * K * SZ + kbyte) : OOB_OFFSET;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + slot * A_BYTES + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
+    if (++lka == NS) { lka = 0; lta += Sx; }
+  };
+  auto load_b = [&](int slot) {
+    int tm, tn;
+    tile_mn(ltb, &tm, &tn);
+    const int n0 = tn * BN;
+    const int cok = lkb * 64 + coff < K;
+    const int kbyte = lkb * 128;
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int g = i * NW + wave;
       if (g < GB) {
         int bl = b_lane[i];
         const unsigned voff = cok ? (unsigned)(bl + n0 * K * SZ + kbyte) : OOB_OFFSET;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(sbase + A_BYTES + g * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + B_BASE + slot * B_BYTES + g * 1024), 16, voff, 0, 0, 0);
       }
     }
-    if (++lkb == NS) { lkb = 0; lt += Sx; }
+    if (++lkb == NS) { lkb = 0; ltb += Sx; }
   };
 
   const int lr = lane & 15, lg = lane >> 4;
   const int xoff0 = (wm * TM + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
-  const int woff0 = A_BYTES + (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
-  auto read_frags = [&](int buf, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
-    const unsigned char* px = smem + buf * STAGE_BYTES + (xoff0 ^ (c << 6));
-    const unsigned char* pw = smem + buf * STAGE_BYTES + (woff0 ^ (c << 6));
+  const int woff0 = B_BASE + (wn * TN + lr) * ROWB + ((lg ^ ((lr >> 1) & 7)) << 4);
+  auto read_frags = [&](int sa, int sb, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+    const unsigned char* px = smem + sa * A_BYTES + (xoff0 ^ (c << 6));
+    const unsigned char* pw = smem + sb * B_BYTES + (woff0 ^ (c << 6));
 #pragma unroll
     for (int i = 0; i < FM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(px + i * 2048);
 #pragma unroll
@@ -1044,23 +1056,30 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
 
   if (G > 0) {
-    load_stage(0);
-    if (G > 1) load_stage(1);
+    load_b(0);
+    if (G > 1) load_b(1);
+#pragma unroll
+    for (int p = 0; p < NA; ++p)
+      if (p < G) load_a(p);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_frags(0, 0, xa, wa);
+    read_frags(0, 0, 0, xa, wa);
   }
-  int ct = t0, ckb = 0, buf = 0;   // compute cursor
+  int ct = t0, ckb = 0, sa = 0, sb = 0;   // compute cursor; LDS slots of the current stage
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
     const bool c1 = ckb * 64 + 32 < K;
-    read_frags(buf, 1, xb, wb);
+    read_frags(sa, sb, 1, xb, wb);
     mma(xa, wa);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // A(g + 2) - issued behind the previous barrier as the youngest A_PER instructions - may stay in flight (NA = 3)
+    if (NA == 3 && g >= 1 && g + 2 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (g + 2 < G) load_stage(buf);
+    if (g + 2 < G) load_b(sb);                 // the weight slot just consumed
+    if (g + NA < G) load_a(sa);                // the activation slot just consumed
+    const int sa1 = sa + 1 == NA ? 0 : sa + 1, sb1 = sb ^ 1;
     const bool last = ckb + 1 == NS;
-    if (!last && g + 1 < G) read_frags(buf ^ 1, 0, xa, wa);
+    if (!last && g + 1 < G) read_frags(sa1, sb1, 0, xa, wa);
     if (c1) mma(xb, wb);
     if (last) {   // the tile is complete: epilogue on the accumulators, then start the next tile's first chunk
       int tm, tn;
@@ -1070,12 +1089,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (g + 1 < G) read_frags(buf ^ 1, 0, xa, wa);
+      if (g + 1 < G) read_frags(sa1, sb1, 0, xa, wa);
       ckb = 0; ct += Sx;
     } else {
       ++ckb;
     }
-    buf ^= 1;
+    sa = sa1; sb = sb1;
   }
 }
 
@@ -1877,8 +1896,11 @@ static bool gemm1x1_ok(const ConvArgs& a) {
 static const int kGemmFallback = 13;
 template <int BN, int WM, int WN>
 static int launch_gemm1x1(ConvK k, hipStream_t s) {
-  constexpr int lds_tiles = 2 * (256 + BN) * 128;
-  const int lds = lds_tiles + k.Cout * 4;   // + the bias vector
+  // three activation slots where the bias vector leaves room for them (Cout <= 2016), else two
+  static const int force_na = getenv("DDMI_GEMM1X1_NA") ? atoi(getenv("DDMI_GEMM1X1_NA")) : 0;   // diagnostics
+  const int lds3 = (3 * 256 + 2 * BN) * 128 + k.Cout * 4, lds2 = (2 * 256 + 2 * BN) * 128 + k.Cout * 4;
+  const bool na3 = lds3 <= 160 * 1024 && force_na != 2;
+  const int lds = na3 ? lds3 : lds2;
   DDMI_REQUIRE(lds <= 160 * 1024, "gemm1x1: Cout too large for the bias in LDS");
   k.tiles_n = cdiv(k.Cout, BN);
   const int tiles = cdiv(k.M, 256) * k.tiles_n;
@@ -1889,21 +1911,21 @@ static int launch_gemm1x1(ConvK k, hipStream_t s) {
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   dim3 grid(std::min(tiles, n_cu));   // one workgroup per CU walks its share of the tiles
-  auto kern = conv_gemm1x1_kernel<BN, WM, WN, false>;
-  auto kern_st = conv_gemm1x1_kernel<BN, WM, WN, true>;   // + the consumer GroupNorm's statistics out of the epilogue
+  // STATS: + the consumer GroupNorm's statistics out of the epilogue
+  void (*kerns[4])(ConvK) = {conv_gemm1x1_kernel<BN, WM, WN, false, 2>, conv_gemm1x1_kernel<BN, WM, WN, true, 2>,
+                             conv_gemm1x1_kernel<BN, WM, WN, false, 3>, conv_gemm1x1_kernel<BN, WM, WN, true, 3>};
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_st), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (auto kp : kerns) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  auto kern = kerns[(na3 ? 2 : 0) + (k.chstat ? 1 : 0)];
   {
     double flops, bytes;
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_gemm1x1<bf16,256x" + std::to_string(BN) + ",persistent>";
     PROF_SCOPE(name.c_str(), flops, bytes, s);
-    if (k.chstat) hipLaunchKernelGGL(kern_st, grid, dim3(WM * WN * 64), lds, s, k);
-    else hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
