@@ -1651,6 +1651,7 @@ static const RingCfg kRing[] = {
     {128, 224, 1},   // 22: ring <128,224,2,2,1,4> of 12, interleaved
     {256, 224, 1},   // 23: ring <256,224,4,2,1,5> interleaved, one stage deeper (158 KB)
     {256, 224, -3},  // 24: gemm1x1<224,4,2> PERSISTENT 1x1 kernel, 8 waves, per-wave 64x112, 120 KB  (kps -3; other shapes fall back to 13)
+    {256, 128, -3},  // 25: gemm1x1<128,4,2> the same for channel counts that are multiples of 128 (tri-plane UNet, decoders), per-wave 64x64
 };
 bool conv_halo_shape_ok(int H, int W) {
   if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
@@ -1889,9 +1890,10 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
 }
 
 // shapes the persistent 1x1 kernel (configuration 24) serves; anything else asked of it runs on the pipe kernel (13)
-static bool gemm1x1_ok(const ConvArgs& a) {
-  return a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.ups && a.splitk <= 1 && !a.force_ws && a.Cout % 224 == 0 && a.y_nchw == nullptr &&
-         a.y32 == nullptr && a.x2 == nullptr && a.Cin % 8 == 0 && a.y != nullptr;
+static bool gemm1x1_ok(const ConvArgs& a, int bn = 224) {
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.ups && a.splitk <= 1 && !a.force_ws && a.Cout % bn == 0 && a.y_nchw == nullptr &&
+         a.y32 == nullptr && a.x2 == nullptr && a.Cin % 8 == 0 && a.y != nullptr && a.Cin > 128 &&
+         (a.emb == nullptr || (a.Hout * a.Wout) % 64 == 0);   // (the fast epilogue's conditions; at least three stages per tile)
 }
 static const int kGemmFallback = 13;
 template <int BN, int WM, int WN>
@@ -1990,6 +1992,7 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 22: return launch_ring<128, 224, 2, 2, 1, 4, true>(k, splitk, batch, s);
       case 23: return launch_ring<256, 224, 4, 2, 1, 5, true>(k, splitk, batch, s);
       case 24: return launch_gemm1x1<224, 4, 2>(k, s);
+      case 25: return launch_gemm1x1<128, 4, 2>(k, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -2031,7 +2034,7 @@ static int check_conv(const ConvArgs& a, int dt) {
 // wave tile (rows, channels) of the bf16 configurations kRing[id]
 static const int kRingWave[][2] = {{32, 112}, {32, 112}, {32, 112}, {32, 112}, {64, 64}, {32, 64}, {32, 64}, {32, 32}, {64, 64}, {64, 112}, {64, 112},
                                    {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64},
-                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}};
+                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}};
 static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave tile per ring configuration");
 
 // Rows per statistics block (the wave tile height) when a launch of `a` with a.chstat set would fill the WHOLE
@@ -2044,7 +2047,7 @@ int conv_chstat_rows(const ConvArgs& a, int dt) {
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
-  if (t.kps == -3 && !gemm1x1_ok(a)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
+  if (t.kps == -3 && !gemm1x1_ok(a, t.bn)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
   if (t.id < 0) return 0;
   const bool paired = t.kps != -1 || a.order > 2 || (a.order == 0 && a.KH * a.KW == 1);   // ring and halo kernels always are
   const int TM = kRingWave[t.id][0], TN = kRingWave[t.id][1];
@@ -2061,7 +2064,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
-  if (t.kps == -3 && !gemm1x1_ok(a)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
+  if (t.kps == -3 && !gemm1x1_ok(a, t.bn)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
   // order: 1 tap-major, 2 channel-major, +2 = paired-fragment instantiation of the pipe kernel; 0 = heuristic
@@ -2138,7 +2141,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
       if (no_gemm) continue;
       ConvArgs probe = a0;
       probe.splitk = 1;
-      if (!gemm1x1_ok(probe)) continue;
+      if (!gemm1x1_ok(probe, rc.bn)) continue;
     }
     // prune: tile width must fit Cout without more than ~15 % padding; tile height not larger than 2x the problem
     int padded = cdiv(a0.Cout, rc.bn) * rc.bn;

@@ -421,12 +421,14 @@ def test_occupancy_training_step_vs_autograd():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("case", [(40, 448, 32, 32, 1344), (9, 1344, 8, 8, 1344), (3, 224, 64, 64, 224), (1, 96, 16, 16, 448)])
+@pytest.mark.parametrize("case", [(40, 448, 32, 32, 1344), (9, 1344, 8, 8, 1344), (3, 224, 64, 64, 224), (1, 96, 16, 16, 448),
+                                  (6, 256, 32, 32, 768, 25), (2, 512, 16, 64, 512, 25)])
 def test_persistent_1x1_kernel(case):
     """Configuration 24 (`conv_gemm1x1_kernel`: one workgroup per CU walks XCD-ordered tiles, the next tile's stages land under the
     previous tile's epilogue, bias from LDS) on grids larger and smaller than the CU count, a ragged last M tile (9 x 64 rows), a
     K that ends in a half block (224, 96) and both tile orders (m-major / n-major by operand size) - against torch."""
-    B, Cin, H, W, Cout = case
+    B, Cin, H, W, Cout = case[:5]
+    cfg = case[5] if len(case) > 5 else 24          # 25: the 256 x 128 instantiation (channel counts that are multiples of 128)
     tag = "gemm1x1%s" % (case,)
     x = iw.normal(tag, "x", (B, Cin, H, W))
     w = iw.normal(tag, "w", (Cout, Cin, 1, 1), 0.0, 1.0 / math.sqrt(Cin))
@@ -437,7 +439,7 @@ def test_persistent_1x1_kernel(case):
     xd, wd, bd = _dev(x), _dev(w), _dev(b)
     y = torch.empty(tuple(ref.shape), device=DEV, dtype=torch.float32)
     try:
-        _lib.check(L.ddmi_debug_conv_config(24))
+        _lib.check(L.ddmi_debug_conv_config(cfg))
         _lib.check(L.ddmi_op_conv2d(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, Cin, H, W, Cout, 1, 1, 0, _lib.numerics_code("bf16"), 1))
     finally:
         L.ddmi_debug_conv_config(-1)
