@@ -119,20 +119,25 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
   int cpg = C / GN_GROUPS;
   if constexpr (CHSTAT) {
     extern __shared__ double cred[];   // [2 C]: (sum, sumsq) per channel over the sample
-    for (int i = tid; i < 2 * C; i += blockDim.x) {
-      const int c = i >> 1;
+    for (int c = tid; c < C; c += blockDim.x) {   // one thread per channel: (sum, sumsq) pairs, eight blocks in flight
       const bool second = ch.cs2 != nullptr && c >= C1;
       const int ldc = ch.cs2 == nullptr ? C : (second ? C - C1 : C1), nblk = HW / (second ? ch.rows2 : ch.rows1);
-      const float* p = (second ? ch.cs2 : ch.cs1) + ((int64_t)b * nblk * ldc) * 2 + (i - (second ? 2 * C1 : 0));
-      double acc = 0.0;
+      const float2* p = reinterpret_cast<const float2*>((second ? ch.cs2 : ch.cs1) + ((int64_t)b * nblk * ldc) * 2) + (c - (second ? C1 : 0));
+      double a1 = 0.0, a2 = 0.0;
       int k = 0;
-      for (; k + 3 < nblk; k += 4) {   // four loads in flight; the adds stay in block order
-        const float v0 = p[(int64_t)k * ldc * 2], v1 = p[(int64_t)(k + 1) * ldc * 2], v2 = p[(int64_t)(k + 2) * ldc * 2],
-                    v3 = p[(int64_t)(k + 3) * ldc * 2];
-        acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+      for (; k + 7 < nblk; k += 8) {   // the adds stay in block order (fixed order: deterministic)
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * ldc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a1 += (double)v[u].x; a2 += (double)v[u].y; }
       }
-      for (; k < nblk; ++k) acc += (double)p[(int64_t)k * ldc * 2];
-      cred[i] = acc;
+      for (; k < nblk; ++k) {
+        const float2 v = p[(int64_t)k * ldc];
+        a1 += (double)v.x; a2 += (double)v.y;
+      }
+      cred[2 * c] = a1;
+      cred[2 * c + 1] = a2;
     }
     __syncthreads();
     if (tid < GN_GROUPS) {
