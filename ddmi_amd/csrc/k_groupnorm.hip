@@ -3,6 +3,7 @@
 //   gn_stats : per-(sample, group) sum / sum-of-squares; per-thread fp32 partials over a few dozen pixels, fixed-order
 //              fp64 combine per block and across blocks (deterministic; E[x^2]-E[x]^2 keeps ~1e-7 relative accuracy)
 //   gn_apply : y = silu?(x * (rstd*gamma) + (beta - mean*rstd*gamma)), per-channel scale/shift staged in LDS
+#include <cstdlib>
 #include "kernels.h"
 #include "prof.h"
 
@@ -295,7 +296,8 @@ int launch_gn_chstat_finish(const float* cs1, int rows1, const float* cs2, int r
 
 static int gn_splits(int B, int HW) {
   // enough blocks to fill 256 CUs a few times over, at least 16 pixels per block
-  int want = std::max(1, (256 * 4) / std::max(B, 1));
+  static const int target = getenv("DDMI_GN_BLOCKS") ? atoi(getenv("DDMI_GN_BLOCKS")) : 256 * 4;   // diagnostics: workgroups per launch to aim for
+  int want = std::max(1, target / std::max(B, 1));
   return std::max(1, std::min(std::min(want, HW / 16), GN_MAXSPLIT));
 }
 
