@@ -1117,10 +1117,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
 // What it replaces: a separate 1x1 launch at 0.4-0.6 PFLOP/s that wrote the skip tensor (HBM-bound at 64x64) plus this kernel's
 // epilogue reading it back as the residual.  Split z = 0 carries the skip blocks.
 #define HALO_MAX_ROWS 400  // 6 x 66 = 396 rows at W = 64, rounded up to whole 8-row DMA groups (the tail lanes write zeros)
-template <int BN, int WM, int WN, bool SKIP>
+// KT = 2 instantiation: the parity form of upsample + 3x3 (four 2x2 convolutions on the source grid, blockIdx.y = parity):
+// a (TR+1) x (W+1) halo whose border side depends on the parity, four taps per channel block, the up4 scatter in the epilogue.
+template <int BN, int WM, int WN, bool SKIP, int KT = 3>
 __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   using T = bf16_t;
-  constexpr int BM = 256, NW = WM * WN;
+  constexpr int BM = 256, NW = WM * WN, TAPS = KT * KT;
+  static_assert(KT == 3 || (KT == 2 && !SKIP), "halo kernel: 3x3, or the 2x2 parity convolutions of an upsample");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   static_assert(TM % 16 == 0 && TN % 16 == 0 && (TN / 2) % 8 == 0 && NW % 2 == 0, "bad tile");
   constexpr int GB = BN / 8, B_PER = (GB + NW - 1) / NW;
@@ -1143,18 +1146,18 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   const int tile_m = __builtin_amdgcn_readfirstlane(tmn.m), tile_n = __builtin_amdgcn_readfirstlane(tmn.n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int W = a.Win, H = a.Hin, hw = H * W;
-  const int Ktot = 9 * a.Cin;
+  const int Ktot = TAPS * a.Cin;
   const int NCB = (a.Cin + 63) >> 6;
   // a tile is TR whole rows of ONE sample (hw >= 256), or SPT whole samples of RS = H rows each (hw = 64 / 128: the
   // 8x8 level); every sample block carries its own one-pixel border, so the halo has SPT * (RS + 2) rows of W + 2
-  const int HWd = W + 2;
+  const int HWd = W + KT - 1;
   const int SPT = hw >= BM ? 1 : BM / hw, RS = hw >= BM ? BM / W : H;
-  const int HRS = (RS + 2) * HWd, NH = SPT * HRS, GH = (NH + 7) >> 3;
+  const int HRS = (RS + KT - 1) * HWd, NH = SPT * HRS, GH = (NH + 7) >> 3;
   const int b_first = m0 / hw;
   const int ty0 = hw >= BM ? (m0 - b_first * hw) / W : 0;
 
   const T* xg = (const T*)a.x + (int64_t)b_first * hw * a.Cin;
-  const T* wg = (const T*)a.w;
+  const T* wg = (const T*)a.w + (KT == 2 ? (int64_t)blockIdx.y * a.w_bstride : 0);
   const uint64_t x_rem = a.x_bytes - (uint64_t)b_first * hw * a.Cin * sizeof(T);
   const unsigned x_extent = x_rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)x_rem;
   auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_extent, 0x00020000);
@@ -1162,8 +1165,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
 
   // ---- the block list of this workgroup: its split's 64-channel blocks of x (nine stages each), then - SKIP, split 0 - the blocks
   // of the skip sources (one stage each).  split-K: whole blocks per split (SPS is a multiple of 9)
-  const int cb_begin = (blockIdx.z * a.SPS) / 9;
-  const int cb_end = min(NCB, cb_begin + a.SPS / 9);
+  const int cb_begin = (blockIdx.z * a.SPS) / TAPS;
+  const int cb_end = min(NCB, cb_begin + a.SPS / TAPS);
   const int nmain = max(cb_end - cb_begin, 0);
   // The skip arguments are read from the kernarg segment WHERE THEY ARE USED (laundered pointer, scalar loads that hit the constant
   // cache): as ordinary kernel arguments they would occupy a dozen SGPRs for the whole 3x3 loop, which has none to spare.
@@ -1179,7 +1182,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       nsk = NCB2 + ((skip_arg(int(0), offsetof(ConvK, C3)) + 63) >> 6);
     }
   }
-  const int nblk = nmain + nsk, nstage = nmain * 9 + nsk;
+  const int nblk = nmain + nsk, nstage = nmain * TAPS + nsk;
   // block -> (64-channel block inside its source, the source's channel count); scalar
   auto blk_cbl = [&](int blk) {
     if (!SKIP || blk < nmain) return cb_begin + blk;
@@ -1218,7 +1221,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     int sb = 0, rem = hr;                           // sample block of the tile, halo row inside it
     if (SPT > 1) { sb = hr / HRS; rem = hr - sb * HRS; }
     const int hy = rem / HWd, hx = rem - hy * HWd;
-    const int iy = ty0 - 1 + hy, ix = hx - 1;
+    // 2x2: the border is on the parity's side (recomputed from blockIdx.y here: two SALU ops instead of two loop-long SGPRs)
+    const int iy = ty0 - (KT == 2 ? 1 - (int)(blockIdx.y >> 1) : 1) + hy, ix = hx - (KT == 2 ? 1 - (int)(blockIdx.y & 1) : 1);
     const int ok = (hr < NH) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W) & (ch < C);
     // samples past the batch end fall outside the descriptor's extent and read as zeros
     const unsigned voff = ok ? (unsigned)(((sb * hw + iy * W + ix) * C + ch) * SZ) : OOB_OFFSET;
@@ -1273,7 +1277,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   auto read_frags = [&](int hbuf, int bbuf, int shift, bool plain, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
     const unsigned char* ph = HB + hbuf * H_BYTES;
     const int vb = (SKIP && plain) ? wm * TM - wn * TN + (woff0 >> 7) : hr00 + shift;
-    const int rj = (SKIP && plain) ? 0 : 2;
+    const int rj = (SKIP && plain) ? 0 : KT - 1;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       int hr = vb + i * 16 + ((i * 16) / W) * rj;
@@ -1326,8 +1330,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       int t2 = tap + 2, b2 = blk;   // the stage two ahead: taps of this block, then of the next (a skip block is one stage long)
       if (one_stage) {
         t2 = 0; b2 = blk + 2;
-      } else if (t2 >= 9) {
-        t2 -= 9; ++b2;
+      } else if (t2 >= TAPS) {
+        t2 -= TAPS; ++b2;
         if (SKIP && b2 >= nmain) { b2 += t2; t2 = 0; }
       }
       load_b_stage(b2, t2, bbuf, b2 < nblk);
@@ -1335,9 +1339,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       // no such lead for ITS successor (the stage after the barrier already reads it), so one-stage blocks are fetched TWO blocks
       // ahead: whole, into the halo buffer this barrier has just released (the current block's chunk-1 reads are retired) - behind
       // the last barrier of the last nine-stage block and behind the barrier of every one-stage block.
-      const int q = tap * NW + wave;
-      if (!one_stage && tap < 8) {
-        if (blk + 1 < nblk && q < ((SKIP && blk + 1 >= nmain) ? BM / 8 : GH)) load_halo_group(q, blk + 1, hbuf ^ 1);
+      if (!one_stage && tap < TAPS - 1) {
+        // (2x2: three stages carry the next halo, so a stage issues up to PPS groups per wave)
+        constexpr int PPS = KT == 3 ? 1 : (HALO_MAX_ROWS / 8 + NW * (TAPS - 1) - 1) / (NW * (TAPS - 1));
+#pragma unroll 1
+        for (int pp = 0; pp < PPS; ++pp) {
+          const int q = (tap * PPS + pp) * NW + wave;
+          if (blk + 1 < nblk && q < ((SKIP && blk + 1 >= nmain) ? BM / 8 : GH)) load_halo_group(q, blk + 1, hbuf ^ 1);
+        }
       } else if (SKIP && blk + 1 >= nmain && blk + 2 < nblk) {
         for (int g = wave; g < BM / 8; g += NW) load_halo_group(g, blk + 2, hbuf);
       }
@@ -1345,8 +1354,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     // advance the scalar state to the next stage
     if (!one_stage) {
       ++tap;
-      if (++kw == 3) { kw = 0; shift += HWd - 2; } else { ++shift; }
-      if (tap == 9) { tap = 0; shift = 0; ++blk; hbuf ^= 1; }
+      if (++kw == KT) { kw = 0; shift += HWd - (KT - 1); } else { ++shift; }
+      if (tap == TAPS) { tap = 0; shift = 0; ++blk; hbuf ^= 1; }
     } else {
       ++blk; hbuf ^= 1;
     }
@@ -1661,6 +1670,8 @@ bool conv_halo_shape_ok(int H, int W) {
   return (256 / hw) * (H + 2) * (W + 2) <= HALO_MAX_ROWS;
 }
 static bool halo_ok(const ConvArgs& a) {
+  // the parity form of upsample + 3x3: 2x2 taps on the source grid (the KT = 2 instantiation)
+  if (a.ups == 3) return a.KH == 2 && a.KW == 2 && a.pad == 1 && !a.x2 && conv_halo_shape_ok(a.Hin, a.Win);
   if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hout == a.Hin && a.Wout == a.Win)) return false;
   return conv_halo_shape_ok(a.Hin, a.Win);
 }
@@ -1717,7 +1728,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.CPT = cdiv(a.Cin, 32);
   k.NK = k.CPT * a.KH * a.KW;
   k.NS = kps < 0 ? cdiv(a.Cin, 64) * a.KH * a.KW : cdiv(k.NK, kps);
-  k.SPS = kps == -2 ? 9 * cdiv(cdiv(a.Cin, 64), splitk) : cdiv(k.NS, splitk);  // halo: whole channel blocks per split
+  k.SPS = kps == -2 ? a.KH * a.KW * cdiv(cdiv(a.Cin, 64), splitk) : cdiv(k.NS, splitk);  // halo: whole channel blocks per split
   k.out_scale = a.out_scale;
   static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
   k.dbg = dbg;
@@ -1937,9 +1948,25 @@ template <int BN, int WM, int WN>
 static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
   constexpr int lds = 2 * HALO_MAX_ROWS * 128 + 2 * BN * 128;
   static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
-  DDMI_REQUIRE(batch == 1, "halo kernel: no batched-GEMM mode");
+  DDMI_REQUIRE(batch == 1 || (k.up4 && batch == 4 && splitk == 1), "halo kernel: no batched-GEMM mode");
   k.tiles_n = cdiv(k.Cout, BN);
-  dim3 grid(cdiv(k.M, 256) * k.tiles_n, 1, splitk);
+  dim3 grid(cdiv(k.M, 256) * k.tiles_n, batch, splitk);
+  if (k.up4) {   // four 2x2 parity convolutions on the source grid
+    auto kern2 = conv_halo_kernel<BN, WM, WN, false, 2>;
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr2_set = true;
+    }
+    double flops, bytes;
+    conv_work(k, batch, 2, &flops, &bytes);
+    static const std::string name2 = "conv_halo_up4<bf16,256x" + std::to_string(BN) + ">";
+    PROF_SCOPE(name2.c_str(), flops, bytes, s);
+    k.ts = nullptr;
+    hipLaunchKernelGGL(kern2, grid, dim3(WM * WN * 64), lds, s, k);
+    HIP_TRY(hipGetLastError());
+    return DDMI_OK;
+  }
   auto kern = conv_halo_kernel<BN, WM, WN, false>;
   auto kern_skip = conv_halo_kernel<BN, WM, WN, true>;   // + the folded 1x1 skip connection
   static bool attr_set = false;

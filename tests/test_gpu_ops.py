@@ -134,13 +134,14 @@ def test_conv2d_every_bf16_variant(cfg):
         L.ddmi_debug_conv_config(-1)
 
 
-UPSAMPLE_CASES = [(2, 64, 8, 8, 64), (1, 224, 16, 16, 224), (3, 32, 5, 7, 96), (2, 448, 32, 32, 448), (5, 128, 4, 4, 224)]
+UPSAMPLE_CASES = [(2, 64, 8, 8, 64), (1, 224, 16, 16, 224), (3, 32, 5, 7, 96), (2, 448, 32, 32, 448), (5, 128, 4, 4, 224),
+                  (5, 72, 8, 8, 224), (2, 128, 64, 64, 128), (3, 64, 8, 16, 96)]   # 2x2 halo kernel: sample-packed tiles past the batch end, ragged channel block, W = 64, non-square
 
 
 @pytest.mark.parametrize("case", UPSAMPLE_CASES)
 def test_conv2d_upsample_parity_form(case):
     """bf16: nearest x2 upsample + 3x3 conv runs as four 2x2 parity convolutions on the source grid with pre-summed
-    weights (k_conv.hip conv_out_row) - borders, odd sizes, M tails, on the ring, pipe and small-tile kernels."""
+    weights (k_conv.hip conv_out_row) - borders, odd sizes, M tails, on the ring, pipe, small-tile and (cfg 19 / 20) 2x2 halo kernels."""
     B, Cin, H, W, Cout = case
     tag = "convup%s" % (case,)
     x = iw.normal(tag, "x", (B, Cin, H, W))
@@ -150,7 +151,7 @@ def test_conv2d_upsample_parity_form(case):
                    torch.from_numpy(b), padding=1)
     L = _lib.lib()
     try:
-        for cfg in (-1, 7, 11, 13, 16, 17):
+        for cfg in (-1, 7, 11, 13, 16, 17, 19, 20):
             _lib.check(L.ddmi_debug_conv_config(cfg))
             got = conv_op(x, w, b, 1, 1, "bf16")
             assert got.shape == ref.shape

@@ -13,6 +13,7 @@ UNET_SHAPES = [
     ("224->224 k3 @64", 224, 64, 224, 3, 1, 0, 7), ("448->448 k3 @32", 448, 32, 448, 3, 1, 0, 6),
     ("896->896 k3 @16", 896, 16, 896, 3, 1, 0, 6), ("1344->1344 k3 @8", 1344, 8, 1344, 3, 1, 0, 10),
     ("448->448 k3 up @32->64", 448, 32, 448, 3, 1, 1, 1), ("896->896 k3 up @16->32", 896, 16, 896, 3, 1, 1, 1),
+    ("1344->1344 k3 up @8->16", 1344, 8, 1344, 3, 1, 1, 1),
     ("448->224 k3 @64", 448, 64, 224, 3, 1, 0, 2), ("672->224 k3 @64", 672, 64, 224, 3, 1, 0, 1),
     ("1344->448 k3 @32", 1344, 32, 448, 3, 1, 0, 1), ("2240->896 k3 @16", 2240, 16, 896, 3, 1, 0, 1),
     ("2688->1344 k3 @8", 2688, 8, 1344, 3, 1, 0, 2), ("448->1344 k1 @32 (qkv)", 448, 32, 1344, 1, 1, 0, 5),
