@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libddmi_hip.so")
 SOURCES = ["k_elementwise.hip", "k_groupnorm.hip", "k_conv.hip", "k_attention.hip", "k_mlp2d.hip", "k_mlp3d.hip", "mlp3d_host.hip", "k_mlpv.hip", "mlpv_host.hip", "k_mcubes.hip", "models_video.hip", "net.hip",
-           "models.hip", "mlp2d_host.hip", "capi.hip", "prof.hip", "k_train.hip", "train_capi.hip"]
+           "models.hip", "mlp2d_host.hip", "capi.hip", "prof.hip", "k_train.hip", "k_attn_bwd.hip", "train_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
@@ -36,7 +36,7 @@ def _newest_header() -> float:
 
 # per-file extras.  k_attention: keep MFMA results in VGPRs - the softmax between the two matrix products is VALU work on
 # the score accumulators, and with AGPR accumulators the compiler brackets it with ~80 v_accvgpr moves per 64-key tile
-EXTRA_FLAGS = {"k_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"k_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "k_attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _compile(src: str, force: bool, hdr_mtime: float) -> str:

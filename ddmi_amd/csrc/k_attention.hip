@@ -561,6 +561,9 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
     const int q_idx = q_tile * (64 * QF) + (wave * QF + qf) * 16 + lr;
     if (!q_ok[qf]) continue;
     const float inv = 1.0f / ol[qf][0];
+    // row log-sum-exp for the training backward: m_run is the (reference) maximum in the exp2 domain, ol the sum of the bf16 P
+    // values that multiplied V - the normalisation the output actually carries
+    if (a.lse != nullptr && lg == 0) a.lse[((int64_t)b * a.heads + h) * N + q_idx] = (m_run[qf] + __log2f(ol[qf][0])) * 0.6931471805599453f;
     int seg = 0;
     int64_t r = row_of(q_idx, &seg);
     T* op = (T*)(SEG3 ? a.out[seg] : a.out[0]) + r * a.ld_out + h * a.hs_out;
@@ -647,6 +650,7 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
     if (a.d <= 64) return big ? launch_attention_v2<64, 2>(a, s) : launch_attention_v2<64, 1>(a, s);
     return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);
   }
+  DDMI_REQUIRE(!a.lse, "attention: the log-sum-exp output exists on the bf16 production kernel only");
   if (dt == DT_BF16) {
     if (a.d <= 32) return launch_attention_t<bf16_t, 32, 32, 64>(a, s);
     if (a.d <= 64) return launch_attention_t<bf16_t, 64, 64, 64>(a, s);
@@ -662,8 +666,9 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
 }
 
 // QKVAttentionLegacy layout: qkv [B, T, heads * 3d] with per-head [q | k | v] channel blocks; out [B, T, heads * d]
-int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s) {
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse) {
   AttnArgs a{};
+  a.lse = lse;
   a.qkv[0] = qkv; a.out[0] = out;
   a.seg_len[0] = T;
   a.ld_qkv = heads * 3 * d; a.ld_out = heads * d;

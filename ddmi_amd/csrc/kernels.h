@@ -149,9 +149,15 @@ struct AttnArgs {
   int q_prescaled;     // q already carries softmax scale x log2 e (folded into the qkv projection's q rows, bf16 networks): see
                        // attention_v2_kernel LAZY
   int xcd_map;         // filled by the bf16 launcher: workgroup -> (sample, head, query tile) order (k_attention.hip)
+  float* lse;          // optional [B][heads][N]: natural-log row log-sum-exp of the scaled scores, for the training backward
+                       // (written by attention_v2_kernel only: launch_attention refuses it on the other paths)
 };
 int launch_attention(const AttnArgs& a, int dt, hipStream_t s);
-int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s);
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse = nullptr);
+// k_attn_bwd.hip: one-pass backward from the forward's log-sum-exp (bf16, d = 32, T a multiple of 64)
+int launch_attention_legacy_backward_lse(const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                                         int B, int T, int heads, hipStream_t s);
+inline bool attention_bwd_lse_ok(int dt, int T, int d) { return dt == DT_BF16 && d == 32 && T % 64 == 0; }
 
 // ---- fused plane sampling + coordinate MLP (image) ------------------------------------------------------
 struct Mlp2dLayer { const void* w; const float* bias; int K; };  // w [256][K] dtype dt (folded), bias [256] fp32

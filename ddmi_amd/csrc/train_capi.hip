@@ -277,6 +277,22 @@ int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T,
   DDMI_REQUIRE(h && qkv && out, "train_attn_fwd: null argument");
   return launch_attention_legacy(qkv, out, h->dt, B, T, heads, d, (hipStream_t)stream);
 }
+// the same pair with the forward's row log-sum-exp handed over (lse [B][heads][T] fp32, caller-owned): the backward then makes one
+// pass over the scores (k_attn_bwd.hip).  bf16 handles, d = 32, T a multiple of 64 (ddmi_train_attn_lse_ok); anything else is refused.
+int ddmi_train_attn_lse_ok(ddmi_train* h, int T, int d) { return h && attention_bwd_lse_ok(h->dt, T, d) ? 1 : 0; }
+int ddmi_train_attn_fwd_lse(ddmi_train* h, const void* qkv, void* out, float* lse, int B, int T, int heads, int d, void* stream) {
+  DDMI_REQUIRE(h && qkv && out && lse, "train_attn_fwd_lse: null argument");
+  DDMI_REQUIRE(attention_bwd_lse_ok(h->dt, T, d), "train_attn_fwd_lse: bf16, head dim 32, token count a multiple of 64");
+  return launch_attention_legacy(qkv, out, h->dt, B, T, heads, d, (hipStream_t)stream, lse);
+}
+int ddmi_train_attn_bwd_lse(ddmi_train* h, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T,
+                            int heads, int d, void* stream) {
+  DDMI_REQUIRE(h && qkv && out && dout && dqkv && lse, "train_attn_bwd_lse: null argument");
+  DDMI_REQUIRE(attention_bwd_lse_ok(h->dt, T, d), "train_attn_bwd_lse: bf16, head dim 32, token count a multiple of 64");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, (size_t)B * heads * T * sizeof(float), s));
+  return launch_attention_legacy_backward_lse(qkv, out, dout, dqkv, lse, (float*)h->ws, B, T, heads, s);
+}
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
                         void* stream) {
   DDMI_REQUIRE(h && qkv && out && dout && dqkv, "train_attn_bwd: null argument");

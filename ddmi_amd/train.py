@@ -13,6 +13,7 @@ Activations are NHWC tensors in the storage dtype of the numerics mode (fp32 par
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional, Sequence
 
@@ -185,19 +186,30 @@ class AttentionLegacyFn(torch.autograd.Function):
         B, H, W, C3 = qkv.shape
         d = C3 // (3 * heads)
         out = torch.empty((B, H, W, heads * d), dtype=tc.dtype, device=qkv.device)
-        _lib.check(_lib.lib().ddmi_train_attn_fwd(tc.h, qkv.data_ptr(), out.data_ptr(), B, H * W, heads, d, _stream()))
-        ctx.save_for_backward(qkv, out)
+        L = _lib.lib()
+        # the forward's row log-sum-exp rides along when the one-pass backward exists for this shape (bf16, d = 32, T % 64 == 0)
+        if L.ddmi_train_attn_lse_ok(tc.h, H * W, d) and os.environ.get("DDMI_ATTN_BWD_LEGACY") != "1":
+            lse = torch.empty((B, heads, H * W), dtype=torch.float32, device=qkv.device)
+            _lib.check(L.ddmi_train_attn_fwd_lse(tc.h, qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H * W, heads, d, _stream()))
+            ctx.save_for_backward(qkv, out, lse)
+        else:
+            _lib.check(L.ddmi_train_attn_fwd(tc.h, qkv.data_ptr(), out.data_ptr(), B, H * W, heads, d, _stream()))
+            ctx.save_for_backward(qkv, out)
         ctx.tc, ctx.heads = tc, heads
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out = ctx.saved_tensors
+        qkv, out = ctx.saved_tensors[:2]
         B, H, W, C3 = qkv.shape
         d = C3 // (3 * ctx.heads)
         dqkv = torch.empty_like(qkv)
-        _lib.check(_lib.lib().ddmi_train_attn_bwd(ctx.tc.h, qkv.data_ptr(), out.data_ptr(), dout.contiguous().data_ptr(), dqkv.data_ptr(), B,
-                                                  H * W, ctx.heads, d, _stream()))
+        if len(ctx.saved_tensors) == 3:
+            _lib.check(_lib.lib().ddmi_train_attn_bwd_lse(ctx.tc.h, qkv.data_ptr(), out.data_ptr(), dout.contiguous().data_ptr(),
+                                                          ctx.saved_tensors[2].data_ptr(), dqkv.data_ptr(), B, H * W, ctx.heads, d, _stream()))
+        else:
+            _lib.check(_lib.lib().ddmi_train_attn_bwd(ctx.tc.h, qkv.data_ptr(), out.data_ptr(), dout.contiguous().data_ptr(), dqkv.data_ptr(), B,
+                                                      H * W, ctx.heads, d, _stream()))
         return None, dqkv, None
 
 

@@ -368,6 +368,13 @@ int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const fl
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream);
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
                         void* stream);
+/* the same pair with the forward's row log-sum-exp saved for the backward (lse [B,heads,T] fp32, natural log of the sum of
+ * exp(scaled scores)): the backward then makes one pass over the scores instead of three.  Available when
+ * ddmi_train_attn_lse_ok() returns 1 (bf16 handle, d = 32, T a multiple of 64); refused (DDMI_ERR_INVALID) otherwise. */
+int ddmi_train_attn_lse_ok(ddmi_train* h, int T, int d);
+int ddmi_train_attn_fwd_lse(ddmi_train* h, const void* qkv, void* out, float* lse, int B, int T, int heads, int d, void* stream);
+int ddmi_train_attn_bwd_lse(ddmi_train* h, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T,
+                            int heads, int d, void* stream);
 /* y = act(x) W^T + b (fp32 [B,K] -> [B,N]; act = SiLU when silu_in): time_embed and the ResBlock emb_layers */
 int ddmi_train_linear_fwd(ddmi_train* h, const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in,
                           void* stream);

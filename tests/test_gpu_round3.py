@@ -445,3 +445,45 @@ def test_persistent_1x1_kernel(case):
         L.ddmi_debug_conv_config(-1)
     assert rel_err(y, ref) < 1.5e-2 and rel_l2(y, ref) < 1e-2, (rel_err(y, ref), rel_l2(y, ref))
     assert float((y.cpu() - ref).abs().max()) < 0.03 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,heads,side", [(3, 2, 8), (8, 3, 32), (5, 14, 16), (16, 2, 16)])
+def test_attention_backward_from_the_forward_lse(B, heads, side, monkeypatch):
+    """The one-pass attention backward (k_attn_bwd.hip): the forward hands over the row log-sum-exp, dQ / dK / dV come from two
+    kernels with the query / the key on the MFMA lane.  Against the oracle's QKVAttentionLegacy under autograd (fp32), against the
+    three-pass kernels it replaces, bit-reproducible; batches in plain order (B = 3, 5) and dealt to the XCDs by sample (8, 16);
+    one tile (T = 64: 64 rows per workgroup), 256 and 1024 tokens (128 rows per workgroup)."""
+    from ddmi_amd import train as T
+    tc = T.TrainContext("bf16", DEV)
+    d, tok = 32, side * side
+    tag = "attnbwd%s" % ((B, heads, side),)
+    qkv = torch.from_numpy(iw.normal(tag, "qkv", (B, heads * 3 * d, tok))).to(torch.bfloat16).float()
+    dout = torch.from_numpy(iw.normal(tag, "dout", (B, heads * d, tok))).to(torch.bfloat16).float()
+    qr = qkv.clone().requires_grad_(True)
+    out_r = O.qkv_attention_legacy(qr, heads)
+    out_r.backward(dout)
+
+    def run():
+        qd = qkv.reshape(B, -1, side, side).permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16).requires_grad_(True)
+        out = T.AttentionLegacyFn.apply(tc, qd, heads)
+        out.backward(dout.reshape(B, -1, side, side).permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16))
+        return (out.detach().float().permute(0, 3, 1, 2).reshape(B, heads * d, tok).cpu(),
+                qd.grad.float().permute(0, 3, 1, 2).reshape(B, heads * 3 * d, tok).cpu())
+
+    assert _lib.lib().ddmi_train_attn_lse_ok(tc.h, tok, d) == 1
+    out, dq = run()
+    out2, dq2 = run()
+    assert torch.equal(dq, dq2) and torch.equal(out, out2)          # no atomics anywhere
+    assert rel_l2(out, out_r.detach()) < 6e-3
+    assert rel_l2(dq, qr.grad) < 1.2e-2 and rel_err(dq, qr.grad) < TOL_BF16
+    # the q, k and v blocks separately (a wrong dK hides behind a large dV in a norm over all three)
+    g = dq.reshape(B, heads, 3, d, tok)
+    gr = qr.grad.reshape(B, heads, 3, d, tok)
+    for part in range(3):
+        assert rel_l2(g[:, :, part], gr[:, :, part]) < 1.5e-2, part
+    monkeypatch.setenv("DDMI_ATTN_BWD_LEGACY", "1")
+    out_l, dq_l = run()
+    assert torch.equal(out_l, out)                                   # the forward kernel is the same, with or without the lse output
+    assert rel_l2(dq, dq_l) < 1.2e-2
+    # fp32 handles keep the three-pass kernels
+    assert _lib.lib().ddmi_train_attn_lse_ok(T.TrainContext("fp32", DEV).h, tok, d) == 0
