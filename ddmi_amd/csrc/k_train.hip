@@ -216,6 +216,8 @@ struct WgradTnK {
   const bf16_t* x;    // [B][H][W][Ci]
   float* slab;        // [S][Co][Ci][KK]
   int B, H, W, Co, Ci, S, TR, wshift;
+  int gx, gy;         // ci / co blocks of the tile grid (the launch is 1-D: wg_block)
+  int all_frags;      // diagnostics (DDMI_WGRAD_ALLFRAGS): bit 0 multiply the zero fragments of ragged tiles, bit 1 plain workgroup order (round 2)
   int ups;            // x is [B][H/2][W/2][Ci] and the convolution ran on its nearest x2 upsampling (Upsample.conv): halo row (iy, ix)
                       // is fetched from source pixel (iy >> 1, ix >> 1) - a change of DMA addresses only
 };
@@ -237,20 +239,51 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* lo, const unsi
 }
 // byte offset inside a [rows][64 channel] tile of (row r, 16-channel unit 0): KiB blocks of 8 rows, [unit][row & 7][32 B]
 __device__ __forceinline__ int wg_row(int r) { return (r >> 3) * 768 + r * 32; }
+// the same offset without the quarter-rate multiply (WIDE tap loop; in the narrow loop, which computes two addresses per tap, the
+// multiply form schedules better: 562 vs 624 us at 896 -> 896 @16x16)
+__device__ __forceinline__ int wg_row_s(int r) { return ((r >> 3) << 10) | ((r & 7) << 5); }
 
-template <int KK>
+// 1-D launch, XCD-aware: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  The tile list is
+// slice-major - the gx * gy workgroups of one pixel slice read the SAME dY / X tiles - and XCD x takes a contiguous eighth of
+// it, so the readers of a slice share one L2 (as a 3-D grid their linear ids were consecutive: eight XCDs, every tile fetched
+// from HBM by each of them; 224 -> 224 at 64x64 has exactly 8 workgroups per slice).  All workgroups are resident at once (one
+// per CU) and walk their slices in step.  Returns false for the padding of the last eighth.
+__device__ __forceinline__ bool wg_block(const WgradTnK& a, int* bx, int* by, int* bz) {
+  const int per = a.gx * a.gy, n = per * a.S, chunk = (int)(gridDim.x >> 3);
+  const int idx = a.all_frags & 2 ? (int)blockIdx.x : ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);   // (bit 1: plain order)
+  if (idx >= n) return false;
+  const int z = idx / per, rem = idx - z * per;
+  *bz = z;
+  *by = rem / a.gx;
+  *bx = rem - *by * a.gx;
+  return true;
+}
+
+// WIDE (W >= 32): the two 4-pixel blocks of a lane's k-step (pixels p and p + 16) lie in one image row, their halo rows 16 apart =
+// two KiB blocks of the X image: the second transposing read is the first one's address + 2048 (an instruction offset), which halves
+// the address arithmetic of the tap loop (it was ~10 VALU per 4 MFMAs).
+template <int KK, bool WIDE>
 __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
   constexpr int KS3 = KK == 9 ? 3 : 1, PAD = KK == 9 ? 1 : 0;
   extern __shared__ __attribute__((aligned(1024))) unsigned char wg_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave & 3, hf = wave >> 2;
+  // wave -> (co half hf, ci fragment wi).  Waves w and w + 4 share a SIMD; the pairing (hf 0, wi) + (hf 1, wi ^ 2) puts on every
+  // SIMD one wave of each co half AND one wave of each ci half, so a ragged tile (Co = 224: the second co block holds 96 channels,
+  // Ci = 224: the last ci block 32) leaves every SIMD the same share of the MFMAs that are left - none are spent on zero fragments
+  // (round 2 multiplied them: 23 % of the kernel's MFMAs at 224 channels)
+  const int hf = wave >> 2, wi = (wave ^ (hf << 1)) & 3;
   const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, p4 = lr & 3;
   const int W = a.W, H = a.H, TR = a.TR, PT = TR * W;          // pixels per tile (<= 128)
   const int HWd = W + 2 * PAD, NHR = (TR + 2 * PAD) * HWd;     // halo geometry (no halo for 1x1)
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
+  int bx, by, bz;
+  if (!wg_block(a, &bx, &by, &bz)) return;   // (workgroup-uniform, before any barrier)
+  const int ci0 = bx * 64, co0 = by * 128;
+  // co fragments of this wave that hold channels (0..4); a wave whose ci fragment is past Ci only moves tiles
+  const int nf_co = min(4, max(0, (a.Co - co0 - 64 * hf + 15) >> 4));
+  const int nf = a.all_frags & 1 ? 4 : ci0 + 16 * wi < a.Ci ? nf_co : 0;
   const int tiles_per_sample = (H * W) / PT, ntiles = a.B * tiles_per_sample;
-  const int per = (ntiles + a.S - 1) / a.S, t_begin = blockIdx.z * per, t_end = min(ntiles, t_begin + per);
+  const int per = (ntiles + a.S - 1) / a.S, t_begin = bz * per, t_end = min(ntiles, t_begin + per);
 
   // ---- DMA roles (fixed over the tiles): instruction gi = wave + 8 j moves rows 8 gi .. 8 gi + 7; lane = (row, 16-byte slot)
   const int drow = (lane >> 1) & 7, dchunk = 2 * (lane >> 4) + (lane & 1);   // LDS position 16 lane = [unit][row][half]
@@ -307,32 +340,44 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
   __syncthreads();
   int stage = 0;
   for (int t = t_begin; t < t_end; ++t) {
-    if (t + 1 < t_end) issue(t + 1, stage ^ 1);   // the other stage was last read before the barrier that ended tile t-1
+    // the other stage was last read before the barrier that ended tile t-1.  (Spreading the nine DMA instructions over the k-steps,
+    // the two waves of a SIMD half a tile apart - an LDS-DMA instruction costs its wave 60-180 issue cycles - measured 5-8 %
+    // SLOWER on every shape: the pieces' scalar bookkeeping inside the k-loop costs more than the idle matrix pipe it removes.)
+    if (t + 1 < t_end) issue(t + 1, stage ^ 1);
     const unsigned char* Y = wg_smem + stage * WG_STAGE + hf * WG_YB;
     const unsigned char* X = wg_smem + stage * WG_STAGE + 2 * WG_YB;
+    // two copies of the k-loop (wave-uniform choice): all four co fragments, or the first two (a ragged co half: nf <= 2); a wave
+    // without channels skips it.  (Guarding fragments 2 / 3 inside ONE loop body cut it into basic blocks the scheduler no longer
+    // interleaves: +6 % on the full waves.)
+    auto k_loop = [&](auto nfc) {
+      constexpr int NF = decltype(nfc)::value;
 #pragma unroll 1
-    for (int ks = 0; ks < PT / 32; ++ks) {
-      // k index of the k-step: lane group lg, element e -> pixel 4 lg + e (e < 4), 16 + 4 lg + e - 4 (e >= 4); this lane
-      // supplies the address of row q of both blocks
-      const int pl0 = ks * 32 + 4 * lg + q, pl1 = pl0 + 16;
-      const unsigned char* y0 = Y + wg_row(pl0) + 8 * p4;
-      const unsigned char* y1 = Y + wg_row(pl1) + 8 * p4;
-      bf16x8 af[4];
+      for (int ks = 0; ks < PT / 32; ++ks) {
+        // k index of the k-step: lane group lg, element e -> pixel 4 lg + e (e < 4), 16 + 4 lg + e - 4 (e >= 4); this lane
+        // supplies the address of row q of both blocks
+        const int pl0 = ks * 32 + 4 * lg + q, pl1 = pl0 + 16;
+        const unsigned char* y0 = Y + wg_row(pl0) + 8 * p4;
+        const unsigned char* y1 = Y + wg_row(pl1) + 8 * p4;
+        bf16x8 af[NF];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) af[f] = wg_tr_frag(y0 + 256 * f, y1 + 256 * f);
-      const int r0 = (pl0 >> a.wshift) * HWd + (pl0 & (W - 1)), r1 = (pl1 >> a.wshift) * HWd + (pl1 & (W - 1));
-      const unsigned char* xb = X + 256 * wi + 8 * p4;
+        for (int f = 0; f < NF; ++f) af[f] = wg_tr_frag(y0 + 256 * f, y1 + 256 * f);
+        const int r0 = (pl0 >> a.wshift) * HWd + (pl0 & (W - 1)), r1 = (pl1 >> a.wshift) * HWd + (pl1 & (W - 1));
+        const unsigned char* xb = X + 256 * wi + 8 * p4;
 #pragma unroll
-      for (int kh = 0; kh < KS3; ++kh)
+        for (int kh = 0; kh < KS3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < KS3; ++kw) {
-          const int sh = kh * HWd + kw;
-          const bf16x8 bf = wg_tr_frag(xb + wg_row(r0 + sh), xb + wg_row(r1 + sh));
+          for (int kw = 0; kw < KS3; ++kw) {
+            const int sh = kh * HWd + kw;
+            const unsigned char* xlo = xb + (WIDE ? wg_row_s(r0 + sh) : wg_row(r0 + sh));
+            const bf16x8 bf = wg_tr_frag(xlo, WIDE ? xlo + 2048 : xb + wg_row(r1 + sh));
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
-            acc[f][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bf, acc[f][kh * KS3 + kw], 0, 0, 0);
-        }
-    }
+            for (int f = 0; f < NF; ++f)
+              acc[f][kh * KS3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bf, acc[f][kh * KS3 + kw], 0, 0, 0);
+          }
+      }
+    };
+    if (nf > 2) k_loop(std::integral_constant<int, 4>{});
+    else if (nf > 0) k_loop(std::integral_constant<int, 2>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t+1 has landed
     __syncthreads();                                    // ... everyone's has, and everyone is done reading tile t
     stage ^= 1;
@@ -346,7 +391,7 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
       for (int e = 0; e < 4; ++e) {
         const int co = co0 + 64 * hf + 16 * f + 4 * lg + e;
         if (co < a.Co) {
-          float* dst = a.slab + (((int64_t)blockIdx.z * a.Co + co) * a.Ci + ci) * KK;
+          float* dst = a.slab + (((int64_t)bz * a.Co + co) * a.Ci + ci) * KK;
 #pragma unroll
           for (int t = 0; t < KK; ++t) dst[t] = acc[f][t][e];
         }
@@ -366,9 +411,11 @@ __global__ void __launch_bounds__(512) wgrad_tn1_kernel(WgradTnK a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 3, hf = wave >> 2;
   const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, p4 = lr & 3;
-  const int ci0 = blockIdx.x * 256, co0 = blockIdx.y * 256;
+  int bx, by, bz;
+  if (!wg_block(a, &bx, &by, &bz)) return;
+  const int ci0 = bx * 256, co0 = by * 256;
   const int ntiles = a.B;                         // a.B = number of 64-pixel tiles of the flat pixel list here
-  const int per = (ntiles + a.S - 1) / a.S, t_begin = blockIdx.z * per, t_end = min(ntiles, t_begin + per);
+  const int per = (ntiles + a.S - 1) / a.S, t_begin = bz * per, t_end = min(ntiles, t_begin + per);
   const int drow = (lane >> 1) & 7, dchunk = 2 * (lane >> 4) + (lane & 1);
   unsigned yoff[4], xoff[4];                       // instruction gi = wave + 8 j: panel gi >> 3, rows 8 (gi & 7) ..
 #pragma unroll
@@ -429,7 +476,7 @@ __global__ void __launch_bounds__(512) wgrad_tn1_kernel(WgradTnK a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int co = co0 + 128 * hf + 16 * f + 4 * lg + e;
-        if (co < a.Co) a.slab[((int64_t)blockIdx.z * a.Co + co) * a.Ci + ci] = acc[f][u][e];
+        if (co < a.Co) a.slab[((int64_t)bz * a.Co + co) * a.Ci + ci] = acc[f][u][e];
       }
   }
 }
@@ -468,10 +515,13 @@ int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B
   a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
   a.B = B; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci; a.ups = ups ? 1 : 0;
   a.S = wgrad_tn_splits(B, H, W, Ci, Co, k);
+  static const int all_frags = getenv("DDMI_WGRAD_ALLFRAGS") ? atoi(getenv("DDMI_WGRAD_ALLFRAGS")) : 0;   // diagnostics
+  a.all_frags = all_frags;
   const int kk = k * k;
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG1_STAGE));
     attr_done = true;
   }
@@ -479,11 +529,14 @@ int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B
   if (k == 3) {
     a.TR = std::min(128, H * W) / W;
     a.wshift = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
-    dim3 g((unsigned)cdiv(Ci, 64), (unsigned)cdiv(Co, 128), (unsigned)a.S);
-    hipLaunchKernelGGL(wgrad_tn_kernel<9>, g, dim3(512), 2 * WG_STAGE, s, a);
+    a.gx = cdiv(Ci, 64); a.gy = cdiv(Co, 128);
+    dim3 g((unsigned)(cdiv(a.gx * a.gy * a.S, 8) * 8));
+    if (W >= 32) hipLaunchKernelGGL((wgrad_tn_kernel<9, true>), g, dim3(512), 2 * WG_STAGE, s, a);
+    else hipLaunchKernelGGL((wgrad_tn_kernel<9, false>), g, dim3(512), 2 * WG_STAGE, s, a);
   } else {
     a.B = (int)((int64_t)B * H * W / 64);   // 64-pixel tiles of the flat pixel list
-    dim3 g((unsigned)cdiv(Ci, 256), (unsigned)cdiv(Co, 256), (unsigned)a.S);
+    a.gx = cdiv(Ci, 256); a.gy = cdiv(Co, 256);
+    dim3 g((unsigned)(cdiv(a.gx * a.gy * a.S, 8) * 8));
     hipLaunchKernelGGL(wgrad_tn1_kernel, g, dim3(512), 2 * WG1_STAGE, s, a);
   }
   const int64_t n = (int64_t)Co * Ci * kk;

@@ -94,7 +94,9 @@ static void prefer_halo(ConvArgs* c, int dt) {
   if (dt == DT_BF16 && c->KH == 1 && c->Cout % 112 == 0 && (int64_t)c->B * c->Hout * c->Wout >= 256 * 64) {
     // 1x1 (qkv / proj / skip, forward and dgrad): the pipe kernel equals or beats the heuristic's ring tile on every such shape
     // (profiles/r3_conv1x1_variants_b512.txt: 992 vs 1 072 us, 789 vs 830, 408 vs 434, 339 vs 355)
-    c->cfg = 14;   // pipe<256,224,4,2>
+    // round 3: the persistent 1x1 kernel where the channel counts allow (4-20 % over the pipe kernel at B = 512); launch_conv
+    // falls back to the pipe kernel by itself for the shapes it does not take (Cin <= 128, ragged Cout)
+    c->cfg = c->Cout % 224 == 0 ? 25 : 14;   // gemm1x1<224,4,2> : pipe<256,224,4,2>
     c->order = 3;  // paired fragments
     return;
   }

@@ -11,8 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ddmi_amd import _lib  # noqa: E402
 from ddmi_amd import train as T  # noqa: E402
 
-SHAPES = [(64, 224, 224, 3), (64, 448, 224, 3), (32, 448, 448, 3), (32, 896, 448, 3), (16, 672, 672, 3), (16, 1344, 672, 3),
-          (8, 896, 896, 3), (8, 1792, 896, 3), (32, 224, 448, 1), (16, 448, 672, 1)]
+SHAPES = [(64, 224, 224, 3), (64, 448, 224, 3), (64, 672, 224, 3), (32, 448, 448, 3), (32, 896, 448, 3), (32, 1344, 448, 3),
+          (16, 896, 896, 3), (16, 1792, 896, 3), (16, 2240, 896, 3), (8, 1344, 1344, 3), (8, 2688, 1344, 3), (32, 224, 448, 1), (16, 448, 896, 1)]
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
