@@ -139,6 +139,19 @@ int ddmi_train_conv_fwd(ddmi_train* h, const void* x, const float* w, const floa
   a.x = x; a.bias = bias; a.emb = emb; a.emb_stride = emb_stride; a.res = res; a.y = y;
   a.B = B; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = Ho; a.Wout = Wo; a.Cout = Cout;
   a.KH = a.KW = k; a.stride = stride; a.pad = k / 2; a.ups = ups ? 1 : 0; a.out_scale = 1.f;
+  // Upsample.conv (bias only): the parity form of nearest x2 + 3x3 the inference networks use - four 2x2 convolutions on the source
+  // grid with pre-summed weights (summed in fp32 from the master weights, every step), 4/9 of the FLOPs, on the 2x2 halo kernel
+  static const bool no_up4 = getenv("DDMI_CONV_UP4") && atoi(getenv("DDMI_CONV_UP4")) == 0;
+  if (ups && k == 3 && dt == DT_BF16 && !emb && !res && !no_up4) {
+    const size_t w4 = al((size_t)16 * Cout * Cin * dt_size(dt));
+    DDMI_TRY(reserve(h, w4, s));
+    Carve c{h};
+    void* wp = c.take(w4);
+    DDMI_TRY(launch_pack_conv_up4_f32(w, wp, Cout, Cin, s));
+    a.w = wp; a.ups = 3; a.KH = a.KW = 2; a.pad = 1; a.splitk = 1;
+    a.cfg = Cout % 224 == 0 ? 20 : 0;   // halo<224,4,2> (2x2 instantiation); launch_conv falls back when the shape is not eligible
+    return launch_conv(a, dt, s);
+  }
   prefer_halo(&a, dt);
   a.splitk = conv_pick_splitk(a, dt);
   const size_t wbytes = al((size_t)Cout * Cin * k * k * dt_size(dt));

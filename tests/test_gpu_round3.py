@@ -487,3 +487,29 @@ def test_attention_backward_from_the_forward_lse(B, heads, side, monkeypatch):
     assert rel_l2(dq, dq_l) < 1.2e-2
     # fp32 handles keep the three-pass kernels
     assert _lib.lib().ddmi_train_attn_lse_ok(T.TrainContext("fp32", DEV).h, tok, d) == 0
+
+
+@pytest.mark.parametrize("B,cin,cout,hw", [(2, 64, 224, 16), (3, 448, 448, 8), (2, 224, 96, 32)])
+def test_training_upsample_conv_parity_form(B, cin, cout, hw):
+    """Upsample.conv of the training path (bias only): the forward runs the parity form of nearest x2 + 3x3 - four 2x2
+    convolutions on the source grid, weights pre-summed in fp32 from the master weights each step (2x2 halo kernel where the shape
+    allows, Cout = 96 falls back) - the backward stays on the 3x3 weights.  Output and all gradients against torch."""
+    from ddmi_amd import train as T
+    tc = T.TrainContext("bf16", DEV)
+    tag = "upt%s" % ((B, cin, cout, hw),)
+    x = torch.from_numpy(iw.normal(tag, "x", (B, cin, hw, hw))).to(torch.bfloat16).float()
+    w = torch.from_numpy(iw.normal(tag, "w", (cout, cin, 3, 3), 0.0, 1.0 / math.sqrt(cin * 9)))
+    b = torch.from_numpy(iw.normal(tag, "b", (cout,), 0.0, 0.1))
+    dy = torch.from_numpy(iw.normal(tag, "dy", (B, cout, 2 * hw, 2 * hw))).to(torch.bfloat16).float()
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wr, br, padding=1)
+    yr.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16).requires_grad_(True)
+    wd, bd = w.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    y = T.ConvFn.apply(tc, xd, wd, bd, None, None, 1, True)
+    got = y.detach().float().permute(0, 3, 1, 2).cpu()
+    assert got.shape == yr.shape
+    assert rel_l2(got, yr.detach()) < 6e-3 and rel_err(got, yr.detach()) < TOL_BF16
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16))
+    assert rel_l2(xd.grad.float().permute(0, 3, 1, 2).cpu(), xr.grad) < 1e-2
+    assert rel_l2(wd.grad.cpu(), wr.grad) < 1e-2 and rel_l2(bd.grad.cpu(), br.grad) < 1e-2
