@@ -217,7 +217,7 @@ struct WgradTnK {
   float* slab;        // [S][Co][Ci][KK]
   int B, H, W, Co, Ci, S, TR, wshift;
   int gx, gy;         // ci / co blocks of the tile grid (the launch is 1-D: wg_block)
-  int all_frags;      // diagnostics (DDMI_WGRAD_ALLFRAGS): bit 0 multiply the zero fragments of ragged tiles, bit 1 plain workgroup order (round 2)
+  int all_frags;      // diagnostics (DDMI_WGRAD_ALLFRAGS): bit 0 multiply the zero fragments of ragged tiles, bit 1 plain workgroup order (round 2), bit 2 no stagger of the DMA issue
   int ups;            // x is [B][H/2][W/2][Ci] and the convolution ran on its nearest x2 upsampling (Upsample.conv): halo row (iy, ix)
                       // is fetched from source pixel (iy >> 1, ix >> 1) - a change of DMA addresses only
 };
@@ -304,8 +304,10 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
     xoff[j] = a.ups ? ((((hy - PAD) >> 1) * (W >> 1) + ((hx - PAD) >> 1)) * a.Ci + ci) * 2 : (((hy - PAD) * W + hx - PAD) * a.Ci + ci) * 2;
     xhy[j] = ok ? hy - PAD : -(1 << 20);
   }
-  auto issue = [&](int t, int stage) {
-    const int b = t / tiles_per_sample, ty0 = (t - b * tiles_per_sample) * TR;
+  // (sample, first row) of the tile to fetch next, advanced tile by tile: the division t / tiles_per_sample per tile was ~25
+  // instructions of every wave's issue stream
+  int nb = t_begin / tiles_per_sample, nty = (t_begin - nb * tiles_per_sample) * TR;
+  auto issue = [&](int b, int ty0, int stage) {
     unsigned char* base = wg_smem + stage * WG_STAGE;
     const bf16_t* yg = a.dy + ((int64_t)b * H * W + ty0 * W) * a.Co;
     const int x_px = a.ups ? (H >> 1) * (W >> 1) : H * W;     // pixels of one sample of x
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (t_begin < t_end) issue(t_begin, 0);
+  if (t_begin < t_end) issue(nb, nty, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int stage = 0;
@@ -343,7 +345,15 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
     // the other stage was last read before the barrier that ended tile t-1.  (Spreading the nine DMA instructions over the k-steps,
     // the two waves of a SIMD half a tile apart - an LDS-DMA instruction costs its wave 60-180 issue cycles - measured 5-8 %
     // SLOWER on every shape: the pieces' scalar bookkeeping inside the k-loop costs more than the idle matrix pipe it removes.)
-    if (t + 1 < t_end) issue(t + 1, stage ^ 1);
+    // An LDS-DMA instruction costs its wave 60-180 issue cycles and all eight waves used to issue their nine at the top of the tile,
+    // the matrix pipe idle meanwhile (fetching nothing after the first tile - timing only - is 20-28 % faster).  The two waves of a
+    // SIMD are now a k-step apart: the hf 1 wave issues behind its first k-step, under the hf 0 wave's MFMAs and vice versa.
+    nty += TR;
+    if (nty >= H) { nty = 0; ++nb; }
+    const bool more = t + 1 < t_end && !(a.all_frags & 8);   // (bit 3, timing experiments only: no tile after the first is fetched)
+    // (WIDE only: in the narrow instantiation the second in-loop copy of the issue code spills, 6-12 % slower)
+    const bool late = WIDE && more && hf == 1 && nf > 0 && !(a.all_frags & 4);
+    if (more && !late) issue(nb, nty, stage ^ 1);
     const unsigned char* Y = wg_smem + stage * WG_STAGE + hf * WG_YB;
     const unsigned char* X = wg_smem + stage * WG_STAGE + 2 * WG_YB;
     // two copies of the k-loop (wave-uniform choice): all four co fragments, or the first two (a ragged co half: nf <= 2); a wave
@@ -361,6 +371,9 @@ __global__ void __launch_bounds__(512) wgrad_tn_kernel(WgradTnK a) {
         bf16x8 af[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) af[f] = wg_tr_frag(y0 + 256 * f, y1 + 256 * f);
+        if constexpr (WIDE) {
+          if (late && ks == 1) issue(nb, nty, stage ^ 1);
+        }
         const int r0 = (pl0 >> a.wshift) * HWd + (pl0 & (W - 1)), r1 = (pl1 >> a.wshift) * HWd + (pl1 & (W - 1));
         const unsigned char* xb = X + 256 * wi + 8 * p4;
 #pragma unroll

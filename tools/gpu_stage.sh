@@ -19,7 +19,7 @@ for st in "$@"; do
     train)     timeout 1500 python -m pytest tests/test_gpu_train.py -q -x > $log 2>&1 ;;
     trainall)  timeout 1500 python -m pytest tests/test_gpu_train.py -q > $log 2>&1 ;;
     wgradbench) timeout 600 python tools/bench_wgrad.py 128 > $log 2>&1 ;;
-    wgradbenchA) DDMI_WGRAD_ALLFRAGS=3 timeout 600 python tools/bench_wgrad.py 128 > $log 2>&1 ;;
+    wgradbenchA) DDMI_WGRAD_ALLFRAGS=4 timeout 600 python tools/bench_wgrad.py 128 > $log 2>&1 ;;
     stepbench) timeout 300 python tools/bench_step.py > $log 2>&1 ;;
     opstests)  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_networks.py -q -k "philox or ddpm_step or pipeline or generate_chain" > $log 2>&1 ;;
     mlpts)     DDMI_MLP2D_TS=1 timeout 300 python tools/bench_mlp.py --which 2d > $log 2>&1 ;;
