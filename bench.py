@@ -120,7 +120,7 @@ def _profile_entry(glob_pat, live_name):
         bm, bn, kk, nst = (int(v) for v in m.groups()[:4])
         pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}, {'true' if m.group(5) else 'false'}>")
     elif m2 and m2.group(1).startswith("halo"):  # conv_halo_kernel<BN, WM, WN, SKIP>: BM is fixed at 256
-        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}>")
+        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}(, 3)?>")   # (, 3: the 3x3 tap grid; 2 = conv_halo_up4)
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
