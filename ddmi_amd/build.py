@@ -36,7 +36,11 @@ def _newest_header() -> float:
 
 # per-file extras.  k_attention: keep MFMA results in VGPRs - the softmax between the two matrix products is VALU work on
 # the score accumulators, and with AGPR accumulators the compiler brackets it with ~80 v_accvgpr moves per 64-key tile
-EXTRA_FLAGS = {"k_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "k_attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# -fno-slp-vectorize: packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32, which the SLP vectoriser forms from adjacent scalar multiplies)
+# is an anti-lever beside MFMAs (MI355X_MICROARCH.md, per-instruction cycle constants): measured on one box, attention backward
+# dQ 289 -> 266 us, dK/dV 380 -> 360, the eager-maximum forward 270 -> 261; the lazy forward has none in its hot path (unchanged)
+_ATTN_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]
+EXTRA_FLAGS = {"k_attention.hip": _ATTN_FLAGS, "k_attn_bwd.hip": _ATTN_FLAGS}
 
 
 def _compile(src: str, force: bool, hdr_mtime: float) -> str:
