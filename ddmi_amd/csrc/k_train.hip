@@ -830,7 +830,9 @@ __global__ void gn_bwd_finish_kernel(const float* __restrict__ part, float* __re
 template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mr,
                                     const float* __restrict__ ab, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    T* __restrict__ dx, int HW, int C, int NV, int R, int silu) {
+                                    T* __restrict__ dx, int HW, int C, int NV, int R, int silu, const T* __restrict__ dres) {
+  // dres: a second gradient of x (the residual / skip path of the block whose first op this GroupNorm is), added here instead of
+  // by autograd's own add kernel: one more read in this pass against a read-read-write pass of its own
   constexpr int VN = TrVec<T>::N;
   __shared__ float smr[TR_GROUPS * 2], sab[TR_GROUPS * 2];
   const int b = blockIdx.y, tid = threadIdx.x, cpg = C / TR_GROUPS;
@@ -861,6 +863,12 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
       if (silu) dz *= tr_dsilu(ga[i] * xh + be[i]);
       ov[i] = rstd[i] * (dz * ga[i] - mA[i] - xh * mB[i]);
     }
+    if (dres != nullptr) {
+      float rv[VN];
+      TrVec<T>::load(dres + o, rv);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) ov[i] += rv[i];
+    }
     TrVec<T>::store(dx + o, ov);
   }
 }
@@ -869,7 +877,8 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
 size_t gn_backward_scratch_floats(int B, int HW, int C) { return (size_t)B * 64 + (size_t)2 * B * C + (size_t)B * gn_nsplit(B, HW) * C * 4; }
 
 int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
-                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s, int accumulate) {
+                       float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s, int accumulate,
+                       const void* dres) {
   const int vn = dt == DT_F32 ? 4 : 8;
   DDMI_REQUIRE(C % TR_GROUPS == 0 && C % vn == 0, "gn_backward: C must be a multiple of 32 and of the 16-byte vector");
   const int NV = C / vn;
@@ -888,11 +897,11 @@ int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, con
   if (dt == DT_F32) {
     hipLaunchKernelGGL(gn_bwd_partial_kernel<float>, g, dim3(threads), lds, s, (const float*)x, (const float*)dy, meanrstd, gamma, beta, part, HW, C, NV, R, silu);
     hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B), dim3(256), (size_t)2 * C * sizeof(float), s, part, ab, dgp, dbp, ns, HW, C);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (const float*)dy, meanrstd, ab, gamma, beta, (float*)dx, HW, C, NV, R, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g, dim3(threads), 0, s, (const float*)x, (const float*)dy, meanrstd, ab, gamma, beta, (float*)dx, HW, C, NV, R, silu, (const float*)dres);
   } else {
     hipLaunchKernelGGL(gn_bwd_partial_kernel<bf16_t>, g, dim3(threads), lds, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, gamma, beta, part, HW, C, NV, R, silu);
     hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B), dim3(256), (size_t)2 * C * sizeof(float), s, part, ab, dgp, dbp, ns, HW, C);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, ab, gamma, beta, (bf16_t*)dx, HW, C, NV, R, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)dy, meanrstd, ab, gamma, beta, (bf16_t*)dx, HW, C, NV, R, silu, (const bf16_t*)dres);
   }
   HIP_TRY(hipGetLastError());
   DDMI_TRY(launch_sum_b(dgp, dgamma, B, C, s, accumulate));

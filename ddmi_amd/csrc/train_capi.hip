@@ -287,6 +287,18 @@ int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const fl
   DDMI_TRY(reserve(h, gn_backward_scratch_floats(B, HW, C) * sizeof(float), s));
   return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s, (acc >> 2) & 1);
 }
+// the same with a second gradient of x added in the last pass: dx = GroupNorm backward(dy) + dres (dres [B,HW,C] in the handle's
+// storage type, may alias nothing else; null = ddmi_train_gn_bwd).  For the block input that feeds both the norm and the block's
+// residual / skip path (ResBlock, AttentionBlock): the host passes the skip path's gradient here instead of adding the two itself.
+int ddmi_train_gn_bwd_res(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
+                          const void* dres, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream) {
+  const int acc = h ? h->acc_next : 0;
+  if (h) h->acc_next = 0;
+  DDMI_REQUIRE(h && x && gamma && beta && meanrstd && dy && dx && dgamma && dbeta, "train_gn_bwd_res: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, gn_backward_scratch_floats(B, HW, C) * sizeof(float), s));
+  return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s, (acc >> 2) & 1, dres);
+}
 
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream) {
   DDMI_REQUIRE(h && qkv && out, "train_attn_fwd: null argument");

@@ -93,6 +93,7 @@ class ToNCHW(torch.autograd.Function):
 
 
 FUSE_GRAD_ACCUMULATION = True   # False: every gradient goes back through autograd's AccumulateGrad (tests compare both)
+FUSE_RESIDUAL_GRAD = os.environ.get("DDMI_TRAIN_FUSE_RES", "1") != "0"   # the block input's two gradients summed in the GroupNorm backward
 
 
 def _grad_slot(p):
@@ -147,8 +148,12 @@ class ConvFn(torch.autograd.Function):
 
 
 class GroupNormFn(torch.autograd.Function):
+    """GroupNorm32 (+ SiLU).  `passthrough=True` also returns x itself as a second output: a block hands THAT to its residual / skip
+    path, so both gradients of the block input arrive in this backward, and the kernel's last pass writes their sum
+    (ddmi_train_gn_bwd_res) - autograd's own add of the two (38 read-read-write passes per AFHQ step) never runs."""
+
     @staticmethod
-    def forward(ctx, tc, x, gamma, beta, eps, silu):
+    def forward(ctx, tc, x, gamma, beta, eps, silu, passthrough=False):
         x = x.contiguous()
         B, H, W, Cc = x.shape
         y = torch.empty_like(x)
@@ -158,12 +163,17 @@ class GroupNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, beta, mr)
         ctx.tc, ctx.silu = tc, int(silu)
         ctx.params = (gamma, beta)
+        if passthrough:
+            ctx.set_materialize_grads(False)      # an unused pass-through arrives as None, not as a tensor of zeros
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, mr = ctx.saved_tensors
         B, H, W, Cc = x.shape
+        if dy is None:                            # only the pass-through was used
+            return None, dres, None, None, None, None, None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         gg, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
@@ -171,10 +181,15 @@ class GroupNormFn(torch.autograd.Function):
         dg, db = (None, None) if fused else (torch.empty_like(gamma), torch.empty_like(beta))
         if fused:
             _lib.check(_lib.lib().ddmi_train_accumulate_next(ctx.tc.h, 4))
-        _lib.check(_lib.lib().ddmi_train_gn_bwd(ctx.tc.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mr.data_ptr(), dy.data_ptr(),
-                                                dx.data_ptr(), (gg if fused else dg).data_ptr(), (gb if fused else db).data_ptr(), B, H * W, Cc,
-                                                ctx.silu, _stream()))
-        return None, dx, dg, db, None, None
+        if dres is not None:
+            _lib.check(_lib.lib().ddmi_train_gn_bwd_res(ctx.tc.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mr.data_ptr(), dy.data_ptr(),
+                                                        dres.contiguous().data_ptr(), dx.data_ptr(), (gg if fused else dg).data_ptr(),
+                                                        (gb if fused else db).data_ptr(), B, H * W, Cc, ctx.silu, _stream()))
+        else:
+            _lib.check(_lib.lib().ddmi_train_gn_bwd(ctx.tc.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mr.data_ptr(), dy.data_ptr(),
+                                                    dx.data_ptr(), (gg if fused else dg).data_ptr(), (gb if fused else db).data_ptr(), B, H * W, Cc,
+                                                    ctx.silu, _stream()))
+        return None, dx, dg, db, None, None, None
 
 
 class AttentionLegacyFn(torch.autograd.Function):
@@ -356,8 +371,8 @@ class _Norm(nn.Module):   # GroupNorm32(32, C)
         self.weight = nn.Parameter(torch.empty((c,)))
         self.bias = nn.Parameter(torch.empty((c,)))
 
-    def run(self, tc, x, silu):
-        return GroupNormFn.apply(tc, x, self.weight, self.bias, 1e-5, silu)
+    def run(self, tc, x, silu, passthrough=False):
+        return GroupNormFn.apply(tc, x, self.weight, self.bias, 1e-5, silu, passthrough and FUSE_RESIDUAL_GRAD)
 
 
 class _Linear(nn.Module):
@@ -385,7 +400,9 @@ class ResBlock(nn.Module):
 
     def run(self, tc, x, emb):
         """`emb` is this block's emb_layers OUTPUT [B, cout]: TrainUNetModel.forward projects all blocks at once (EmbProjFn)."""
-        h = self.in_layers[0].run(tc, x, silu=True)
+        h = self.in_layers[0].run(tc, x, silu=True, passthrough=True)
+        if isinstance(h, tuple):
+            h, x = h                                                                             # x for the skip path: see GroupNormFn
         h = self.in_layers[2].run(tc, h, emb=emb)                                                # h + emb_out[..., None, None]
         h = self.out_layers[0].run(tc, h, silu=True)
         skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection.run(tc, x)
@@ -401,7 +418,10 @@ class AttentionBlock(nn.Module):
         self.proj_out = _Conv(ch, ch, 1, dims=1)
 
     def run(self, tc, x, emb=None):
-        qkv = self.qkv.run(tc, self.norm.run(tc, x, silu=False))
+        hn = self.norm.run(tc, x, silu=False, passthrough=True)
+        if isinstance(hn, tuple):
+            hn, x = hn
+        qkv = self.qkv.run(tc, hn)
         a = AttentionLegacyFn.apply(tc, qkv, self.heads)
         return self.proj_out.run(tc, a, res=x)
 

@@ -364,6 +364,10 @@ int ddmi_train_gn_fwd(ddmi_train* h, const void* x, const float* gamma, const fl
                       int C, float eps, int silu, void* stream);
 int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
                       void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream);
+/* dx = GroupNorm backward(dy) + dres: the block input's second gradient (its residual / skip path, openaimodel.py:272-275, 321-325)
+ * added in the backward's last pass instead of by the host's tape; dres [B,HW,C] in the handle's storage type (null: as above) */
+int ddmi_train_gn_bwd_res(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
+                          const void* dres, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream);
 /* QKVAttentionLegacy openaimodel.py:397-426: qkv [B,T,heads*3*d] (per-head [q|k|v]), out [B,T,heads*d]; backward d = 32 */
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream);
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,

@@ -513,3 +513,41 @@ def test_training_upsample_conv_parity_form(B, cin, cout, hw):
     y.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16))
     assert rel_l2(xd.grad.float().permute(0, 3, 1, 2).cpu(), xr.grad) < 1e-2
     assert rel_l2(wd.grad.cpu(), wr.grad) < 1e-2 and rel_l2(bd.grad.cpu(), br.grad) < 1e-2
+
+
+@pytest.mark.parametrize("numerics", ["fp32", "bf16"])
+def test_block_input_gradients_summed_in_the_groupnorm_backward(numerics, monkeypatch):
+    """ResBlock / AttentionBlock hand their input to the skip path THROUGH the GroupNorm op (GroupNormFn passthrough), whose backward
+    adds the skip path's gradient in its last pass (ddmi_train_gn_bwd_res).  Same loss and gradients as with autograd adding the two
+    (DDMI_TRAIN_FUSE_RES=0 semantics: FUSE_RESIDUAL_GRAD False): a ResBlock with a 1x1 skip, one with the identity, an AttentionBlock."""
+    from ddmi_amd import train as T
+    tc = T.TrainContext(numerics, DEV)
+    B, hw = 2, 8
+    blocks = [T.ResBlock(64, 96, 96), T.ResBlock(96, 96, 96), T.AttentionBlock(96, 32)]
+    for i, m in enumerate(blocks):
+        for k, p in m.named_parameters():
+            p.data = torch.from_numpy(iw.normal("fuse_res%d" % i, k, tuple(p.shape), 0.0, 0.05) + (1.0 if k.endswith("0.weight") and p.dim() == 1 else 0.0)).float()
+        m.to(DEV)
+    x0 = torch.from_numpy(iw.normal("fuse_res", "x", (B, hw, hw, 64))).to(DEV, tc.dtype)
+    embs = [torch.from_numpy(iw.normal("fuse_res", "e%d" % i, (B, 96), 0.0, 0.3)).to(DEV) for i in range(2)]
+    dy = torch.from_numpy(iw.normal("fuse_res", "dy", (B, hw, hw, 96))).to(DEV, tc.dtype)
+
+    def run(fused):
+        monkeypatch.setattr(T, "FUSE_RESIDUAL_GRAD", fused)
+        for m in blocks:
+            m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        h = blocks[0].run(tc, x * 1.0, embs[0])      # (x * 1.0: the block input is a non-leaf, as inside the UNet)
+        h = blocks[1].run(tc, h, embs[1])
+        h = blocks[2].run(tc, h)
+        h.backward(dy)
+        return h.detach().float().cpu(), x.grad.float().cpu(), {f"{i}.{k}": p.grad.float().cpu() for i, m in enumerate(blocks) for k, p in m.named_parameters() if p.grad is not None}   # (emb_layers run outside the block)
+
+    y1, gx1, gp1 = run(True)
+    y0, gx0, gp0 = run(False)
+    assert torch.equal(y1, y0)
+    tol = 2e-6 if numerics == "fp32" else 1e-2      # bf16: the fused sum is rounded once, autograd's twice
+    assert rel_l2(gx1, gx0) < tol
+    assert len(gp0) >= 14 and set(gp0) == set(gp1)
+    for k in gp0:
+        assert rel_l2(gp1[k], gp0[k]) < tol, k
