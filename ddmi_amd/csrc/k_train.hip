@@ -501,6 +501,29 @@ __global__ void wgrad_tn_finish_kernel(const float* __restrict__ slab, float* __
     dw[i] = accumulate ? dw[i] + acc : acc;
   }
 }
+// 16-byte form, four slices in flight per thread; the slices are still added in slice order (bit-identical to the scalar kernel)
+__global__ void __launch_bounds__(256) wgrad_tn_finish_vec4_kernel(const float4* __restrict__ slab, float4* __restrict__ dw, int64_t n4, int S,
+                                                                   int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= S; z += 4) {
+      const float4 a = slab[(int64_t)z * n4 + i], b = slab[(int64_t)(z + 1) * n4 + i], c = slab[(int64_t)(z + 2) * n4 + i],
+                   d = slab[(int64_t)(z + 3) * n4 + i];
+      acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x; acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
+      acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z; acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; z < S; ++z) {
+      const float4 a = slab[(int64_t)z * n4 + i];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    if (accumulate) {
+      const float4 o = dw[i];
+      acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
+    }
+    dw[i] = acc;
+  }
+}
 
 // H, W: the grid the convolution ran on (= dY's; with `ups` the input x is [H/2][W/2])
 bool wgrad_tn_ok(int dt, int B, int H, int W, int Ci, int Co, int k, int stride, int ups) {
@@ -553,7 +576,10 @@ int launch_wgrad_tn(const void* dy, const void* x, float* dw, float* slab, int B
     hipLaunchKernelGGL(wgrad_tn1_kernel, g, dim3(512), 2 * WG1_STAGE, s, a);
   }
   const int64_t n = (int64_t)Co * Ci * kk;
-  hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S, accumulate);
+  if (n % 4 == 0 && (((uintptr_t)slab | (uintptr_t)dw) & 15) == 0)
+    hipLaunchKernelGGL(wgrad_tn_finish_vec4_kernel, dim3(tr_blocks(n / 4)), dim3(256), 0, s, (const float4*)slab, (float4*)dw, n / 4, a.S, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_tn_finish_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, slab, dw, n, a.S, accumulate);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -1437,17 +1463,38 @@ int launch_eps_loss(const float* model_out, const float* x_t, const float* noise
 }
 
 // torch.optim.AdamW (decoupled weight decay, bias-corrected moments), one pass over a flat fp32 parameter slab
+// one AdamW element (torch.optim.AdamW, decoupled weight decay; the same expression order in both kernels below)
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                          float bc2_sqrt, float gscale) {
+  const float gi = g * gscale;
+  float pi = p * (1.0f - lr * wd);
+  const float mi = b1 * m + (1.0f - b1) * gi;
+  const float vi = b2 * v + (1.0f - b2) * gi * gi;
+  m = mi; v = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p = pi;
+}
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i] * gscale;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi -= (lr / bc1) * (mi / denom);
-    p[i] = pi;
+    float pi = p[i], mi = m[i], vi = v[i];
+    adamw_one(pi, g[i], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+// 16-byte form (n4 = n / 4 vectors; 7 x 16 bytes of traffic per vector: the step is a pure stream of 28 bytes per parameter)
+__global__ void __launch_bounds__(256) adamw_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                         float4* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps, float wd,
+                                                         float bc1, float bc2_sqrt, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pi = p[i], mi = m[i], vi = v[i];
+    const float4 gi = g[i];
+    adamw_one(pi.x, gi.x, mi.x, vi.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adamw_one(pi.y, gi.y, mi.y, vi.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adamw_one(pi.z, gi.z, mi.z, vi.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adamw_one(pi.w, gi.w, mi.w, vi.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
@@ -1455,7 +1502,13 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
   DDMI_REQUIRE(step >= 1, "adamw: step counts from 1");
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
   PROF_SCOPE("adamw", 0, 28.0 * n, s);
-  hipLaunchKernelGGL(adamw_kernel, dim3(tr_blocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), grad_scale);
+  const int64_t n4 = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 ? n / 4 : 0;   // 16-byte body, scalar tail
+  if (n4 > 0)
+    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(tr_blocks(n4)), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, n4, lr, b1, b2,
+                       eps, wd, bc1, sqrtf(bc2), grad_scale);
+  if (n - 4 * n4 > 0)
+    hipLaunchKernelGGL(adamw_kernel, dim3(tr_blocks(n - 4 * n4)), dim3(256), 0, s, p + 4 * n4, g + 4 * n4, m + 4 * n4, v + 4 * n4, n - 4 * n4, lr, b1,
+                       b2, eps, wd, bc1, sqrtf(bc2), grad_scale);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
