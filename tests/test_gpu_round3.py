@@ -551,3 +551,24 @@ def test_block_input_gradients_summed_in_the_groupnorm_backward(numerics, monkey
     assert len(gp0) >= 14 and set(gp0) == set(gp1)
     for k in gp0:
         assert rel_l2(gp1[k], gp0[k]) < tol, k
+
+
+def test_attention_lse_entry_points_refuse_what_they_do_not_serve():
+    """ddmi_train_attn_fwd_lse / _bwd_lse exist for bf16 handles, head dim 32, token counts that are multiples of 64; everything else is
+    refused with DDMI_ERR_INVALID and a message (the plain pair serves it) - no silent fallback inside the library."""
+    from ddmi_amd import train as T
+    L = _lib.lib()
+    tc16, tc32 = T.TrainContext("bf16", DEV), T.TrainContext("fp32", DEV)
+    assert L.ddmi_train_attn_lse_ok(tc16.h, 256, 32) == 1
+    assert L.ddmi_train_attn_lse_ok(tc16.h, 100, 32) == 0 and L.ddmi_train_attn_lse_ok(tc16.h, 256, 64) == 0
+    assert L.ddmi_train_attn_lse_ok(tc32.h, 256, 32) == 0
+    B, heads, tok, d = 1, 2, 100, 32
+    qkv = torch.zeros((B, tok, heads * 3 * d), dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros((B, tok, heads * d), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros((B, heads, tok), dtype=torch.float32, device=DEV)
+    rc = L.ddmi_train_attn_fwd_lse(tc16.h, qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, tok, heads, d, None)
+    assert rc != 0 and b"multiple of 64" in L.ddmi_last_error()
+    rc = L.ddmi_train_attn_bwd_lse(tc16.h, qkv.data_ptr(), out.data_ptr(), out.data_ptr(), lse.data_ptr(), qkv.data_ptr(), B, tok, heads, d, None)
+    assert rc != 0
+    rc = L.ddmi_train_attn_fwd_lse(tc16.h, qkv.data_ptr(), out.data_ptr(), None, B, 128, heads, d, None)
+    assert rc != 0 and b"null" in L.ddmi_last_error()
