@@ -741,8 +741,11 @@ int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s, int a
 // pass 1, grid (32, B): a thread owns ONE channel of the group for a fixed set of pixels -> per-channel and per-group sums
 // reduced through LDS in a fixed order (no atomics: deterministic)
 // ---------------------------------------------------------------------------------------------------------------------
+// FAST (bf16 storage): v_exp_f32 + v_rcp_f32 as in the forward (k_groupnorm.hip) - the precise expf and division were ~60 VALU
+// instructions per element and held the GroupNorm backward's statistics pass at 2.9 TB/s; the fp32 parity mode keeps them
+template <bool FAST = false>
 __device__ __forceinline__ float tr_dsilu(float z) {
-  const float sg = 1.0f / (1.0f + expf(-z));
+  const float sg = FAST ? __frcp_rn(1.0f + __expf(-z)) : 1.0f / (1.0f + expf(-z));
   return sg * (1.0f + z * (1.0f - sg));
 }
 
@@ -793,7 +796,7 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restri
       ga[i] = gamma[c]; be[i] = beta[c];
       s0[i] = s1[i] = s2[i] = s3[i] = 0.f;
     }
-    for (int p = p0 + r; p < p1; p += R) {
+    for (int p = p0 + r; p < p1; p += R) {   // (two pixels per trip - four loads in flight - measured SLOWER: 63 -> 80 us average)
       const int64_t o = ((int64_t)b * HW + p) * C + v * VN;
       float xv[VN], gv[VN];
       TrVec<T>::load(x + o, xv);
@@ -802,7 +805,7 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restri
       for (int i = 0; i < VN; ++i) {
         const float xh = (xv[i] - mean[i]) * rstd[i];
         float dz = gv[i];
-        if (silu) dz *= tr_dsilu(ga[i] * xh + be[i]);
+        if (silu) dz *= tr_dsilu<sizeof(T) == 2>(ga[i] * xh + be[i]);
         const float dxh = dz * ga[i];
         s0[i] += dz * xh; s1[i] += dz; s2[i] += dxh; s3[i] += dxh * xh;
       }
@@ -886,7 +889,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     for (int i = 0; i < VN; ++i) {
       const float xh = (xv[i] - mean[i]) * rstd[i];
       float dz = gv[i];
-      if (silu) dz *= tr_dsilu(ga[i] * xh + be[i]);
+      if (silu) dz *= tr_dsilu<sizeof(T) == 2>(ga[i] * xh + be[i]);
       ov[i] = rstd[i] * (dz * ga[i] - mA[i] - xh * mB[i]);
     }
     if (dres != nullptr) {
