@@ -147,6 +147,8 @@ SYMBOLS = {
     "ddmi_train_gn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _VP]),
     "ddmi_train_gn_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_gn_bwd_res": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_cat2": (_I, [_VP, _VP, _VP, _VP, C.c_int64, _I, _I, _VP]),
+    "ddmi_train_split2": (_I, [_VP, _VP, _VP, _VP, C.c_int64, _I, _I, _VP]),
     "ddmi_train_attn_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_attn_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_attn_lse_ok": (_I, [_VP, _I, _I]),

@@ -672,6 +672,30 @@ int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, in
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
+// channel concatenation of two NHWC tensors (the UNet decoder's th.cat([h, hs.pop()], dim=1), openaimodel.py:739) and its inverse, in
+// 16-byte vectors: row r of out = [a row r (va vectors) | b row r (vb vectors)].  SPLIT copies the other way (out -> a, b).
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) cat2_kernel(uint4* __restrict__ a, uint4* __restrict__ b, uint4* __restrict__ out, int64_t rows, int va, int vb) {
+  const int vt = va + vb;
+  const int64_t n = rows * vt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / vt;
+    const int c = (int)(i - r * vt);
+    uint4* side = c < va ? a + r * va + c : b + r * vb + (c - va);
+    if (SPLIT) *side = out[i];
+    else out[i] = *side;
+  }
+}
+int launch_cat2(const void* a, const void* b, void* out, int dt, int64_t rows, int Ca, int Cb, hipStream_t s, int split) {
+  const int vn = 16 / (int)dt_size(dt);
+  DDMI_REQUIRE(Ca > 0 && Cb > 0 && Ca % vn == 0 && Cb % vn == 0, "cat2: channel counts must be multiples of the 16-byte vector");
+  const int64_t n = rows * ((Ca + Cb) / vn);
+  PROF_SCOPE("cat2", 0, 2.0 * n * 16, s);
+  if (split) hipLaunchKernelGGL(cat2_kernel<true>, dim3(tr_blocks(n)), dim3(256), 0, s, (uint4*)a, (uint4*)b, (uint4*)out, rows, Ca / vn, Cb / vn);
+  else hipLaunchKernelGGL(cat2_kernel<false>, dim3(tr_blocks(n)), dim3(256), 0, s, (uint4*)a, (uint4*)b, (uint4*)out, rows, Ca / vn, Cb / vn);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
 int launch_zero_insert2x(const void* dy, void* u, int dt, int B, int Ho, int Wo, int C, hipStream_t s) {
   const int64_t n = (int64_t)B * 4 * Ho * Wo * C;
   PROF_SCOPE("dgrad_layout", 0, 1.25 * n * dt_size(dt), s);

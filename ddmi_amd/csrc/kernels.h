@@ -228,6 +228,7 @@ size_t gn_backward_scratch_floats(int B, int HW, int C);
 int launch_gn_backward(const void* x, const void* dy, const float* meanrstd, const float* gamma, const float* beta, void* dx,
                        float* dgamma, float* dbeta, float* scratch, int dt, int B, int HW, int C, int silu, hipStream_t s, int accumulate = 0,
                        const void* dres = nullptr);
+int launch_cat2(const void* a, const void* b, void* out, int dt, int64_t rows, int Ca, int Cb, hipStream_t s, int split);
 int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch, int dt, int B,
                                      int T, int heads, int d, hipStream_t s);
 int launch_linear_small_backward(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int B, int K, int N,

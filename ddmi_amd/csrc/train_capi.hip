@@ -300,6 +300,16 @@ int ddmi_train_gn_bwd_res(ddmi_train* h, const void* x, const float* gamma, cons
   return launch_gn_backward(x, dy, meanrstd, gamma, beta, dx, dgamma, dbeta, (float*)h->ws, h->dt, B, HW, C, silu, s, (acc >> 2) & 1, dres);
 }
 
+// out [rows, Ca + Cb] = [a | b] along the channel axis of NHWC rows (rows = B*H*W); ddmi_train_split2 is the inverse (the gradient of the
+// concatenation): a, b <- the two column blocks of `in`.  Storage type of the handle; Ca, Cb multiples of the 16-byte vector.
+int ddmi_train_cat2(ddmi_train* h, const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, void* stream) {
+  DDMI_REQUIRE(h && a && b && out && rows > 0, "train_cat2: bad arguments");
+  return launch_cat2(a, b, out, h->dt, rows, Ca, Cb, (hipStream_t)stream, 0);
+}
+int ddmi_train_split2(ddmi_train* h, const void* in, void* a, void* b, int64_t rows, int Ca, int Cb, void* stream) {
+  DDMI_REQUIRE(h && a && b && in && rows > 0, "train_split2: bad arguments");
+  return launch_cat2(a, b, const_cast<void*>(in), h->dt, rows, Ca, Cb, (hipStream_t)stream, 1);
+}
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream) {
   DDMI_REQUIRE(h && qkv && out, "train_attn_fwd: null argument");
   return launch_attention_legacy(qkv, out, h->dt, B, T, heads, d, (hipStream_t)stream);

@@ -192,6 +192,30 @@ class GroupNormFn(torch.autograd.Function):
         return None, dx, dg, db, None, None, None
 
 
+class CatFn(torch.autograd.Function):
+    """th.cat([a, b], dim=1) of the decoder (openaimodel.py:739) on NHWC tensors: one 16-byte-vector copy kernel each way
+    (torch's channel-last concatenation and the two strided slice copies of its backward ran at half the bandwidth)."""
+
+    @staticmethod
+    def forward(ctx, tc, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        out = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=a.dtype, device=a.device)
+        rows = a.numel() // Ca
+        _lib.check(_lib.lib().ddmi_train_cat2(tc.h, a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, Ca, Cb, _stream()))
+        ctx.tc, ctx.meta = tc, (tuple(a.shape), tuple(b.shape), rows, Ca, Cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sa, sb, rows, Ca, Cb = ctx.meta
+        dout = dout.contiguous()
+        da = torch.empty(sa, dtype=dout.dtype, device=dout.device)
+        db = torch.empty(sb, dtype=dout.dtype, device=dout.device)
+        _lib.check(_lib.lib().ddmi_train_split2(ctx.tc.h, dout.data_ptr(), da.data_ptr(), db.data_ptr(), rows, Ca, Cb, _stream()))
+        return None, da, db
+
+
 class AttentionLegacyFn(torch.autograd.Function):
     """QKVAttentionLegacy on qkv [B,H,W,heads*3*d] -> [B,H,W,heads*d]."""
 
@@ -540,7 +564,9 @@ class TrainUNetModel(nn.Module):
             hs.append(h)
         h = self._run_block(tc, self.middle_block, h, embs)
         for block in self.output_blocks:
-            h = torch.cat([h, hs.pop()], dim=-1)        # th.cat([h, hs.pop()], dim=1) in NHWC
+            skip = hs.pop()                              # th.cat([h, hs.pop()], dim=1) in NHWC
+            vec = 16 // h.element_size()
+            h = CatFn.apply(tc, h, skip) if h.shape[-1] % vec == 0 and skip.shape[-1] % vec == 0 else torch.cat([h, skip], dim=-1)
             h = self._run_block(tc, block, h, embs)
         h = self.out[2].run(tc, self.out[0].run(tc, h, silu=True))
         return ToNCHW.apply(tc, h)

@@ -368,6 +368,10 @@ int ddmi_train_gn_bwd(ddmi_train* h, const void* x, const float* gamma, const fl
  * added in the backward's last pass instead of by the host's tape; dres [B,HW,C] in the handle's storage type (null: as above) */
 int ddmi_train_gn_bwd_res(ddmi_train* h, const void* x, const float* gamma, const float* beta, const float* meanrstd, const void* dy,
                           const void* dres, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int silu, void* stream);
+/* th.cat([h, hs.pop()], dim=1) of the decoder (openaimodel.py:739) on NHWC rows, and its gradient: out [rows, Ca+Cb] = [a | b];
+ * split2 copies the two column blocks of `in` back to a and b.  rows = B*H*W; Ca, Cb multiples of the 16-byte vector. */
+int ddmi_train_cat2(ddmi_train* h, const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, void* stream);
+int ddmi_train_split2(ddmi_train* h, const void* in, void* a, void* b, int64_t rows, int Ca, int Cb, void* stream);
 /* QKVAttentionLegacy openaimodel.py:397-426: qkv [B,T,heads*3*d] (per-head [q|k|v]), out [B,T,heads*d]; backward d = 32 */
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream);
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,

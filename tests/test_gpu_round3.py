@@ -572,3 +572,20 @@ def test_attention_lse_entry_points_refuse_what_they_do_not_serve():
     assert rc != 0
     rc = L.ddmi_train_attn_fwd_lse(tc16.h, qkv.data_ptr(), out.data_ptr(), None, B, 128, heads, d, None)
     assert rc != 0 and b"null" in L.ddmi_last_error()
+
+
+@pytest.mark.parametrize("numerics", ["fp32", "bf16"])
+def test_decoder_concat_op_and_its_gradient(numerics):
+    """CatFn (ddmi_train_cat2 / ddmi_train_split2): the decoder's channel concatenation on NHWC tensors and its gradient are exact
+    copies - equal to torch.cat and to slicing, bit for bit, with unequal channel counts and a row count that is not a block multiple."""
+    from ddmi_amd import train as T
+    tc = T.TrainContext(numerics, DEV)
+    a = torch.from_numpy(iw.normal("cat2", "a", (3, 5, 7, 224))).to(DEV, tc.dtype).requires_grad_(True)
+    b = torch.from_numpy(iw.normal("cat2", "b", (3, 5, 7, 448))).to(DEV, tc.dtype).requires_grad_(True)
+    out = T.CatFn.apply(tc, a, b)
+    assert torch.equal(out, torch.cat([a, b], dim=-1))
+    g = torch.from_numpy(iw.normal("cat2", "g", (3, 5, 7, 672))).to(DEV, tc.dtype)
+    out.backward(g)
+    assert torch.equal(a.grad, g[..., :224]) and torch.equal(b.grad, g[..., 224:])
+    rc = _lib.lib().ddmi_train_cat2(tc.h, a.data_ptr(), b.data_ptr(), out.data_ptr(), 105, 223, 448, None)
+    assert rc != 0 and b"16-byte" in _lib.lib().ddmi_last_error()

@@ -41,7 +41,7 @@ for st in "$@"; do
     upbench)   timeout 600 python tools/bench_conv.py --batch 512 --only "up @" --cfgs 13,11,19,20 > $log 2>&1 ;;
     uptest)    timeout 900 python -m pytest tests/test_gpu_ops.py -q -k "upsample_parity_form" > $log 2>&1 ;;
     benchtrainL) DDMI_ATTN_BWD_LEGACY=1 timeout 1200 python bench.py --workload train --steps 2 --warmup 1 > gpurun_out/${tag}_bench_trainL.json 2> $log ;;
-    attnbwd)   timeout 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_train.py -q -k "attention or upsample_conv or block_input or lse" > $log 2>&1 ;;
+    attnbwd)   timeout 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_train.py -q -k "attention or upsample_conv or block_input or lse or concat" > $log 2>&1 ;;
     attnbench) timeout 300 python tools/bench_attn_mh.py 128 > $log 2>&1 ;;
     *) echo "unknown stage $st" ;;
   esac
