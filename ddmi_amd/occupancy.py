@@ -342,8 +342,12 @@ class Generator3D:
     def generate_mesh_fromdiffusion(self, latent, vaemodel, mlp, device=None):
         """-> (mesh, mesh2): mesh = TriMesh(vertices float64 [nv,3], faces int64 [nf,3]) on the host, mesh2 = the
         device-resident pair pytorch3d's Meshes is built from (verts float32 [1,nv,3], faces int64 [1,nf,3])."""
+        return self.generate_mesh_fromplanes(vaemodel.decode(latent), mlp)
+
+    def generate_mesh_fromplanes(self, planes, mlp):
+        """The same from already decoded planes of ONE latent ((xy, yz, xz) lists of [1, C, H, W] tensors): the decoder may have run on
+        a batch of latents (OccupancyPipeline.decode_batch)."""
         from .mcubes import extract_mesh
-        planes = vaemodel.decode(latent)
         grid = occupancy_grid_logits(mlp, planes, self.resolution0, self.padding)
         assert grid.shape[0] == 1, "the reference extracts one mesh per call (tools/ldm/occupancy.py:216-217)"
         v, f = extract_mesh(grid[0], self.threshold, self.padding)

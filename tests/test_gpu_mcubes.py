@@ -151,3 +151,12 @@ def test_occupancy_pipeline_is_batch_invariant(golden):
     assert same(alone.vertices, meshes[2].vertices) and same(alone.faces, meshes[2].faces)
     other = pipe.generate([8], base_seed=11)[0]
     assert not (same(other.vertices, meshes[2].vertices) and same(other.faces, meshes[2].faces))
+    # the tri-plane decoder on all three latents at once (decode_batch; the bf16 default is 32), meshes still one latent at a time:
+    # the same meshes as with the reference's decode batch of 1 (the parity mode's default)
+    assert pipe.decode_batch == 1
+    pipe3 = OccupancyPipeline(ucfg, cfgs["TOY_DD3"], cfgs["MLP3D_CFG"], dcfg, cfgs["TOY_EMBED3"], threshold=0.5, resolution0=32,
+                              upsampling_steps=0, padding=0.1, numerics="fp32", max_batch=3, device=DEV, decode_batch=3)
+    pipe3.load_named_seed("toyocc").finalize()
+    batched = pipe3.generate([5, 6, 7], base_seed=11)
+    for m, ref in zip(batched, meshes):
+        assert same(m.vertices, ref.vertices) and same(m.faces, ref.faces)
