@@ -347,8 +347,11 @@ class Generator3D:
     def generate_mesh_fromplanes(self, planes, mlp):
         """The same from already decoded planes of ONE latent ((xy, yz, xz) lists of [1, C, H, W] tensors): the decoder may have run on
         a batch of latents (OccupancyPipeline.decode_batch)."""
+        return self.mesh_from_grid(occupancy_grid_logits(mlp, planes, self.resolution0, self.padding))
+
+    def mesh_from_grid(self, grid):
+        """Marching cubes on the dense logit grid [1, n, n, n] of ONE latent (generation.py:146-183), on the current stream."""
         from .mcubes import extract_mesh
-        grid = occupancy_grid_logits(mlp, planes, self.resolution0, self.padding)
         assert grid.shape[0] == 1, "the reference extracts one mesh per call (tools/ldm/occupancy.py:216-217)"
         v, f = extract_mesh(grid[0], self.threshold, self.padding)
         mesh2 = {"verts": v.float().unsqueeze(0), "faces": f.unsqueeze(0)}

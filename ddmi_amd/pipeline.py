@@ -290,9 +290,31 @@ class OccupancyPipeline:
             seeds = torch.tensor([sample_seed(base_seed, i) for i in indices], dtype=torch.int64, device=dev)
             z = self.ddpm.sample([B, *self.latent_shape], seeds=seeds, device=dev)
         meshes = []
+        # One latent at a time, software-pipelined over two streams: the marching cubes of shape j (small kernels, two host
+        # round-trips: the triangle count, then the mesh itself) run on a side stream under the 3 ms MLP3D launch of shape j + 1.
+        from .occupancy import occupancy_grid_logits
+        main, side = torch.cuda.current_stream(dev), (torch.cuda.Stream(dev) if self.decode_batch > 1 else None)
+        pending = None
+
+        def finish(p):
+            grid, ready = p
+            if side is None:
+                return self.mesh_gen.mesh_from_grid(grid)[0]
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                grid.record_stream(side)
+                return self.mesh_gen.mesh_from_grid(grid)[0]
+
         for j0 in range(0, B, self.decode_batch):
             planes = self.vae.decode(z[j0:j0 + self.decode_batch].contiguous())
             for j in range(planes[0][0].shape[0]):
                 one = tuple([t[j:j + 1] for t in lst] for lst in planes)      # (a batch slice of an NHWC tensor is an NHWC tensor)
-                meshes.append(self.mesh_gen.generate_mesh_fromplanes(one, self.mlp)[0])
+                grid = occupancy_grid_logits(self.mlp, one, self.mesh_gen.resolution0, self.mesh_gen.padding)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                if pending is not None:
+                    meshes.append(finish(pending))
+                pending = (grid, ready)
+        if pending is not None:
+            meshes.append(finish(pending))
         return (meshes, z) if return_latent else meshes
