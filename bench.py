@@ -480,7 +480,7 @@ def run_sky(args, rank, local_rank, world, dev):
     from ddmi_amd import dist as D
     from ddmi_amd.config import load_ldm_args
     from ddmi_amd.pipeline import VideoPipeline
-    B = args.batch or 128   # 4.1 clips/s at 16, 7.0 at 64, 7.8 at 128, 8.2 at 256
+    B = args.batch or 256   # 4.1 clips/s at 16, 7.0 at 64, 7.8 at 128, 8.2 at 256 (round 2); 8.83 at 128, 9.27 at 256 (round 3)
     a = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "skytimelapse.yaml"))
     ddpmconfig = dict(a.ddpmconfig, timesteps=args.nfe, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0)
     pipe = VideoPipeline(a.unetconfig, a.ddconfig, a.mlpconfig, ddpmconfig, a.embed_dim, frames=int(a.data_config.get("frames", 16)),
@@ -627,7 +627,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
-    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 1024, sky 128, train 128)")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 1024, sky 256, train 128)")
     ap.add_argument("--no-graph", action="store_true", help="train workload: eager launches instead of the hipGraph replay")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
