@@ -383,6 +383,8 @@ def run_shapenet(args, rank, local_rank, world, dev):
     pipe = OccupancyPipeline(a.unetconfig, a.ddconfig, a.mlpconfig, ddpmconfig, a.embed_dim, threshold=0.2, resolution0=128,
                              numerics="bf16", max_batch=B, device=dev)
     pipe.load_named_seed("shapenet")
+    if os.environ.get("DDMI_BENCH_GRAPH") == "1":   # diagnostics: the UNet forward as a hipGraph replay
+        pipe.unet.set_graph(True)
     D.finalize_with_shared_plans(pipe.finalize, rank, world)
     stats = {}
 
@@ -489,6 +491,8 @@ def run_sky(args, rank, local_rank, world, dev):
     # buffers are per sample, so the batch only fattens the small launches around them)
     pipe.vae.max_batch = int(os.environ.get("DDMI_SKY_DECODE_BATCH", "4"))
     pipe.load_named_seed("sky")
+    if os.environ.get("DDMI_BENCH_GRAPH") == "1":   # diagnostics: the UNet forward as a hipGraph replay
+        pipe.unet.set_graph(True)
     D.finalize_with_shared_plans(pipe.finalize, rank, world)
 
     def one_step(step_idx):
