@@ -127,6 +127,9 @@ SYMBOLS = {
     "ddmi_op_conv2d_skip": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_debug_conv_config": (_I, [_I]),
+    "ddmi_op_attention_block": (_I, [_VP] * 8 + [_I] * 6 + [C.POINTER(_I)]),
+    "ddmi_debug_attn_fused": (_I, [_I]),
+    "ddmi_bench_attention_block": (_I, [_I] * 5 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_op_attention_legacy_hd": (_I, [_VP, _VP, _I, _I, _I, _I, _I]),
     "ddmi_op_attention_mh": (_I, [_VP, _VP, _VP, _VP] + [_I] * 7),
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),

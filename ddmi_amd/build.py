@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libddmi_hip.so")
-SOURCES = ["k_elementwise.hip", "k_groupnorm.hip", "k_conv.hip", "k_attention.hip", "k_mlp2d.hip", "k_mlp3d.hip", "mlp3d_host.hip", "k_mlpv.hip", "mlpv_host.hip", "k_mcubes.hip", "models_video.hip", "net.hip",
+SOURCES = ["k_elementwise.hip", "k_groupnorm.hip", "k_conv.hip", "k_attention.hip", "k_attnblock.hip", "k_mlp2d.hip", "k_mlp3d.hip", "mlp3d_host.hip", "k_mlpv.hip", "mlpv_host.hip", "k_mcubes.hip", "models_video.hip", "net.hip",
            "models.hip", "mlp2d_host.hip", "capi.hip", "prof.hip", "k_train.hip", "k_attn_bwd.hip", "train_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
@@ -40,7 +40,7 @@ def _newest_header() -> float:
 # is an anti-lever beside MFMAs (MI355X_MICROARCH.md, per-instruction cycle constants): measured on one box, attention backward
 # dQ 289 -> 266 us, dK/dV 380 -> 360, the eager-maximum forward 270 -> 261; the lazy forward has none in its hot path (unchanged)
 _ATTN_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]
-EXTRA_FLAGS = {"k_attention.hip": _ATTN_FLAGS, "k_attn_bwd.hip": _ATTN_FLAGS}
+EXTRA_FLAGS = {"k_attention.hip": _ATTN_FLAGS, "k_attn_bwd.hip": _ATTN_FLAGS, "k_attnblock.hip": _ATTN_FLAGS}
 
 
 def _compile(src: str, force: bool, hdr_mtime: float) -> str:

@@ -624,6 +624,155 @@ int ddmi_debug_conv_config(int cfg_id) {
   return DDMI_OK;
 }
 
+int ddmi_debug_attn_fused(int mode) {
+  attnblock_fused_override(mode);
+  return DDMI_OK;
+}
+
+// one AttentionBlock (openaimodel.py:279-325) as the UNet builds it: NCHW in -> GroupNorm -> qkv -> attention -> proj_out + x -> NCHW
+static int build_attention_block_net(UNet& u, const float* gamma, const float* beta, const float* wqkv, const float* bqkv,
+                                     const float* wproj, const float* bproj, int C, int H, int W) {
+  Net& n = u.net;
+  const int64_t s1[1] = {C}, s3[1] = {3 * C}, sq[3] = {3 * C, C, 1}, sp[3] = {C, C, 1};
+  DDMI_TRY(n.add_host("blk.norm.weight", gamma, s1, 1));
+  DDMI_TRY(n.add_host("blk.norm.bias", beta, s1, 1));
+  DDMI_TRY(n.add_host("blk.qkv.weight", wqkv, sq, 3));
+  DDMI_TRY(n.add_host("blk.qkv.bias", bqkv, s3, 1));
+  DDMI_TRY(n.add_host("blk.proj_out.weight", wproj, sp, 3));
+  DDMI_TRY(n.add_host("blk.proj_out.bias", bproj, s1, 1));
+  Op in;
+  in.kind = OP_NCHW_IN;
+  in.ext = 0;
+  in.out = n.new_tensor(C, H, W);
+  n.ops.push_back(in);
+  AttnW w;
+  DDMI_TRY(make_unet_attnblock(u, "blk.", C, &w, H * W));
+  int y = -1;
+  DDMI_TRY(emit_attn_single(n, w, in.out, &y));
+  Op ex;
+  ex.kind = OP_EXPORT;
+  ex.in = y;
+  ex.ext = 1;
+  ex.out_nchw = 1;
+  n.ops.push_back(ex);
+  return n.plan();
+}
+
+int ddmi_op_attention_block(const float* x, const float* gamma, const float* beta, const float* wqkv, const float* bqkv,
+                            const float* wproj, const float* bproj, float* y, int B, int C, int H, int W, int head_channels,
+                            int numerics, int* fused_used) {
+  DDMI_REQUIRE(x && gamma && beta && wqkv && bqkv && wproj && bproj && y && B > 0 && C > 0 && H > 0 && W > 0 && head_channels > 0,
+               "op_attention_block: bad arguments");
+  UNet u;
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(numerics, &u.net.dt, &x3));
+  u.net.x3 = x3;
+  u.net.max_batch = B;
+  u.cfg.num_head_channels = head_channels;
+  DDMI_TRY(build_attention_block_net(u, gamma, beta, wqkv, bqkv, wproj, bproj, C, H, W));
+  if (fused_used) {
+    *fused_used = 0;
+    for (const Op& o : u.net.ops) *fused_used |= o.kind == OP_ATTN_BLOCK;
+  }
+  void* ext[2] = {(void*)x, (void*)y};
+  DDMI_TRY(u.net.run(B, ext, nullptr, 0, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
+// average device time of one AttentionBlock (random weights and input) as the network runs it; `fused_used` reports the form
+int ddmi_bench_attention_block(int B, int C, int H, int W, int iters, double* us_out, int* fused_used) {
+  DDMI_REQUIRE(us_out && iters > 0 && B > 0 && C % 32 == 0, "bench_attention_block: bad arguments");
+  UNet u;
+  u.net.dt = DT_BF16;
+  u.net.max_batch = B;
+  u.cfg.num_head_channels = 32;
+  std::vector<float> gamma(C), beta(C), wqkv((size_t)3 * C * C), bqkv(3 * C), wproj((size_t)C * C), bproj(C);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    return (float)((st >> 40) & 0xFFFF) / 32768.0f - 1.0f;
+  };
+  const float ws = 1.0f / std::sqrt((float)C);
+  for (auto& v : gamma) v = 1.0f + 0.1f * rnd();
+  for (auto& v : beta) v = 0.1f * rnd();
+  for (auto& v : wqkv) v = 1.7f * ws * rnd();
+  for (auto& v : bqkv) v = 0.1f * rnd();
+  for (auto& v : wproj) v = 1.7f * ws * rnd();
+  for (auto& v : bproj) v = 0.1f * rnd();
+  DDMI_TRY(build_attention_block_net(u, gamma.data(), beta.data(), wqkv.data(), bqkv.data(), wproj.data(), bproj.data(), C, H, W));
+  if (fused_used) {
+    *fused_used = 0;
+    for (const Op& o : u.net.ops) *fused_used |= o.kind == OP_ATTN_BLOCK;
+  }
+  Scratch sc;
+  void *xin, *yout;
+  const size_t nb = (size_t)B * C * H * W * sizeof(float);
+  DDMI_TRY(sc.get(nb, &xin));
+  DDMI_TRY(sc.get(nb, &yout));
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(1024), dim3(256), 0, 0, (unsigned*)xin, (int64_t)(nb / 4), 7u, false);
+  void* ext[2] = {xin, yout};
+  // the block's own ops only: the NCHW seam launches (first / last op) are timed separately and subtracted
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  int rc = DDMI_OK;
+  for (int i = 0; i < 2 && rc == DDMI_OK; ++i) rc = u.net.run(B, ext, nullptr, 0, 0);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < iters && rc == DDMI_OK; ++i) rc = u.net.run(B, ext, nullptr, 0, 0);
+  (void)hipEventRecord(e1, 0);
+  hipError_t e = hipDeviceSynchronize();
+  float ms = 0.f, ms_seam = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const TensorDesc& t0 = u.net.tensors[u.net.ops.front().out];
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < iters && rc == DDMI_OK; ++i) {
+    rc = launch_nchw_to_nhwc((const float*)xin, u.net.tptr(u.net.ops.front().out), DT_BF16, B, t0.C, t0.H * t0.W, 0);
+    if (rc == DDMI_OK) rc = launch_nhwc_to_nchw(u.net.tptr(u.net.ops.back().in), DT_BF16, (float*)yout, B, t0.C, t0.H * t0.W, 0);
+  }
+  (void)hipEventRecord(e1, 0);
+  hipError_t e2 = hipDeviceSynchronize();
+  (void)hipEventElapsedTime(&ms_seam, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != DDMI_OK) return rc;
+  if (e != hipSuccess || e2 != hipSuccess) return ddmi_fail(DDMI_ERR_HIP, "bench_attention_block: device error");
+  prof_begin_forward();   // one more run under the per-launch scopes when the caller enabled them (ddmi_profile_enable)
+  if (prof_active()) {
+    rc = u.net.run(B, ext, nullptr, 0, 0);
+    prof_enable(0);
+    if (rc != DDMI_OK) return rc;
+  }
+  if (getenv("DDMI_ATTNBLOCK_TS") && fused_used && *fused_used) {   // per-workgroup phase timeline of the fused launch
+    const int nwg = (int)((cdiv64((int64_t)B * H * W, 1024) + 7) / 8 * 8) * (C / 32);
+    void* tsd = nullptr;
+    DDMI_TRY(sc.get((size_t)nwg * 32, &tsd));
+    HIP_TRY(hipMemset(tsd, 0, (size_t)nwg * 32));
+    attnblock_debug_ts((unsigned long long*)tsd);
+    rc = u.net.run(B, ext, nullptr, 0, 0);
+    attnblock_debug_ts(nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> tsh((size_t)nwg * 4);
+    HIP_TRY(hipMemcpy(tsh.data(), tsd, (size_t)nwg * 32, hipMemcpyDeviceToHost));
+    double pa = 0, pb = 0, pc = 0;
+    unsigned long long t_min = ~0ull, t_max = 0;
+    int cnt = 0;
+    for (int i = 0; i < nwg; ++i) {
+      if (!tsh[4 * i]) continue;
+      pa += (double)(tsh[4 * i + 1] - tsh[4 * i]);
+      pb += (double)(tsh[4 * i + 2] - tsh[4 * i + 1]);
+      pc += (double)(tsh[4 * i + 3] - tsh[4 * i]);
+      t_min = std::min(t_min, tsh[4 * i]);
+      t_max = std::max(t_max, tsh[4 * i + 2]);
+      ++cnt;
+    }
+    fprintf(stderr, "[attnblock ts] C=%d %dx%d B=%d: %d workgroups, projection %.2f us, attention %.2f us (wave 0), workgroup %.2f us (means), launch span %.1f us\n",
+            C, H, W, B, cnt, pa / cnt * 0.01, pb / cnt * 0.01, pc / cnt * 0.01, (double)(t_max - t_min) * 0.01);
+  }
+  *us_out = 1000.0 * (ms - ms_seam) / iters;
+  return DDMI_OK;
+}
+
 int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
                       int silu, int numerics) {
   int dt;

@@ -1,0 +1,385 @@
+// Fused AttentionBlock body for the LDM UNet (openaimodel.py:279-325 `AttentionBlock._forward`, :397-426 `QKVAttentionLegacy`):
+//     qkv = Conv1d(C, 3C, 1)(GroupNorm(x));  a = softmax(q k^T / sqrt(d)) v  per head
+// as ONE launch that never writes the [B, T, 3C] qkv tensor (1.4 GB at 32x32, B = 512: written by the 1x1 convolution and read back
+// by the attention kernel in the five-launch form).  `proj_out` + residual stay the persistent 1x1 kernel's (k_conv.hip).
+//
+// Workgroup = 8 waves = one head of one GROUP of 1024 token rows (1 sample at 32x32, 4 at 16x16, 16 at 8x8).
+//   Phase A  q | k | v of the head for the group's 1024 rows = x[1024][C] . Wh^T[C][96] on MFMA, operands swapped (A = weight rows,
+//            B = token rows) so a lane ends with 8 consecutive channels of one token:
+//              - x goes global -> registers directly as B fragments (each row is used by exactly one wave: nothing to share, no LDS
+//                round trip); the GroupNorm in front writes it in fragment order, so a fragment is one contiguous KiB (from the
+//                row-major tensor every 16-lane group of a load touched 16 cache lines: 12 B/clk per CU, the projection ran at
+//                a quarter of the MFMA rate); wave w owns rows [128 w, 128 w + 128) in two passes of 64;
+//              - the head's weights stream through a 2 x 12 KB LDS stage per 64-channel chunk by LDS-DMA from a host-packed image
+//                that already IS the swizzled LDS layout (a linear 12 KB copy), one chunk ahead of its MFMAs, one barrier per chunk;
+//              - K and V land in LDS for all 1024 rows (2 x 64 KB, the attention kernel's row layouts); Q never leaves registers:
+//                the wave that projected a row is the wave that runs that row's queries (8 B fragments = 32 VGPRs).
+//   Phase B  attention_v2_kernel's lazy-maximum loop (k_attention.hip) over the LDS-resident K / V of the query's own sample:
+//            no global loads, no staging stores and no barrier inside the loop.
+// XCD x owns the groups g = x (mod 8) whole (all heads of a group read the same x rows through one L2).
+#include "kernels.h"
+#include "prof.h"
+#include <cstdlib>
+#include <cstring>
+#include <math.h>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+// timing-only ablation builds (tools/build_variant.sh -DAB_DBG=n; results are wrong): 1 no x loads after chunk 0, 2 no weight DMA after
+// chunk 0, 4 no per-chunk barrier, 8 no MFMAs in the projection
+#ifndef AB_DBG
+#define AB_DBG 0
+#endif
+#ifndef AB_OUT_SC1
+#define AB_OUT_SC1 1
+#endif
+#define AB_ROWS 1024                 // token rows per workgroup
+#define AB_KV_BYTES (AB_ROWS * 64)   // one of K / V: [row][32 channels] bf16
+#define AB_WCHUNK (96 * 128)         // one 64-channel chunk of a head's [96][C] weights: [96 rows][128 B]
+
+struct AttnBlockK {
+  const void* x;
+  const void* w;
+  const float* bias;
+  void* out;
+  unsigned x_bytes;
+  int rows;        // B * N valid token rows
+  int N, C, heads, groups, xcd;
+  unsigned long long* ts;   // diagnostics (attnblock_debug_ts): per workgroup [start, projection done, attention done] in 100 MHz ticks
+};
+
+// K rows: attention_v2's 64-byte-row swizzle (conflict-free ds_read_b128 fragments); V rows: its transposed-read swizzle
+__device__ __forceinline__ int ab_kswz(int row, int slot) {
+  int r = (row >> 2) & 3;
+  return slot ^ ((0x78 >> (r * 2)) & 3);
+}
+__device__ __forceinline__ int ab_vswz(int key) { return 2 * ((key >> 2) & 1); }
+
+template <int QF>
+__global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+  unsigned char* const Ks = ab_smem;
+  unsigned char* const Vs = ab_smem + AB_KV_BYTES;
+  unsigned char* const Wst = ab_smem + 2 * AB_KV_BYTES;   // [2][AB_WCHUNK]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  int g, h;
+  {
+    const int L = blockIdx.x;
+    if (a.xcd) {   // XCD x (= L % 8 under round-robin dispatch) owns the groups g = x (mod 8); heads of a group consecutive
+      const int slot = L >> 3, gl = slot / a.heads;
+      h = slot - gl * a.heads;
+      g = gl * 8 + (L & 7);
+    } else {
+      g = L / a.heads;
+      h = L - g * a.heads;
+    }
+    if (g >= a.groups) return;   // workgroup-uniform, before any barrier
+  }
+  const int N = a.N, C = a.C, NC = C >> 6;
+  const int row0 = g * AB_ROWS;
+  unsigned long long* const ts = a.ts && tid == 0 ? a.ts + 4 * blockIdx.x : nullptr;
+  if (ts) ts[0] = wall_clock64();
+  auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.w + (size_t)h * NC * AB_WCHUNK), 0, NC * AB_WCHUNK, 0x00020000);
+  const float* const biasp = a.bias + h * 96;
+  auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.x_bytes, 0x00020000);
+
+  // ================= Phase A: q | k | v projection ==================================================================
+  bf16x8 qb[8];
+  const int wsw = ((lr >> 1) & 7);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int tok0 = wave * 128 + p * 64;   // first LDS row of this pass
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int tf = 0; tf < 4; ++tf)
+#pragma unroll
+      for (int cf = 0; cf < 6; ++cf) acc[tf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // x is in B-fragment order [16-token block][k-step][lane][8] (launch_gn_apply frag_out): one fragment = one contiguous KiB.
+    // Blocks past the last sample start beyond x_bytes: the descriptor's range check returns zeros
+    const unsigned xl = (unsigned)((row0 + tok0) >> 4) * (unsigned)(C * 32) + (unsigned)(lane * 16);
+    u32x4 xa[4][2], xb[4][2];
+    auto load_x = [&](int c, u32x4(&xr)[4][2]) {
+#pragma unroll
+      for (int tf = 0; tf < 4; ++tf)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          xr[tf][ks] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xl + (unsigned)(tf * C * 32 + (2 * c + ks) * 1024), 0, 0);
+    };
+    auto dma_w = [&](int c, int buf) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int piece = wave + 8 * i;
+        if (piece < 12)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(Wst + buf * AB_WCHUNK + piece * 1024), 16,
+                                                   (unsigned)(c * AB_WCHUNK + piece * 1024 + lane * 16), 0, 0, 0);
+      }
+    };
+    // Chunk ORDER: head h starts at chunk h % NC and wraps.  All heads of a group run at once, in step, on the same x rows: walking
+    // the chunks in the same order made every workgroup wait for the same HBM miss at every chunk (the projection alone took 19 us
+    // with its MFMAs removed); staggered, a chunk is first touched by one or two heads and is an L2 hit for the others a step later.
+    const int cs0 = h % NC;
+    auto chunk_of = [&](int c) { const int t = c + cs0; return t >= NC ? t - NC : t; };
+    auto step = [&](int c, u32x4(&cur)[4][2], u32x4(&nxt)[4][2]) {
+      // the BUILTIN, not inline asm: hipcc's wait-count pass cannot see into an asm string, keeps the chunk-c loads on its scoreboard and
+      // then waits for them again behind the chunk c + 1 loads (vmcnt retires in order: that wait drained the whole prefetch)
+      __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's weight pieces and x fragments of chunk c have landed
+      if (!(AB_DBG & 4)) __builtin_amdgcn_s_barrier();   // everybody's have; everybody is done reading stage (c + 1) & 1
+      if (c + 1 < NC) {
+        if (!(AB_DBG & 2)) dma_w(chunk_of(c + 1), (c + 1) & 1);
+        if (!(AB_DBG & 1)) load_x(chunk_of(c + 1), nxt);
+      }
+      const unsigned char* wb = Wst + (c & 1) * AB_WCHUNK + lr * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 wf[6];
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) wf[cf] = *reinterpret_cast<const bf16x8*>(wb + cf * 2048 + (((4 * ks + lg) ^ wsw) << 4));
+#pragma unroll
+        for (int tf = 0; tf < 4; ++tf) {
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, cur[tf][ks]);
+#pragma unroll
+          for (int cf = 0; cf < 6; ++cf)
+            if (!(AB_DBG & 8)) acc[tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cf], xf, acc[tf][cf], 0, 0, 0);
+            else acc[tf][cf][0] += (float)wf[cf][0] + (float)xf[0];
+        }
+      }
+    };
+    dma_w(chunk_of(0), 0);
+    load_x(chunk_of(0), xa);
+#pragma unroll 1
+    for (int c = 0; c < NC; c += 2) {
+      step(c, xa, xb);
+      if (c + 1 < NC) step(c + 1, xb, xa);
+    }
+    // ---- epilogue: + bias; Q -> B fragments in registers, K / V -> LDS rows (the weight rows were permuted on the host so that the
+    //      two fragments of a pair hand a lane 8 consecutive positions) -----------------------------------------------------------
+    f32x4 bv[6];
+#pragma unroll
+    for (int cf = 0; cf < 6; ++cf) bv[cf] = *reinterpret_cast<const f32x4*>(biasp + cf * 16 + 4 * lg);
+#pragma unroll
+    for (int tf = 0; tf < 4; ++tf) {
+      const int tok = tok0 + tf * 16 + lr;
+      bf16x8 q8, k8, v8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q8[j] = (bf16_t)(acc[tf][0][j] + bv[0][j]);
+        q8[4 + j] = (bf16_t)(acc[tf][1][j] + bv[1][j]);
+        k8[j] = (bf16_t)(acc[tf][2][j] + bv[2][j]);
+        k8[4 + j] = (bf16_t)(acc[tf][3][j] + bv[3][j]);
+        v8[j] = (bf16_t)(acc[tf][4][j] + bv[4][j]);
+        v8[4 + j] = (bf16_t)(acc[tf][5][j] + bv[5][j]);
+      }
+      qb[p * 4 + tf] = q8;
+      *reinterpret_cast<bf16x8*>(Ks + tok * 64 + ab_kswz(tok, lg) * 16) = k8;
+      *reinterpret_cast<bf16x8*>(Vs + tok * 64 + ((lg ^ ab_vswz(tok)) << 4)) = v8;
+    }
+    __syncthreads();   // the weight stages are free for the next pass; after the second pass: every K / V row is visible
+  }
+
+  if (ts) ts[1] = wall_clock64();
+  // ================= Phase B: attention over the LDS-resident K / V (attention_v2_kernel's LAZY loop, D = 32) =============
+  constexpr int RB = 64, KT = 64, NDF = 2;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  const int tq = lr >> 2, tp = lr & 3;
+  const int vkey = 4 * lg + tq;
+  const int vsw = ab_vswz(vkey);
+  const int vbase = vkey * RB + (tp & 1) * 8;
+  const int ntiles = N / KT;
+#pragma unroll
+  for (int rnd = 0; rnd < 8 / QF; ++rnd) {
+    const int qrow0 = wave * 128 + rnd * QF * 16;
+    const int keybase = qrow0 & ~(N - 1);   // the query's own sample inside the group (N is a power of two)
+    float m_run[QF];
+    f32x4 o[QF][NDF], ol[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      m_run[qf] = 0.f;
+      ol[qf] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+    }
+#pragma unroll 1
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const unsigned char* kb = Ks + (keybase + kt * KT) * RB;
+      const unsigned char* vb = Vs + (keybase + kt * KT) * RB;
+      f32x4 sc[QF][4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int row = 16 * f + lr;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * RB + ab_kswz(row, lg) * 16);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          const float init = -m_run[qf];
+          sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[rnd * QF + qf], f32x4{init, init, init, init}, 0, 0, 0);
+        }
+      }
+      float lmax[QF];
+      bool grow = kt == 0;
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) {
+        float t = sc[qf][0][0];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
+        lmax[qf] = t;
+        grow |= t > 6.0f;
+      }
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // move the reference of every query of the wave to its running maximum
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          float t = lmax[qf];
+          t = fmaxf(t, __shfl_xor(t, 16));
+          t = fmaxf(t, __shfl_xor(t, 32));
+          t = fmaxf(t, kt == 0 ? -1e30f : 0.f);
+          if (kt != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(-t);
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+            ol[qf][0] *= alpha;
+          }
+          m_run[qf] += t;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
+        }
+      }
+      bf16x8 pf[QF][2];
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)__builtin_amdgcn_exp2f(sc[qf][f][j]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+          const int coff = ((2 * df + (tp >> 1)) ^ vsw) << 4;
+          typedef short s16x4 __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + vbase + (32 * u) * RB + coff));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + vbase + (32 * u + 16) * RB + coff));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (k_attention.hip: the element-wise one miscompiles)
+#pragma unroll
+          for (int qf = 0; qf < QF; ++qf) o[qf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][df], 0, 0, 0);
+        }
+      }
+    }
+    // ---- output rows: LDS position 16 df + 4 lg + j of V holds channel 8 lg + 4 df + j (host permutation of the v rows), so the
+    //      lane's two fragments are 8 consecutive channels = one 16-byte store -----------------------------------------------
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      const int row = row0 + qrow0 + qf * 16 + lr;
+      if (row >= a.rows) continue;
+      const float inv = 1.0f / ol[qf][0];
+      bf16x8 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[j] = (bf16_t)(o[qf][0][j] * inv);
+        t[4 + j] = (bf16_t)(o[qf][1][j] * inv);
+      }
+#if AB_OUT_SC1
+      // sc1 store: written through and DROPPED from this XCD's L2 (MI355X_MICROARCH.md, store flavours) - the 64 KB a workgroup writes
+      // would otherwise push the group's x rows, which the other heads still need, out of the 4 MiB L2
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), o_rsrc, (unsigned)(row * C * 2 + h * 64 + 16 * lg), 0, 16);
+#else
+      *reinterpret_cast<bf16x8*>((bf16_t*)a.out + (int64_t)row * C + h * 32 + 8 * lg) = t;
+#endif
+    }
+  }
+  if (a.ts) {   // diagnostics only: when the slowest wave is done
+    if (ts) ts[2] = wall_clock64();
+    __syncthreads();
+    if (ts) ts[3] = wall_clock64();
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+static inline uint16_t ab_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+bool attnblock_shape_ok(int dt, int N, int C, int d, int max_batch) {
+  if (dt != DT_BF16 || d != 32 || C % 64 != 0 || C < 64) return false;
+  if (N != 64 && N != 256 && N != 1024) return false;
+  const int64_t groups = cdiv64((int64_t)max_batch * N, AB_ROWS);
+  return groups * AB_ROWS * C * 2 < ((int64_t)1 << 31);   // 32-bit buffer offsets over the padded row range
+}
+
+size_t attnblock_weight_bytes(int C, int heads) { return (size_t)heads * (C / 64) * AB_WCHUNK; }
+
+// w [3C][C] / b [3C] in QKVAttentionLegacy order (per head [q | k | v] blocks of 32 rows, openaimodel.py:406-408), q rows already
+// carrying softmax scale x log2 e.  wp: bf16 LDS images [head][chunk][96 rows][128 B]; bp: [head][96] in the images' row order.
+void attnblock_pack_weights(const float* w, const float* b, int C, int heads, uint16_t* wp, float* bp) {
+  const int NC = C / 64;
+  for (int h = 0; h < heads; ++h)
+    for (int r = 0; r < 96; ++r) {
+      const int cf = r >> 4, rr = r & 15, blk = cf >> 1, half = cf & 1, l = rr >> 2, j = rr & 3;
+      // fragment pair (2 blk, 2 blk + 1), lane group l: q / k - channels 8 l + 4 half + j (a lane's 8 values are consecutive channels);
+      // v - LDS position 8 l + 4 half + j must hold the channel c with 16 df + 4 l' + j' -> 8 l' + 4 df + j' (see the output store)
+      int ch;
+      if (blk < 2) ch = 8 * l + 4 * half + j;
+      else {
+        const int pos = 8 * l + 4 * half + j, df = pos >> 4, l2 = (pos >> 2) & 3, j2 = pos & 3;
+        ch = 8 * l2 + 4 * df + j2;
+      }
+      const int src = h * 96 + blk * 32 + ch;
+      bp[h * 96 + r] = b[src];
+      for (int c = 0; c < NC; ++c) {
+        uint16_t* img = wp + ((size_t)(h * NC + c) * 96 + r) * 64;
+        for (int s = 0; s < 8; ++s) {
+          const int phys = s ^ ((r >> 1) & 7);
+          for (int e = 0; e < 8; ++e) img[phys * 8 + e] = ab_bf16_rne(w[(size_t)src * C + 64 * c + 8 * s + e]);
+        }
+      }
+    }
+}
+
+static unsigned long long* g_ab_ts = nullptr;
+void attnblock_debug_ts(unsigned long long* buf) { g_ab_ts = buf; }
+
+int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, void* out, int B, int N, int C, int heads, hipStream_t s) {
+  DDMI_REQUIRE(x && wp && bp && out && B > 0, "attention block: bad arguments");
+  DDMI_REQUIRE(attnblock_shape_ok(DT_BF16, N, C, 32, B) && heads * 32 == C, "attention block: shape not served by the fused kernel");
+  AttnBlockK k{};
+  k.x = x; k.w = wp; k.bias = bp; k.out = out;
+  k.rows = B * N;
+  k.x_bytes = (unsigned)((size_t)k.rows * C * 2);
+  k.N = N; k.C = C; k.heads = heads;
+  k.groups = cdiv(k.rows, AB_ROWS);
+  k.xcd = k.groups >= 8 ? 1 : 0;
+  k.ts = g_ab_ts;
+  const int gpad = k.xcd ? cdiv(k.groups, 8) * 8 : k.groups;
+  constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK;
+  static int qf_env = getenv("DDMI_ATTNBLOCK_QF") ? atoi(getenv("DDMI_ATTNBLOCK_QF")) : 2;
+  auto k2 = attnblock_kernel<2>;
+  auto k4 = attnblock_kernel<4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const double T = (double)B * N;
+  PROF_SCOPE("attnblock_qkv_attn", 2.0 * T * C * 3 * C + 4.0 * T * N * C, 2.0 * T * C * 2, s);
+  hipLaunchKernelGGL(qf_env == 4 ? k4 : k2, dim3(gpad * heads), dim3(512), lds, s, k);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

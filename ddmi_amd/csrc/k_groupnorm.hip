@@ -112,7 +112,7 @@ template <typename T, bool CHSTAT>
 __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, T* __restrict__ y,
                                 const double* __restrict__ part,
                                 GnSegs sg, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                float eps, int silu, int HW, int C, int NV, int R, GnChstat ch, int x3_out) {
+                                float eps, int silu, int HW, int C, int NV, int R, GnChstat ch, int x3_out, int frag_out) {
   constexpr int VN = Vec16<T>::N;
   __shared__ float mr[GN_GROUPS * 2];  // mean, rstd per group
   int b = blockIdx.y;
@@ -169,6 +169,52 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
     mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
+  if constexpr (sizeof(T) == 2) {
+    if (frag_out) {
+      // Output in MFMA B-fragment order for the fused attention block (k_attnblock.hip): [16-token block][32-channel k-step][lane = 16 (c >> 3
+      // & 3) + (token & 15)][8 channels], so that a wave of that kernel loads a whole fragment as ONE contiguous KiB (from the
+      // row-major tensor every 16-lane group of its loads touched 16 cache lines: 12 B/clk per CU, measured).  Here the lanes of a
+      // wave take the fragment's own (token, channel vector) map: the STORE is the contiguous KiB, the load pays the 16-line
+      // pattern - on a pass that needs ~12 B/clk per CU that is free, where scattered 16-byte stores cost the pass 2x.
+      const int lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6, lr = lane & 15, lg = lane >> 4;
+      const int KS = C >> 5, TB = HW >> 4;
+      const int per_tb = cdiv(TB, gridDim.x), tb0 = blockIdx.x * per_tb, tb1 = min(TB, tb0 + per_tb);
+      const int nchunk = (tb1 - tb0 + 7) >> 3;
+      typedef __attribute__((ext_vector_type(4))) unsigned int raw16;
+      for (int item = wave; item < nchunk * KS; item += NW) {   // item = (8 token blocks, one k-step): the lane's 8 channels are fixed
+        const int ks = item % KS, t0 = tb0 + (item / KS) * 8;
+        const int c0 = 32 * ks + 8 * lg;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int g = (c0 + i) / cpg;
+          const float s = mr[g * 2 + 1] * gamma[c0 + i];
+          sc[i] = s;
+          sh[i] = beta[c0 + i] - mr[g * 2] * s;
+        }
+        const T* xb = x + ((int64_t)b * HW + lr) * C + c0;
+        T* yb = y + ((((int64_t)b * TB) * KS + ks) * 64 + lane) * 8;
+        raw16 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (t0 + u < tb1) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const raw16*>(xb + (int64_t)(t0 + u) * 16 * C));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (t0 + u >= tb1) continue;
+          float t[8];
+          Vec16<T>::load(reinterpret_cast<const T*>(&raw[u]), t);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float q = t[j] * sc[j] + sh[j];
+            if (silu) q = q * __frcp_rn(1.0f + __expf(-q));
+            t[j] = q;
+          }
+          Vec16<T>::store(yb + (int64_t)(t0 + u) * KS * 512, t);
+        }
+      }
+      return;
+    }
+  }
   int v = tid % NV, r = tid / NV;
   if (r >= R) return;
   float sc[VN], sh[VN];
@@ -328,10 +374,14 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
   return DDMI_OK;
 }
 
+static bool gn_frag_out_ok(int dt, int B, int HW, int C) { return dt == DT_BF16 && C % 32 == 0 && HW % 16 == 0; }
+
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw, int nseg, const void* x2,
-                    int C1, int x3_out) {
+                    int C1, int x3_out, int frag_out) {
   DDMI_REQUIRE(!x3_out || dt == DT_F32, "groupnorm: the [xh | xl | xh] output belongs to the fp32 (bf16x3) networks");
+  DDMI_REQUIRE(!frag_out || (gn_frag_out_ok(dt, B, HW, C) && x2 == nullptr && nseg <= 1),
+               "groupnorm: fragment-order output needs bf16, one source, C % 32 == 0 and whole 16-token blocks");
   int vn = dt == DT_F32 ? 4 : 8;
   int NV = C / vn;
   int R = std::max(1, 256 / NV);
@@ -353,17 +403,19 @@ int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const f
   GnChstat none{};
   if (dt == DT_F32)
     hipLaunchKernelGGL((gn_apply_kernel<float, false>), g, dim3(threads), 0, s, (const float*)x, (const float*)x2, C1, (float*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R, none, x3_out);
+                       beta, eps, silu, HW, C, NV, R, none, x3_out, 0);
   else
     hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R, none, 0);
+                       beta, eps, silu, HW, C, NV, R, none, 0, frag_out);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
 
 // GroupNorm apply with the statistics taken from the producers' channel-statistics buffers (bf16 networks; see gn_apply_kernel)
 int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, const float* cs2, int rows2, const float* gamma,
-                           const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2, int C1) {
+                           const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2, int C1, int frag_out) {
+  DDMI_REQUIRE(!frag_out || (gn_frag_out_ok(DT_BF16, B, HW, C) && x2 == nullptr),
+               "groupnorm: fragment-order output needs one source, C % 32 == 0 and whole 16-token blocks");
   DDMI_REQUIRE(cs1 && rows1 > 0 && HW % rows1 == 0 && (cs2 == nullptr || (rows2 > 0 && HW % rows2 == 0 && C1 > 0 && C1 < C)),
                "groupnorm: bad channel-statistics buffers");
   DDMI_REQUIRE(C % GN_GROUPS == 0 && C % 8 == 0, "groupnorm: C must be a multiple of 32");
@@ -375,7 +427,7 @@ int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, 
   GnChstat ch{cs1, cs2, rows1, rows2};
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * 2 + 8.0 * B * C * (HW / rows1), s);
   hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), g, dim3(threads), (size_t)2 * C * sizeof(double), s, (const bf16_t*)x, (const bf16_t*)x2, C1,
-                     (bf16_t*)y, (const double*)nullptr, sg, gamma, beta, eps, silu, HW, C, NV, R, ch, 0);
+                     (bf16_t*)y, (const double*)nullptr, sg, gamma, beta, eps, silu, HW, C, NV, R, ch, 0, frag_out);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }

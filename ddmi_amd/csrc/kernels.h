@@ -65,10 +65,12 @@ int launch_gn_chstat_finish(const float* cs1, int rows1, const float* cs2, int r
                             hipStream_t s);
 // apply pass that reduces the producers' channel statistics itself (no finish launch); bf16 tensors
 int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, const float* cs2, int rows2, const float* gamma,
-                           const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2 = nullptr, int C1 = 0);
+                           const float* beta, float eps, int silu, int B, int HW, int C, hipStream_t s, const void* x2 = nullptr, int C1 = 0,
+                           int frag_out = 0);
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw = nullptr, int nseg = 1,
-                    const void* x2 = nullptr, int C1 = 0, int x3_out = 0);   // x3_out: fp32 in, [xh | xl | xh] bf16 image out (bf16x3 numerics)
+                    const void* x2 = nullptr, int C1 = 0, int x3_out = 0,    // x3_out: fp32 in, [xh | xl | xh] bf16 image out (bf16x3 numerics)
+                    int frag_out = 0);   // bf16: output in MFMA B-fragment order [16 tokens][32 channels][lane][8] for k_attnblock.hip
 
 // ---- implicit-GEMM convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 upsample) ------
 struct ConvArgs {
@@ -250,3 +252,14 @@ int launch_pack_fwd_weight(const float* w, void* out, int dt, int Co, int Ci, in
 int sgemm_splits(int M, int N, int R);
 int launch_sgemm(const float* A, int64_t sam, int64_t sar, const float* Bm, int64_t sbr, int64_t sbn, float* C, const float* bias, int M, int N,
                  int R, float* slab, hipStream_t s);
+
+// ---- fused AttentionBlock body (k_attnblock.hip): GroupNorm output -> qkv projection -> attention in one launch -----------------
+// bf16, head dim 32, QKVAttentionLegacy layout, N = H W in {64, 256, 1024}, C a multiple of 64
+bool attnblock_shape_ok(int dt, int N, int C, int d, int max_batch);
+size_t attnblock_weight_bytes(int C, int heads);
+void attnblock_pack_weights(const float* w_qkv, const float* b_qkv, int C, int heads, uint16_t* wp, float* bp);
+// x: the normalised activations in FRAGMENT order (launch_gn_apply frag_out) -> out [B N][C] (attention output, head h at channels [32 h, 32 h + 32)); q rows of the packed
+// projection carry softmax scale x log2 e
+// diagnostics: 4 x 64-bit words per workgroup (start, projection done, attention done; wave 0's view), null = off
+void attnblock_debug_ts(unsigned long long* buf);
+int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, void* out, int B, int N, int C, int heads, hipStream_t s);

@@ -26,13 +26,18 @@ int unet_finalize(UNet& u);
 struct ResW { int gn1 = -1, c1 = -1, gn2 = -1, c2 = -1, cs = -1, cs2 = -1, emb_off = -1; float eps = 1e-5f;
               int cs_full = -1; };   // cs_full: the un-split 1x1 skip_connection (folded into c2's launch where the shape allows)
 struct AttnW { int gn = -1, cqkv = -1, cp = -1, heads = 1, head_dim = 0, legacy = 0; float eps = 1e-5f, scale = 1.f;
-               int q_prescaled = 0; };   // the projection's q rows carry scale x log2 e (bf16 networks, k_attention.hip LAZY)
+               int q_prescaled = 0;      // the projection's q rows carry scale x log2 e (bf16 networks, k_attention.hip LAZY)
+               int fused = -1; };        // Net::attnblocks index: qkv projection + attention in one launch where the shape allows
 // split > 0: the input will be the channel concat of a `split`-channel tensor and another one (emit_resblock_cat)
 int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split = 0);
 int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out);
 int make_vae_resblock(Net& n, const std::string& pre, int cin, int cout, ResW* w);
 int emit_resblock(Net& n, const ResW& w, int x, int* out);
-int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w);
+// n_tokens > 0: the block only ever runs on H W = n_tokens (lets a fused block skip the separate qkv convolution's weights)
+int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w, int n_tokens = 0);
+bool attnblock_fused_enabled(int n_tokens);
+void attnblock_fused_override(int mode);      // -1: environment, 0: never, 1: wherever the shape allows (networks built afterwards)
+//   // DDMI_ATTN_FUSED (0 = off) / DDMI_ATTN_FUSED_N (comma list of token counts)
 int make_qkv_attn(Net& n, const std::string& pre, int ch, int heads, bool expand, AttnW* w);
 int emit_attn_single(Net& n, const AttnW& w, int x, int* out);
 int emit_attn_joint(Net& n, const AttnW& w, int xy, int tp, int* out_xy, int* out_tp);

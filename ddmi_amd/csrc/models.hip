@@ -101,7 +101,26 @@ static int build_resblock(UNet& u, const std::string& pre, int x, int cout, int*
 }
 
 // AttentionBlock (openaimodel.py:319-325) with QKVAttentionLegacy, head dim = num_head_channels
-int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w) {
+// Which AttentionBlocks run as the fused qkv + attention launch (k_attnblock.hip).  DDMI_ATTN_FUSED=0 keeps the five-launch form
+// everywhere (A/B and the fallback for shapes the fused kernel does not serve); DDMI_ATTN_FUSED_N=1024,256 restricts it to blocks
+// with those token counts.
+static int g_attn_fused_override = -1;   // ddmi_debug_attn_fused: -1 = the environment decides
+void attnblock_fused_override(int mode) { g_attn_fused_override = mode; }
+bool attnblock_fused_enabled(int n_tokens) {
+  if (g_attn_fused_override >= 0) return g_attn_fused_override != 0;
+  static const bool off = getenv("DDMI_ATTN_FUSED") && atoi(getenv("DDMI_ATTN_FUSED")) == 0;
+  if (off) return false;
+  const char* e = getenv("DDMI_ATTN_FUSED_N");
+  if (!e || n_tokens <= 0) return true;
+  for (const char* p = e; *p;) {
+    if (atoi(p) == n_tokens) return true;
+    while (*p && *p != ',') ++p;
+    if (*p == ',') ++p;
+  }
+  return false;
+}
+
+int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w, int n_tokens) {
   Net& n = u.net;
   DDMI_REQUIRE(u.cfg.num_head_channels > 0 && ch % u.cfg.num_head_channels == 0, "channels must be a multiple of num_head_channels");
   w->eps = 1e-5f;
@@ -126,12 +145,17 @@ int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w) {
         for (int c = 0; c < ch; ++c) ws[(size_t)r * ch + c] *= f;
         bs[r] *= f;
       }
-    DDMI_TRY(n.make_conv_host(ws, 3 * ch, ch, 1, &bs, &w->cqkv));
+    // fused qkv + attention launch (k_attnblock.hip): its own packing of the same pre-scaled projection; a block whose only token
+    // count is served by it needs no separate qkv convolution
+    const bool fusable = !n.x3 && w->head_dim == 32 && attnblock_shape_ok(n.dt, 1024, ch, 32, 1) && attnblock_fused_enabled(n_tokens);
+    if (fusable) DDMI_TRY(n.make_attnblock(ws, bs, ch, w->heads, &w->fused));
+    if (!(fusable && n_tokens > 0 && attnblock_shape_ok(n.dt, n_tokens, ch, 32, n.max_batch * n.max_bmul)))
+      DDMI_TRY(n.make_conv_host(ws, 3 * ch, ch, 1, &bs, &w->cqkv));
   } else {
     DDMI_TRY(n.make_conv(pre + "qkv.weight", pre + "qkv.bias", &w->cqkv));
   }
   DDMI_TRY(n.make_conv(pre + "proj_out.weight", pre + "proj_out.bias", &w->cp));
-  DDMI_REQUIRE(n.convs[w->cqkv].Cout == 3 * ch && n.convs[w->cqkv].Cin == ch, "qkv shape mismatch at " + pre);
+  if (w->cqkv >= 0) DDMI_REQUIRE(n.convs[w->cqkv].Cout == 3 * ch && n.convs[w->cqkv].Cin == ch, "qkv shape mismatch at " + pre);
   return DDMI_OK;
 }
 
@@ -139,6 +163,20 @@ int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w) {
 int emit_attn_single(Net& n, const AttnW& w, int x, int* out) {
   const TensorDesc t = n.tensors[x];
   int a = n.op_gn(x, w.gn, 0, w.eps);
+  if (w.fused >= 0 && attnblock_fused_enabled(t.H * t.W) && attnblock_shape_ok(n.dt, t.H * t.W, t.C, w.head_dim, n.max_batch * t.bmul)) {
+    n.ops.back().frag_out = 1;   // the GroupNorm just emitted: its output only feeds the fused launch, which wants whole B fragments
+    Op f;
+    f.kind = OP_ATTN_BLOCK;
+    f.in = a;
+    f.out = n.new_tensor(t.C, t.H, t.W, -1, t.bmul);
+    f.bmul = t.bmul;
+    f.conv = w.fused;
+    f.heads = w.heads; f.head_dim = w.head_dim;
+    n.ops.push_back(f);
+    *out = n.op_conv(f.out, w.cp, 1, 0, x, -1);
+    return DDMI_OK;
+  }
+  DDMI_REQUIRE(w.cqkv >= 0, "attention block: no qkv projection for this token count");
   int qkv = n.op_conv(a, w.cqkv, 1, 0, -1, -1);
   Op o;
   o.kind = OP_ATTN_MH;
@@ -210,7 +248,7 @@ int make_qkv_attn(Net& n, const std::string& pre, int ch, int heads, bool expand
 
 static int build_attnblock(UNet& u, const std::string& pre, int x, int* out) {
   AttnW w;
-  DDMI_TRY(make_unet_attnblock(u, pre, u.net.tensors[x].C, &w));
+  DDMI_TRY(make_unet_attnblock(u, pre, u.net.tensors[x].C, &w, u.net.tensors[x].H * u.net.tensors[x].W));
   return emit_attn_single(u.net, w, x, out);
 }
 

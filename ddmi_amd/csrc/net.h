@@ -30,6 +30,12 @@ struct ConvW {
   std::string wkey;       // state-dict key of the raw fp32 weight (make_conv), valid until finalize drops the host copies
 };
 
+struct AttnBlockW {   // an AttentionBlock's qkv projection as k_attnblock.hip's per-(head, chunk) LDS images
+  void* w = nullptr;
+  float* bias = nullptr;
+  int C = 0, heads = 0;
+};
+
 struct GNW {
   float* gamma = nullptr;
   float* beta = nullptr;
@@ -43,13 +49,16 @@ enum OpKind { OP_NCHW_IN = 0, OP_GN, OP_CONV, OP_ATTN_LEGACY, OP_ATTN_FULL, OP_C
               OP_SEG_IN,      // ext [B, C, L] fp32 -> out (xy), out2 (xt, yt)
               OP_SEG_OUT,     // in, in2 -> ext [B, C, L] fp32
               OP_GN_JOINT,    // GroupNorm whose statistics run over all tokens of the sample: in, in2 -> out, out2
-              OP_ATTN_MH };   // multi-head attention over in (+ in2 when >= 0) -> out (+ out2)
+              OP_ATTN_MH,     // multi-head attention over in (+ in2 when >= 0) -> out (+ out2)
+              OP_ATTN_BLOCK };  // qkv projection + attention of an AttentionBlock in one launch (k_attnblock.hip): in = the GroupNorm
+                                // output, out = the attention output; `conv` indexes Net::attnblocks
 
 struct Op {
   int kind = 0;
   int in = -1, in2 = -1, out = -1, out2 = -1, res = -1;
   int conv = -1, gn = -1;
   int silu = 0;
+  int frag_out = 0;    // OP_GN: output in MFMA B-fragment order (its only consumer is an OP_ATTN_BLOCK)
   float eps = 1e-5f;
   int stride = 1, pad = 0, ups = 0;
   int emb_off = -1;
@@ -99,6 +108,7 @@ struct Net {
   std::map<std::string, HostTensor> host;   // raw state-dict tensors (fp32) until finalize
   std::vector<ConvW> convs;
   std::vector<GNW> gns;
+  std::vector<AttnBlockW> attnblocks;
   std::vector<Op> ops;
   std::vector<TensorDesc> tensors;
   std::vector<void*> dev_allocs;            // everything hipMalloc'ed by this net
@@ -120,6 +130,8 @@ struct Net {
   int dev_upload(const float* src, int64_t n, float** out);
   int make_conv(const std::string& wkey, const std::string& bkey, int* idx);   // [Cout,Cin,K,K] or [Cout,Cin,1] / [Cout,Cin]
   int make_gn(const std::string& prefix, int* idx);
+  // w [3C][C], b [3C]: QKVAttentionLegacy order, q rows pre-scaled (make_unet_attnblock)
+  int make_attnblock(const std::vector<float>& w, const std::vector<float>& b, int C, int heads, int* idx);
   int op_gn(int in, int gn, int silu, float eps, int in2 = -1);  // in2 >= 0: GroupNorm of the channel concat [in | in2]
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
   // conv3x3(in) + conv1x1([skip_in | skip_in2]) in one launch; false when this network / shape cannot fold (caller emits the two ops)

@@ -133,6 +133,25 @@ int Net::make_conv(const std::string& wkey, const std::string& bkey, int* idx) {
   return DDMI_OK;
 }
 
+int Net::make_attnblock(const std::vector<float>& w, const std::vector<float>& b, int C, int heads, int* idx) {
+  DDMI_REQUIRE(dt == DT_BF16 && !x3 && heads * 32 == C && C % 64 == 0, "fused attention block: bf16 networks, head dim 32");
+  DDMI_REQUIRE((int64_t)w.size() == (int64_t)3 * C * C && (int)b.size() == 3 * C, "fused attention block: qkv shape mismatch");
+  const size_t wbytes = attnblock_weight_bytes(C, heads);
+  std::vector<uint16_t> wp(wbytes / 2);
+  std::vector<float> bp((size_t)heads * 96);
+  attnblock_pack_weights(w.data(), b.data(), C, heads, wp.data(), bp.data());
+  AttnBlockW a;
+  a.C = C; a.heads = heads;
+  HIP_TRY(hipMalloc(&a.w, wbytes));
+  dev_allocs.push_back(a.w);
+  HIP_TRY(hipMemcpy(a.w, wp.data(), wbytes, hipMemcpyHostToDevice));
+  DDMI_TRY(dev_upload(bp.data(), (int64_t)bp.size(), &a.bias));
+  weight_bytes += wbytes;
+  attnblocks.push_back(a);
+  *idx = (int)attnblocks.size() - 1;
+  return DDMI_OK;
+}
+
 int Net::make_gn(const std::string& prefix, int* idx) {
   const HostTensor* g = find(prefix + "weight");
   const HostTensor* b = find(prefix + "bias");
@@ -564,7 +583,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         if (fused_finish && o.stat_in >= 0 && stat_rows[o.in] > 0 && (o.in2 < 0 || (o.stat_in2 >= 0 && stat_rows[o.in2] > 0))) {
           DDMI_TRY(launch_gn_apply_chstat(tptr(o.in), tptr(o.out), (const float*)tptr(o.stat_in), stat_rows[o.in],
                                           o.in2 >= 0 ? (const float*)tptr(o.stat_in2) : nullptr, o.in2 >= 0 ? stat_rows[o.in2] : 0, g.gamma, g.beta,
-                                          o.eps, o.silu, B, t.H * t.W, C, s, x2, t.C));
+                                          o.eps, o.silu, B, t.H * t.W, C, s, x2, t.C, o.frag_out));
           break;
         }
         if (o.stat_in >= 0 && stat_rows[o.in] > 0 && (o.in2 < 0 || (o.stat_in2 >= 0 && stat_rows[o.in2] > 0)))
@@ -573,7 +592,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         else
           DDMI_TRY(launch_gn_stats(tptr(o.in), dt, st, B, t.H * t.W, C, s, 0, 1, x2, t.C));
         DDMI_TRY(launch_gn_apply(tptr(o.in), tptr(o.out), dt, st, g.gamma, g.beta, o.eps, o.silu, B, t.H * t.W, C, s, nullptr,
-                                 1, x2, t.C, tensors[o.out].x3img ? 1 : 0));
+                                 1, x2, t.C, tensors[o.out].x3img ? 1 : 0, o.frag_out));
         break;
       }
       case OP_CONV: {
@@ -683,6 +702,13 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           a.B = B;
         }
         DDMI_TRY(launch_attention(a, dt, s));
+        break;
+      }
+      case OP_ATTN_BLOCK: {
+        const TensorDesc& t = tensors[o.in];
+        const AttnBlockW& w = attnblocks[o.conv];
+        DDMI_REQUIRE(w.C == t.C && tensors[o.out].C == t.C, "fused attention block: channel mismatch");
+        DDMI_TRY(launch_attnblock_qkv_attn(tptr(o.in), w.w, w.bias, tptr(o.out), B, t.H * t.W, t.C, w.heads, s));
         break;
       }
       case OP_ATTN_LEGACY: {

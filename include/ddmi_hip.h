@@ -332,6 +332,18 @@ int ddmi_op_attention_legacy_hd(const float* qkv, float* out, int B, int heads, 
  * held in separate buffers internally (N - seg0 - seg1 is the third), the way the xy | xt | yt planes are. */
 int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
                          int seg0, int seg1, int numerics);
+/* One AttentionBlock of the LDM UNet (openaimodel.py:279-325 with QKVAttentionLegacy :397-426), built the way the UNet handle
+ * builds it: x + proj_out(attention(qkv(GroupNorm32(x)))); x, y [B, C, H, W]; wqkv [3C, C], wproj [C, C] (Conv1d weights with the
+ * kernel dim dropped); head_channels = num_head_channels.  In bf16 mode, head dim 32 and H W in {64, 256, 1024} the qkv projection
+ * and the attention are ONE launch (k_attnblock.hip: the [B, T, 3C] qkv tensor is never written); *fused_used reports which form
+ * ran.  ddmi_debug_attn_fused pins the choice for networks built afterwards: 0 = five launches, 1 = fused where the shape
+ * allows, -1 = the DDMI_ATTN_FUSED / DDMI_ATTN_FUSED_N environment (default: fused). */
+int ddmi_op_attention_block(const float* x, const float* gamma, const float* beta, const float* wqkv, const float* bqkv,
+                            const float* wproj, const float* bproj, float* y, int B, int C, int H, int W, int head_channels,
+                            int numerics, int* fused_used);
+int ddmi_debug_attn_fused(int mode);
+/* average device time (us) of one bf16 AttentionBlock with num_head_channels 32 on device-resident pseudo-random data */
+int ddmi_bench_attention_block(int B, int C, int H, int W, int iters, double* us_out, int* fused_used);
 /* timestep_embedding (util.py:150-170): t [B] int64 -> [B, dim] */
 int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim);
 
