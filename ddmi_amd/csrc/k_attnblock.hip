@@ -365,6 +365,8 @@ int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, vo
   k.N = N; k.C = C; k.heads = heads;
   k.groups = cdiv(k.rows, AB_ROWS);
   k.xcd = k.groups >= 8 ? 1 : 0;
+  static const int xcd_env = getenv("DDMI_ATTNBLOCK_XCD") ? atoi(getenv("DDMI_ATTNBLOCK_XCD")) : -1;   // diagnostics: 0 = plain order
+  if (xcd_env == 0) k.xcd = 0;
   k.ts = g_ab_ts;
   const int gpad = k.xcd ? cdiv(k.groups, 8) * 8 : k.groups;
   constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK;

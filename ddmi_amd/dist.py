@@ -67,18 +67,17 @@ def group_size(device) -> int:
     return int(t.item())
 
 
-_SHARED_PLAN_FILES: List[str] = []
+_SHARED_PLAN_PATH: Optional[str] = None   # this process's plan file for shared finalizes (a module variable, NOT an inherited env var)
 
 
-def _drop_shared_plan_files() -> None:
-    for p in _SHARED_PLAN_FILES:
+def _drop_shared_plan_file() -> None:
+    global _SHARED_PLAN_PATH
+    if _SHARED_PLAN_PATH is not None:
         try:
-            os.unlink(p)
+            os.unlink(_SHARED_PLAN_PATH)
         except OSError:
             pass
-    if os.environ.get("DDMI_TUNE_SHARED") == "1":
-        os.environ.pop("DDMI_TUNE_FILE", None)
-        os.environ.pop("DDMI_TUNE_SHARED", None)
+        _SHARED_PLAN_PATH = None
 
 
 def finalize_with_shared_plans(finalize: Callable[[], object], rank: int, world: int) -> Optional[str]:
@@ -86,30 +85,37 @@ def finalize_with_shared_plans(finalize: Callable[[], object], rank: int, world:
     convolution plans: rank 0 tunes into a plan file, its text is broadcast, the other ranks finalize from it.  The
     autotuner is timing-based, so two ranks tuning on their own can pick different tiles / split-K for the same shape;
     with shared plans the bf16 results of a sample are bit-identical whichever GPU produced it.  A user-pinned
-    DDMI_TUNE_FILE is respected as is.  The per-process plan file this function creates is marked (DDMI_TUNE_SHARED) so that a
-    LATER call in the same process runs the same protocol again (rank 0 tunes the new network's shapes into the file, the
-    others receive the whole text) instead of mistaking the file for a user's; it is removed at exit.  If rank 0's finalize
-    raises, the error text is broadcast and every rank raises - nobody waits in the collective.  Returns the plan file path."""
+    DDMI_TUNE_FILE is respected as is.  The per-process plan file this function creates is remembered in a MODULE variable and
+    put into the environment only while `finalize()` runs (the library reads DDMI_TUNE_FILE at finalize): a LATER call in the
+    same process runs the same protocol again on the same file (rank 0 tunes the new network's shapes into it, the others receive
+    the whole text), and a child process started in between (tests, the self-launcher, a build) never inherits a pid-named path it
+    would overwrite or outlive.  The file is removed at exit.  If rank 0's finalize raises, the error text is broadcast and every
+    rank raises - nobody waits in the collective.  Returns the plan file path."""
+    global _SHARED_PLAN_PATH
     if world == 1 or not dist.is_initialized():
         finalize()
         return os.environ.get("DDMI_TUNE_FILE")
-    shared = os.environ.get("DDMI_TUNE_SHARED") == "1"
-    if os.environ.get("DDMI_TUNE_FILE") and not shared:
+    if os.environ.get("DDMI_TUNE_FILE"):   # the user's file: never ours (ours is not left in the environment)
         finalize()
         return os.environ.get("DDMI_TUNE_FILE")
-    import atexit
-    import tempfile
-    path = os.environ.get("DDMI_TUNE_FILE") if shared else \
-        os.path.join(tempfile.gettempdir(), f"ddmi_conv_plans_{os.getpid()}_rank{rank}.txt")
-    if not shared:
-        _SHARED_PLAN_FILES.append(path)
-        if len(_SHARED_PLAN_FILES) == 1:
-            atexit.register(_drop_shared_plan_files)
-        os.environ["DDMI_TUNE_FILE"], os.environ["DDMI_TUNE_SHARED"] = path, "1"
+    if _SHARED_PLAN_PATH is None:
+        import atexit
+        import tempfile
+        _SHARED_PLAN_PATH = os.path.join(tempfile.gettempdir(), f"ddmi_conv_plans_{os.getpid()}_rank{rank}.txt")
+        atexit.register(_drop_shared_plan_file)
+    path = _SHARED_PLAN_PATH
+
+    def finalize_on_shared_file():
+        os.environ["DDMI_TUNE_FILE"] = path
+        try:
+            finalize()
+        finally:
+            os.environ.pop("DDMI_TUNE_FILE", None)
+
     msg = [None, None]   # (plan text, error text)
     if rank == 0:
         try:
-            finalize()
+            finalize_on_shared_file()
             msg[0] = open(path).read() if os.path.exists(path) else ""
         except BaseException as e:   # the other ranks are waiting in the broadcast: tell them before re-raising
             msg[1] = f"{type(e).__name__}: {e}"
@@ -121,7 +127,7 @@ def finalize_with_shared_plans(finalize: Callable[[], object], rank: int, world:
     if rank != 0:
         with open(path, "w") as f:
             f.write(msg[0])
-        finalize()
+        finalize_on_shared_file()
     return path
 
 

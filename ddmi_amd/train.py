@@ -630,6 +630,15 @@ def ema_pytorch_plan(step: int, beta: float, update_every: int, update_after_ste
     return "lerp", float(min(max(value, min_value), beta))
 
 
+def module_parameters_order(names):
+    """The order `nn.Module.parameters()` yields parameters named `names` (given in any order): the root module's OWN parameters
+    (no dot in the name) first, then the submodules' - `named_parameters()` walks `named_modules()`, root first.  For the reference's
+    `DDPM` that puts `mixing_logit` (ddpm.py:156) at index 0 of `AdamW(diffusion_process.parameters())` (tools/ldm/image.py:62) and
+    `model.*` after it, whatever the registration order of the two was."""
+    names = list(names)
+    return [k for k in names if "." not in k] + [k for k in names if "." in k]
+
+
 class LDMTrainStep:
     """`DDPM.forward` + backward + optimizer step of the reference's LDM trainer on one GPU of a data-parallel job.
 
@@ -664,6 +673,8 @@ class LDMTrainStep:
         self.ema: Optional[torch.Tensor] = None
         self.opt_step = 0
         self.micro = 0
+        self.epoch = 0               # the reference trainer's `step`: finished EPOCHS (tools/ldm/image.py:145, 205), set by the caller's loop
+        self.current_iters = 0       # the reference's `current_iters`: micro-steps so far
         self.use_graph = bool(use_graph)     # replay the micro-step as a hipGraph (see _graphed_micro)
         self._graphs: Dict[tuple, object] = {}
         self._graph_generation = 0
@@ -675,6 +686,18 @@ class LDMTrainStep:
             yield "model." + k, p
         if self.mixing_logit is not None:
             yield "mixing_logit", self.mixing_logit
+
+    def optimizer_order(self):
+        """(name, parameter, offset in the flat slab) in the order `torch.optim.AdamW(diffusion_process.parameters())` indexes them
+        (tools/ldm/image.py:62): `nn.Module.parameters()` yields the ROOT module's own parameters first - `mixing_logit` (ddpm.py:156)
+        is index 0 when present - and the `model` submodule's after it.  The flat slab keeps the state-dict order of
+        named_parameters(); only `dae_opt` is indexed this way."""
+        named, off, offs = list(self.named_parameters()), 0, {}
+        for k, p in named:
+            offs[k] = off
+            off += p.numel()
+        by_name = dict(named)
+        return [(k, by_name[k], offs[k]) for k in module_parameters_order(k for k, _ in named)]
 
     def load_state_dict(self, state, strict=True):
         own = dict(self.named_parameters())
@@ -732,8 +755,16 @@ class LDMTrainStep:
             for dst, src in zip(bufs, (z0, t, noise)):
                 dst.copy_(src)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = self._micro_body(*bufs)
+            try:
+                with torch.cuda.graph(graph):
+                    loss = self._micro_body(*bufs)
+            except _lib.DdmiError:
+                # e.g. the scratch arena had to grow for this shape inside the capture (train_capi.hip reserve() refuses that): the
+                # context manager has ended the capture; drop the half-built graph, run this step eagerly (which grows the arena) and
+                # record again on the next call of the shape
+                del graph
+                self._graphs[key] = "warm"
+                return self._micro_body(z0, t, noise)
             g = self._graphs[key] = (graph, bufs, loss)
         else:
             for dst, src in zip(g[1], (z0, t, noise)):
@@ -755,6 +786,7 @@ class LDMTrainStep:
         noise = noise.to(self.device, torch.float32).contiguous()
         loss = self._graphed_micro(z0, t, noise) if self.use_graph else self._micro_body(z0, t, noise)
         self.micro += 1
+        self.current_iters += 1       # tools/ldm/image.py:166
         return loss
 
     def optimizer_step(self, world_size: int = 1):
@@ -796,27 +828,31 @@ class LDMTrainStep:
 
     def checkpoint(self, vaemodel_state=None, mlp_state=None, args=None) -> Dict[str, object]:
         """`diffusion` = DDPM.state_dict() (model.*, mixing_logit, the schedule buffers); `ema` = ema_pytorch's state dict
-        (initted, step, online_model.*, ema_model.*); `dae_opt` = torch.optim.AdamW.state_dict() over `parameters()` order (model.*
-        then mixing_logit, the registration order of ddpm.py:124/156), so the reference's strict loads and its resume accept it."""
+        (initted, step, online_model.*, ema_model.*); `dae_opt` = torch.optim.AdamW.state_dict() indexed in `parameters()` order
+        (optimizer_order: mixing_logit first, then model.*), so the reference's strict loads and its resume accept it.  `step` is
+        the reference's EPOCH counter (`while self.step < self.epochs`, tools/ldm/image.py:145) and `current_iters` its micro-step
+        counter; the optimizer-step count lives only inside dae_opt's per-parameter `step`."""
         named = list(self.named_parameters())
         bufs = self._schedule_buffers()
         sd = {k: p.detach().clone() for k, p in named}
         sd.update(bufs)
         ema, opt_state, off = {"initted": torch.tensor(bool(self.ema_initted)), "step": torch.tensor(int(self.ema_step))}, {}, 0
-        for i, (k, p) in enumerate(named):
+        for k, p in named:
             n = p.numel()
             ema["online_model." + k] = p.detach().clone()
             ema["ema_model." + k] = self.ema[off:off + n].view(p.shape).clone()
-            opt_state[i] = {"step": torch.tensor(float(self.opt_step)), "exp_avg": self.flat.exp_avg[off:off + n].view(p.shape).clone(),
-                            "exp_avg_sq": self.flat.exp_avg_sq[off:off + n].view(p.shape).clone()}
             off += n
+        for i, (k, p, o) in enumerate(self.optimizer_order()):
+            n = p.numel()
+            opt_state[i] = {"step": torch.tensor(float(self.opt_step)), "exp_avg": self.flat.exp_avg[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat.exp_avg_sq[o:o + n].view(p.shape).clone()}
         for k, v in bufs.items():
             ema["online_model." + k] = v.clone()
             ema["ema_model." + k] = v.clone()
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(named)))}
-        return {"args": dict(args) if args else {"ddpmconfig": dict(self._ddpmconfig)}, "step": self.opt_step,
-                "current_iters": self.opt_step * self.accum, "vaemodel": vaemodel_state or {}, "mlp": mlp_state or {},
+        return {"args": dict(args) if args else {"ddpmconfig": dict(self._ddpmconfig)}, "step": int(self.epoch),
+                "current_iters": int(self.current_iters), "vaemodel": vaemodel_state or {}, "mlp": mlp_state or {},
                 "diffusion": sd, "ema": ema, "dae_opt": {"state": opt_state if self.opt_step > 0 else {}, "param_groups": [group]},
                 "scaler": None}
 
@@ -847,15 +883,23 @@ class LDMTrainStep:
                 return self
             opt = ck.get("dae_opt") or {}
             if "state" in opt:
-                off, steps = 0, []
-                for i, (k, p) in enumerate(named):
+                steps = []
+                order = self.optimizer_order()
+                extra = [i for i in opt["state"] if not (isinstance(i, int) and 0 <= i < len(order))]
+                if extra:
+                    raise ValueError(f"dae_opt holds state for parameter indices {extra[:5]} but the model has {len(order)} parameters")
+                for i, (k, p, o) in enumerate(order):   # index i of AdamW(parameters()): mixing_logit first, then model.*
                     n = p.numel()
                     st = opt["state"].get(i)
                     if st is not None:
-                        self.flat.exp_avg[off:off + n].copy_(torch.as_tensor(st["exp_avg"]).to(self.device, torch.float32).reshape(-1))
-                        self.flat.exp_avg_sq[off:off + n].copy_(torch.as_tensor(st["exp_avg_sq"]).to(self.device, torch.float32).reshape(-1))
+                        for key in ("exp_avg", "exp_avg_sq"):
+                            if tuple(torch.as_tensor(st[key]).shape) != tuple(p.shape):
+                                raise ValueError(f"dae_opt state {i} ({key}) has shape {tuple(torch.as_tensor(st[key]).shape)} but parameter "
+                                                 f"{i} of parameters() is '{k}' {tuple(p.shape)}: the checkpoint was written for another "
+                                                 "parameter order or model")
+                        self.flat.exp_avg[o:o + n].copy_(torch.as_tensor(st["exp_avg"]).to(self.device, torch.float32).reshape(-1))
+                        self.flat.exp_avg_sq[o:o + n].copy_(torch.as_tensor(st["exp_avg_sq"]).to(self.device, torch.float32).reshape(-1))
                         steps.append(int(float(st["step"])))
-                    off += n
                 if steps:
                     assert min(steps) == max(steps), "the fused AdamW keeps ONE step count for every parameter"
                     self.opt_step = steps[0]
@@ -866,8 +910,11 @@ class LDMTrainStep:
                 self.flat.exp_avg.copy_(torch.as_tensor(opt["exp_avg"]).to(self.device, torch.float32))
                 self.flat.exp_avg_sq.copy_(torch.as_tensor(opt["exp_avg_sq"]).to(self.device, torch.float32))
                 self.opt_step = int(opt.get("step", 0))
-            if "step" in ck and "state" not in opt and "exp_avg" not in opt:
-                self.opt_step = int(ck["step"])
+            # the trainer's own counters: `step` = finished epochs, `current_iters` = micro-steps (tools/ldm/image.py:127-128); the
+            # accumulation phase follows from the latter.  Neither is the AdamW bias-correction step (that is dae_opt's).
+            self.epoch = int(ck.get("step", 0) or 0)
+            self.current_iters = int(ck.get("current_iters", 0) or 0)
+            self.micro = self.current_iters % self.accum
         return self
 
     def train_step(self, z0, t=None, noise=None, world_size: int = 1):

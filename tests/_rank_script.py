@@ -34,8 +34,9 @@ slab = torch.arange(10, dtype=torch.float32, device=dev) * (rank + 1)
 allreduce_gradients(slab, world, bucket_bytes=16)          # 4-element buckets: three collectives
 rec["grad_slab"] = slab.tolist()
 os.environ.pop("DDMI_TUNE_FILE", None)
-os.environ.pop("DDMI_TUNE_SHARED", None)
 D.finalize_with_shared_plans(fake_finalize, rank, world)
+# the per-process plan file is remembered in the module, not left in the environment for child processes to inherit
+rec["env_after_finalize"] = os.environ.get("DDMI_TUNE_FILE")
 
 
 def second_finalize():

@@ -67,6 +67,8 @@ def test_self_launch_starts_the_ranks(tmp_path):
         assert rec["finalized_from"] == "v 2\nplans tuned by rank 0\n"
         # a later finalize in the same process shares again (the first call's plan file is not mistaken for a user's) ...
         assert rec["second_from"] == "v 2\nplans tuned by rank 0\nsecond network, tuned by rank 0\n"
+        # ... without leaving its pid-named plan path in the environment for child processes to inherit (round-3 advisor item)
+        assert rec["env_after_finalize"] is None
         # ... and rank 0's failure is every rank's failure, not a hang in the broadcast
         assert rec["failure"] and "no such weight" in rec["failure"] and "finalized_after_failure" not in rec
         # the training step's bucketed gradient all-reduce: rank r held (r + 1) * arange(10) -> the sum is 3 * arange(10)

@@ -134,22 +134,41 @@ def test_training_resume_restores_ema_optimizer_and_counters(golden, tmp_path):
     a.ema_update_after_step = 1
     for i in range(4):
         a.train_step(x0, ts(i), nz)
+    a.epoch = 2                                                            # the caller's epoch loop owns the reference's `step`
     path = os.path.join(tmp_path, "ldm-last.pt")
     a.save(path)
     ck = torch.load(path, map_location="cpu", weights_only=True)          # plain containers and tensors only
     assert {"args", "step", "current_iters", "vaemodel", "mlp", "diffusion", "dae_opt", "ema", "scaler"} <= set(ck)
     assert ck["diffusion"]["betas"].shape == (1000,) and "ema_model.betas" in ck["ema"] and "online_model.mixing_logit" in ck["ema"]
-    assert int(ck["ema"]["step"]) == 4 and bool(ck["ema"]["initted"]) and ck["step"] == 4
-    params = [torch.nn.Parameter(torch.zeros_like(p.detach().cpu())) for _, p in a.named_parameters()]
+    # `step` = finished EPOCHS, `current_iters` = micro-steps (tools/ldm/image.py:127-128, 145, 166); optimizer steps live in dae_opt only
+    assert int(ck["ema"]["step"]) == 4 and bool(ck["ema"]["initted"]) and ck["step"] == 2 and ck["current_iters"] == 4
+    # the reference's `self.dae_opt.load_state_dict` on `AdamW(diffusion_process.parameters())` of a REAL nn.Module with the same
+    # structure (a direct `mixing_logit` parameter + a `model` submodule): index 0 is mixing_logit, and every moment lands on a
+    # parameter of its own shape
+    class Holder(torch.nn.Module):
+        def __init__(self, named):
+            super().__init__()
+            self.model = torch.nn.ParameterDict()      # registered first, like DDPM.model (ddpm.py:124)
+            for k, p in named:
+                if k.startswith("model."):
+                    self.model[k[6:].replace(".", "__")] = torch.nn.Parameter(torch.zeros_like(p.detach().cpu()))
+            self.mixing_logit = torch.nn.Parameter(torch.zeros_like(dict(named)["mixing_logit"].detach().cpu()))
+    ref_mod = Holder(list(a.named_parameters()))
+    params = list(ref_mod.parameters())
+    assert params[0] is ref_mod.mixing_logit
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0)
-    opt.load_state_dict(ck["dae_opt"])                                     # the reference's `self.dae_opt.load_state_dict`
-    assert float(opt.state[params[0]]["step"]) == 4.0
+    opt.load_state_dict(ck["dae_opt"])
+    for p_ in params:
+        assert opt.state[p_]["exp_avg"].shape == p_.shape and float(opt.state[p_]["step"]) == 4.0
+    off = dict((k, o) for k, _, o in a.optimizer_order())["mixing_logit"]
+    assert torch.equal(opt.state[params[0]]["exp_avg"].reshape(-1), a.flat.exp_avg[off:off + params[0].numel()].cpu())
+    opt.step()                                                             # shapes line up: the first step does not raise
     assert CK.checkpoint_sampler_config(ck) == {"timesteps": 1000}
     b = _toy_trainer(golden, ema_update_every=1)
     b.load_state_dict({k: v for k, v in ck["diffusion"].items() if k.startswith("model.") or k == "mixing_logit"}, strict=True).finalize()
     b.ema_update_after_step = 1
     b.load_training_state(CK.read_checkpoint(path), resume=True)
-    assert b.opt_step == 4 and b.ema_step == 4 and b.ema_initted
+    assert b.opt_step == 4 and b.ema_step == 4 and b.ema_initted and b.epoch == 2 and b.current_iters == 4 and b.micro == 0
     assert torch.equal(b.flat.data, a.flat.data) and torch.equal(b.ema, a.ema)
     assert torch.equal(b.flat.exp_avg, a.flat.exp_avg) and torch.equal(b.flat.exp_avg_sq, a.flat.exp_avg_sq)
     for i in range(4, 6):
