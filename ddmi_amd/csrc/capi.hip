@@ -746,26 +746,34 @@ int ddmi_bench_attention_block(int B, int C, int H, int W, int iters, double* us
   if (getenv("DDMI_ATTNBLOCK_TS") && fused_used && *fused_used) {   // per-workgroup phase timeline of the fused launch
     const int nwg = (int)((cdiv64((int64_t)B * H * W, 1024) + 7) / 8 * 8) * (C / 32);
     void* tsd = nullptr;
-    DDMI_TRY(sc.get((size_t)nwg * 32, &tsd));
-    HIP_TRY(hipMemset(tsd, 0, (size_t)nwg * 32));
+    DDMI_TRY(sc.get((size_t)nwg * 128, &tsd));
+    HIP_TRY(hipMemset(tsd, 0, (size_t)nwg * 128));
     attnblock_debug_ts((unsigned long long*)tsd);
     rc = u.net.run(B, ext, nullptr, 0, 0);
     attnblock_debug_ts(nullptr);
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<unsigned long long> tsh((size_t)nwg * 4);
-    HIP_TRY(hipMemcpy(tsh.data(), tsd, (size_t)nwg * 32, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tsh((size_t)nwg * 16);
+    HIP_TRY(hipMemcpy(tsh.data(), tsd, (size_t)nwg * 128, hipMemcpyDeviceToHost));
     double pa = 0, pb = 0, pc = 0;
     unsigned long long t_min = ~0ull, t_max = 0;
     int cnt = 0;
+    double pw[8] = {0}, cyc_a = 0, cyc_b = 0;
     for (int i = 0; i < nwg; ++i) {
-      if (!tsh[4 * i]) continue;
-      pa += (double)(tsh[4 * i + 1] - tsh[4 * i]);
-      pb += (double)(tsh[4 * i + 2] - tsh[4 * i + 1]);
-      pc += (double)(tsh[4 * i + 3] - tsh[4 * i]);
-      t_min = std::min(t_min, tsh[4 * i]);
-      t_max = std::max(t_max, tsh[4 * i + 2]);
+      const unsigned long long* t = &tsh[16 * i];
+      if (!t[0]) continue;
+      pa += (double)(t[1] - t[0]);
+      pb += (double)(t[2] - t[1]);
+      pc += (double)(t[3] - t[0]);
+      for (int w = 0; w < 8; ++w) pw[w] += (double)(t[4 + w] - t[1]);
+      cyc_a += (double)(t[13] - t[12]);
+      cyc_b += (double)(t[14] - t[13]);
+      t_min = std::min(t_min, t[0]);
+      t_max = std::max(t_max, t[3]);
       ++cnt;
     }
+    fprintf(stderr, "[attnblock ts] attention phase per wave (us):");
+    for (int w = 0; w < 8; ++w) fprintf(stderr, " %.1f", pw[w] / cnt * 0.01);
+    fprintf(stderr, "; shader clock: projection %.2f GHz, attention %.2f GHz\n", cyc_a / (pa * 10.0), cyc_b / (pb * 10.0));
     fprintf(stderr, "[attnblock ts] C=%d %dx%d B=%d: %d workgroups, projection %.2f us, attention %.2f us (wave 0), workgroup %.2f us (means), launch span %.1f us\n",
             C, H, W, B, cnt, pa / cnt * 0.01, pb / cnt * 0.01, pc / cnt * 0.01, (double)(t_max - t_min) * 0.01);
   }

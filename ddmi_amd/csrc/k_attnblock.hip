@@ -11,7 +11,9 @@
 //                row-major tensor every 16-lane group of a load touched 16 cache lines: 12 B/clk per CU, the projection ran at
 //                a quarter of the MFMA rate); wave w owns rows [128 w, 128 w + 128) in two passes of 64;
 //              - the head's weights stream through a 2 x 12 KB LDS stage per 64-channel chunk by LDS-DMA from a host-packed image
-//                that already IS the swizzled LDS layout (a linear 12 KB copy), one chunk ahead of its MFMAs, one barrier per chunk;
+//                that already IS the swizzled LDS layout (a linear 12 KB copy), one chunk ahead of its MFMAs, one barrier per chunk
+//                (measured and dropped: a four-stage ring in the unwritten halves of the K / V rows, three chunks ahead - 24.1 vs 19.7 us
+//                per projection; the second pass's first chunk fetched under the first pass's last step - 20.1 vs 19.6);
 //              - K and V land in LDS for all 1024 rows (2 x 64 KB, the attention kernel's row layouts); Q never leaves registers:
 //                the wave that projected a row is the wave that runs that row's queries (8 B fragments = 32 VGPRs).
 //   Phase B  attention_v2_kernel's lazy-maximum loop (k_attention.hip) over the LDS-resident K / V of the query's own sample:
@@ -35,6 +37,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef AB_OUT_SC1
 #define AB_OUT_SC1 1
 #endif
+#ifndef AB_PRIO
+#define AB_PRIO 1
+#endif
 #define AB_ROWS 1024                 // token rows per workgroup
 #define AB_KV_BYTES (AB_ROWS * 64)   // one of K / V: [row][32 channels] bf16
 #define AB_WCHUNK (96 * 128)         // one 64-channel chunk of a head's [96][C] weights: [96 rows][128 B]
@@ -47,7 +52,7 @@ struct AttnBlockK {
   unsigned x_bytes;
   int rows;        // B * N valid token rows
   int N, C, heads, groups, xcd;
-  unsigned long long* ts;   // diagnostics (attnblock_debug_ts): per workgroup [start, projection done, attention done] in 100 MHz ticks
+  unsigned long long* ts;   // diagnostics (attnblock_debug_ts): 16 words per workgroup, 100 MHz ticks and shader-clock stamps
 };
 
 // K rows: attention_v2's 64-byte-row swizzle (conflict-free ds_read_b128 fragments); V rows: its transposed-read swizzle
@@ -82,8 +87,8 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
   }
   const int N = a.N, C = a.C, NC = C >> 6;
   const int row0 = g * AB_ROWS;
-  unsigned long long* const ts = a.ts && tid == 0 ? a.ts + 4 * blockIdx.x : nullptr;
-  if (ts) ts[0] = wall_clock64();
+  unsigned long long* const ts = a.ts && tid == 0 ? a.ts + 16 * blockIdx.x : nullptr;
+  if (ts) { ts[0] = wall_clock64(); ts[12] = __builtin_amdgcn_s_memtime(); }
   auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.w + (size_t)h * NC * AB_WCHUNK), 0, NC * AB_WCHUNK, 0x00020000);
   const float* const biasp = a.bias + h * 96;
@@ -182,7 +187,7 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
     __syncthreads();   // the weight stages are free for the next pass; after the second pass: every K / V row is visible
   }
 
-  if (ts) ts[1] = wall_clock64();
+  if (ts) { ts[1] = wall_clock64(); ts[13] = __builtin_amdgcn_s_memtime(); }
   // ================= Phase B: attention over the LDS-resident K / V (attention_v2_kernel's LAZY loop, D = 32) =============
   constexpr int RB = 64, KT = 64, NDF = 2;
   bf16x8 ones;
@@ -195,6 +200,13 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
   const int ntiles = N / KT;
 #pragma unroll
   for (int rnd = 0; rnd < 8 / QF; ++rnd) {
+#if AB_PRIO
+    // The two waves of a SIMD (w and w + 4) run this VALU-bound loop without a barrier between them, and the issue arbiter prefers the
+    // OLDER one (MI355X_MICROARCH.md, two waves per SIMD): waves 0-3 finished after 34.5 us, waves 4-7 after 51.1, the SIMD half idle
+    // in between.  Alternating the priority by round they end after 43.6 / 47.6 us (workgroup 70.9 -> 67.5 us).
+    // The younger wave holds the priority for the first two thirds of its tiles (with the older one running at ~0.5 of its unimpeded
+    // rate meanwhile, both end together when the switch sits at 1 / (1 + 0.5) of the work), the older one afterwards.
+#endif
     const int qrow0 = wave * 128 + rnd * QF * 16;
     const int keybase = qrow0 & ~(N - 1);   // the query's own sample inside the group (N is a power of two)
     float m_run[QF];
@@ -206,15 +218,26 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
 #pragma unroll
       for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
     }
+    // per-lane LDS cursors, advanced by one 64-key tile per trip; everything else in the loop's addresses is an instruction offset
+    const unsigned char* kp = Ks + (keybase + lr) * RB + ab_kswz(lr, lg) * 16;   // (the K swizzle only looks at row bits 2-3)
+    const unsigned char* vp[NDF];
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) vp[df] = Vs + keybase * RB + vbase + (((2 * df + (tp >> 1)) ^ vsw) << 4);
 #pragma unroll 1
-    for (int kt = 0; kt < ntiles; ++kt) {
-      const unsigned char* kb = Ks + (keybase + kt * KT) * RB;
-      const unsigned char* vb = Vs + (keybase + kt * KT) * RB;
+    for (int kt = 0; kt < ntiles; ++kt, kp += KT * RB, vp[0] += KT * RB, vp[1] += KT * RB) {
+#if AB_PRIO
+      {
+        const int prog = rnd * ntiles + kt, sw = (2 * (8 / QF) * ntiles + 1) / 3;
+        if (prog == 0 || prog == sw) {
+          if ((((wave >> 2) ^ (prog == 0 ? 0 : 1)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
+#endif
       f32x4 sc[QF][4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const int row = 16 * f + lr;
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * RB + ab_kswz(row, lg) * 16);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + 16 * f * RB);
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
           const float init = -m_run[qf];
@@ -266,11 +289,10 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
         for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
 #pragma unroll
         for (int df = 0; df < NDF; ++df) {
-          const int coff = ((2 * df + (tp >> 1)) ^ vsw) << 4;
           typedef short s16x4 __attribute__((ext_vector_type(4)));
           typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + vbase + (32 * u) * RB + coff));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + vbase + (32 * u + 16) * RB + coff));
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vp[df] + (32 * u) * RB));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vp[df] + (32 * u + 16) * RB));
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (k_attention.hip: the element-wise one miscompiles)
@@ -301,8 +323,9 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
 #endif
     }
   }
-  if (a.ts) {   // diagnostics only: when the slowest wave is done
-    if (ts) ts[2] = wall_clock64();
+  if (a.ts) {   // diagnostics only: when each wave, and the slowest, is done (+ shader-clock stamps: cycles / 100 MHz ticks = the clock held)
+    if (lane == 0) a.ts[16 * blockIdx.x + 4 + wave] = wall_clock64();
+    if (ts) { ts[2] = wall_clock64(); ts[14] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
     if (ts) ts[3] = wall_clock64();
   }
@@ -370,7 +393,7 @@ int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, vo
   k.ts = g_ab_ts;
   const int gpad = k.xcd ? cdiv(k.groups, 8) * 8 : k.groups;
   constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK;
-  static int qf_env = getenv("DDMI_ATTNBLOCK_QF") ? atoi(getenv("DDMI_ATTNBLOCK_QF")) : 2;
+  static int qf_env = getenv("DDMI_ATTNBLOCK_QF") ? atoi(getenv("DDMI_ATTNBLOCK_QF")) : 4;   // 64 queries per wave and round: 63.0 vs 66.5 us per workgroup at 32x32
   auto k2 = attnblock_kernel<2>;
   auto k4 = attnblock_kernel<4>;
   static bool attr_set = false;

@@ -260,6 +260,6 @@ size_t attnblock_weight_bytes(int C, int heads);
 void attnblock_pack_weights(const float* w_qkv, const float* b_qkv, int C, int heads, uint16_t* wp, float* bp);
 // x: the normalised activations in FRAGMENT order (launch_gn_apply frag_out) -> out [B N][C] (attention output, head h at channels [32 h, 32 h + 32)); q rows of the packed
 // projection carry softmax scale x log2 e
-// diagnostics: 4 x 64-bit words per workgroup (start, projection done, attention done; wave 0's view), null = off
+// diagnostics: 16 x 64-bit words per workgroup (start, projection done, wave 0 done, all done, then each wave's end), null = off
 void attnblock_debug_ts(unsigned long long* buf);
 int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, void* out, int B, int N, int C, int heads, hipStream_t s);
