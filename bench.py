@@ -124,7 +124,9 @@ def _profile_entry(glob_pat, live_name):
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
-        alias = {"mlp2d_fused": "mlp2d_v2_kernel", "mlp3d_fused": "mlp3d_v2_kernel", "mlpvideo_fused": "mlpv_v2_kernel"}
+        alias = {"mlp2d_fused": "mlp2d_v2_kernel", "mlp3d_fused": "mlp3d_v2_kernel", "mlpvideo_fused": "mlpv_v2_kernel",
+                 "attention_legacy": "attention_v2_kernel", "attention_mh": "attention_", "attnblock_qkv_attn": "attnblock_kernel",
+                 "wgrad_tn": "wgrad_tn_kernel"}
         pat = re.compile(re.escape(alias.get(live_name, live_name.split("<")[0])))
     with open(files[-1]) as f:
         doc = json.load(f)
@@ -136,11 +138,15 @@ def _profile_entry(glob_pat, live_name):
     return None
 
 
-def pmc_traffic(live_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+# the committed PMC summaries are per workload: profiles/<round>_pmc_traffic_<suffix>*.json (tools/gpu_profiles.sh, tools/gpu_pmc_workload.sh)
+PMC_TRAFFIC_SUFFIX = {"afhq": "b512", "shapenet": "shapenet", "sky": "sky", "train": "train"}
+
+
+def pmc_traffic(live_name, workload="afhq"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THAT workload (profiles/*_pmc_traffic_<suffix>*.json:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, gfx950 corrections applied).
     The newest file wins; a kernel that is not in it reports null rather than a stale number."""
-    v = _profile_entry("*pmc_traffic*.json", live_name)
+    v = _profile_entry(f"*pmc_traffic_{PMC_TRAFFIC_SUFFIX.get(workload, workload)}*.json", live_name)
     return (v["hbm_bytes_per_launch"], v["_source"]) if v else (None, None)
 
 
@@ -156,16 +162,31 @@ def effective_clock(live_name, achieved_tflops):
             "profile": v["_source"]}
 
 
-def roofline_of(prof, pick):
+_MEASURED_PEAKS = None
+
+
+def measured_peaks():
+    """the pure-MFMA and the device-copy microbenchmarks, run ONCE per process before any timed region (~2 s): the rates
+    this box sustains, quoted beside the nominal 2.5 PFLOP/s / 8 TB/s (`frac` stays against the nominal peak, `frac_of_measured` is new)."""
+    global _MEASURED_PEAKS
+    if _MEASURED_PEAKS is None:
+        from ddmi_amd import _lib
+        _MEASURED_PEAKS = _lib.measured_peaks(mfma_seconds=1.0, copy_gib=2.0)
+    return _MEASURED_PEAKS
+
+
+def roofline_of(prof, pick, workload="afhq"):
     """`pick(prof) -> kernel key`; achieved = algorithmic FLOPs of the timed launches / their HIP-event time."""
     dom = pick(prof)
     if not dom:
         return None
     d = prof[dom]
     ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic(dom)
+    traffic, traffic_src = pmc_traffic(dom, workload)
+    mp = measured_peaks()
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_profile": traffic_src, "clock": effective_clock(dom, ach),
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "measured_peak": mp, "frac_of_measured": round(ach / mp["mfma_bf16_tflops"], 4),
+            "traffic": traffic, "traffic_profile": traffic_src, "clock": effective_clock(dom, ach),
             "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_timed": d["launches"],
             "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
             "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
@@ -422,7 +443,7 @@ def run_shapenet(args, rank, local_rank, world, dev):
     _lib.profile_enable(0)
     if rank != 0:
         return None
-    roof = roofline_of(p1, lambda p: "mlp3d_fused" if "mlp3d_fused" in p else None)
+    roof = roofline_of(p1, lambda p: "mlp3d_fused" if "mlp3d_fused" in p else None, "shapenet")
     tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
     line = {"metric": "shapes/sec (whole node), ShapeNet occupancy: 250-step DDPM + tri-plane decode + 128^3 MLP3D grid + marching cubes",
             "value": args.steps * world * B / elapsed, "unit": "shapes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -536,8 +557,8 @@ def run_sky(args, rank, local_rank, world, dev):
             "config": {"workload": f"SkyTimelapse (configs/ldm/skytimelapse.yaml nets), {args.nfe}-step DDPM on the [64,2048] tri-plane token latent, "
                                    "VITAutoencoder.decode (VideoDecoder_light), MLPVideo over 16x256x256; random-init named-seed weights",
                        "batch_per_gpu": B, "global_batch": world * B, "nfe": args.nfe, "parallelism": f"sample-parallel x{world}"},
-            "nccl_ranks": nranks, "roofline": roofline_of(prof, dom),
-            "decode_mlp_one_clip": {"roofline": roofline_of(p1, dom), "kernel_ms": round(sum(v["total_ms"] for v in p1.values()), 2),
+            "nccl_ranks": nranks, "roofline": roofline_of(prof, dom, "sky"),
+            "decode_mlp_one_clip": {"roofline": roofline_of(p1, dom, "sky"), "kernel_ms": round(sum(v["total_ms"] for v in p1.values()), 2),
                                     "mlpv_ms": round(p1["mlpv_fused"]["total_ms"], 3) if "mlpv_fused" in p1 else None},
             "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}}
     if not args.no_cpu_baseline and world == 1:
@@ -618,11 +639,42 @@ def run_train(args, rank, local_rank, world, dev):
                                    "fp32 master weights, bf16 activations" + ("" if args.no_graph else "; micro-step replayed as one hipGraph"), "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"data-parallel x{world} (one 2.08 GB gradient all-reduce per step, two 1 GiB buckets)"},
             "nccl_ranks": nranks, "loss_last_step": float(loss),
-            "roofline": dict(roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None) or {}, traffic=None),
+            "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None, "train"),
             "step_mfma_frac": round(flops / elapsed / 1e12 / PEAK_BF16_TFLOPS / world, 4),
             "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
             "profiled_kernel_ms_per_step": round(tot_ms, 1)}
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_train()
     return line
+
+
+def cpu_baseline_train():
+    """The oracle's training step on the host (kind 'port'): `p_losses` + torch autograd through the full 519 M-parameter AFHQ UNet at
+    B = 1 (the forward the headline's cpu_baseline times, plus its backward) and one torch.optim.AdamW step - ONE step, ~30-60 s."""
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.unet import unet_manifest
+    from oracle import ddmi_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = AFHQ["unetconfig"]
+    st = iw.fill_state("afhq.unet", unet_manifest(**cfg))
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in st.items()}
+    logit = torch.full((1, 64, 1, 1), -6.0, requires_grad=True)
+    x0 = torch.from_numpy(iw.normal("bench", "train_z", (1, 64, 64, 64)))
+    nz = torch.from_numpy(iw.normal("bench", "train_noise", (1, 64, 64, 64)))
+    opt = torch.optim.AdamW(list(p.values()) + [logit], lr=1e-4, weight_decay=0.0)
+    t0 = time.perf_counter()
+    loss = O.p_losses(p, cfg, O.make_schedule(1000), logit, x0, torch.tensor([500]), nz)
+    loss.backward()
+    t_fb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    opt.step()
+    t_opt = time.perf_counter() - t0
+    return {"value": 1.0 / (t_fb + t_opt), "unit": "samples/sec", "cores": cores, "kind": "port",
+            "sample": f"one training step at B = 1 on the full AFHQ UNet: oracle p_losses + torch autograd ({t_fb:.1f} s) + torch.optim.AdamW.step "
+                      f"({t_opt:.1f} s), timed in full (no extrapolation)",
+            "forward_backward_s": t_fb, "adamw_s": t_opt}
 
 
 def main():
@@ -659,6 +711,9 @@ def main():
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     runners = {"afhq": run_afhq, "shapenet": run_shapenet, "sky": run_sky, "train": run_train}
+    from ddmi_amd import _lib
+    _lib.init_device(local_rank)
+    measured_peaks()   # the two ~1 s microbenchmarks, before any timed region (every rank: the ranks stay in step)
     line = runners[args.workload](args, rank, local_rank, world, dev)
     if args.workload == "afhq" and not args.no_workloads and args.nfe == NFE:
         # BASELINE configs 4 and 5 and the training step ride behind the headline run - one timed step each, same contract, so that
@@ -666,18 +721,18 @@ def main():
         import copy
         import gc
         extra = {}
-        for name, steps, warm in (("shapenet", 1, 1), ("sky", 1, 0), ("train", 3, 1)):
+        for name, steps, warm in (("shapenet", 2, 1), ("sky", 2, 1), ("train", 4, 1)):   # >= 1 warm-up step + >= 2 timed steps each
             gc.collect()
             torch.cuda.empty_cache()
             sub = copy.copy(args)
-            sub.workload, sub.steps, sub.warmup, sub.batch, sub.no_cpu_baseline = name, steps, warm, 0, True
+            sub.workload, sub.steps, sub.warmup, sub.batch, sub.no_cpu_baseline = name, steps, warm, 0, args.no_cpu_baseline
             t0 = time.perf_counter()
             r = runners[name](sub, rank, local_rank, world, dev)
             if rank == 0:
                 extra[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps,
                                "batch": r["config"]["batch_per_gpu"], "dtype": r["dtype"], "roofline": r["roofline"],
                                "wall_s_incl_setup": round(time.perf_counter() - t0, 1)}
-                for k in ("mlp3d_grid_ms", "decode_mlp_one_clip", "step_mfma_frac"):
+                for k in ("mlp3d_grid_ms", "decode_mlp_one_clip", "step_mfma_frac", "cpu_baseline", "kernel_time_share"):
                     if k in r:
                         extra[name][k] = r[k]
         if rank == 0:

@@ -129,6 +129,8 @@ SYMBOLS = {
     "ddmi_debug_conv_config": (_I, [_I]),
     "ddmi_op_attention_block": (_I, [_VP] * 8 + [_I] * 6 + [C.POINTER(_I)]),
     "ddmi_debug_attn_fused": (_I, [_I]),
+    "ddmi_bench_peak_mfma": (_I, [C.c_double, C.POINTER(C.c_double)]),
+    "ddmi_bench_peak_copy": (_I, [C.c_double, C.POINTER(C.c_double)]),
     "ddmi_bench_attention_block": (_I, [_I] * 5 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_op_attention_legacy_hd": (_I, [_VP, _VP, _I, _I, _I, _I, _I]),
     "ddmi_op_attention_mh": (_I, [_VP, _VP, _VP, _VP] + [_I] * 7),
@@ -219,6 +221,16 @@ def profile_collect() -> dict:
     buf = C.create_string_buffer(1 << 16)
     check(lib().ddmi_profile_collect(buf, len(buf)))
     return json.loads(buf.value.decode())
+
+
+def measured_peaks(mfma_seconds: float = 1.0, copy_gib: float = 2.0) -> dict:
+    """The two on-box microbenchmarks (k_microbench.hip): the dense bf16 MFMA rate and the device-copy bandwidth THIS GPU sustains."""
+    tf, tb = C.c_double(0.0), C.c_double(0.0)
+    check(lib().ddmi_bench_peak_mfma(float(mfma_seconds), C.byref(tf)))
+    check(lib().ddmi_bench_peak_copy(float(copy_gib), C.byref(tb)))
+    return {"mfma_bf16_tflops": round(tf.value, 1), "hbm_copy_tbs": round(tb.value, 3),
+            "how": f"pure v_mfma_f32_16x16x32_bf16 loop on random register operands, every CU, 2 waves/SIMD, ~{mfma_seconds:g} s; "
+                   f"16-byte-per-lane copy of {copy_gib:g} GiB x5, (read + written) bytes / s"}
 
 
 def stream_ptr() -> int:

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libddmi_hip.so")
 SOURCES = ["k_elementwise.hip", "k_groupnorm.hip", "k_conv.hip", "k_attention.hip", "k_attnblock.hip", "k_mlp2d.hip", "k_mlp3d.hip", "mlp3d_host.hip", "k_mlpv.hip", "mlpv_host.hip", "k_mcubes.hip", "models_video.hip", "net.hip",
-           "models.hip", "mlp2d_host.hip", "capi.hip", "prof.hip", "k_train.hip", "k_attn_bwd.hip", "train_capi.hip"]
+           "models.hip", "mlp2d_host.hip", "capi.hip", "prof.hip", "k_train.hip", "k_attn_bwd.hip", "train_capi.hip", "k_microbench.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 

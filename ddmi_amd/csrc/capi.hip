@@ -624,6 +624,15 @@ int ddmi_debug_conv_config(int cfg_id) {
   return DDMI_OK;
 }
 
+int ddmi_bench_peak_mfma(double seconds_target, double* tflops) {
+  DDMI_REQUIRE(tflops && seconds_target > 0 && seconds_target <= 10, "bench_peak_mfma: bad arguments");
+  return bench_peak_mfma(seconds_target, tflops, nullptr);
+}
+int ddmi_bench_peak_copy(double gib, double* tb_per_s) {
+  DDMI_REQUIRE(tb_per_s && gib >= 0.25 && gib <= 32, "bench_peak_copy: bad arguments");
+  return bench_peak_copy(gib, tb_per_s);
+}
+
 int ddmi_debug_attn_fused(int mode) {
   attnblock_fused_override(mode);
   return DDMI_OK;

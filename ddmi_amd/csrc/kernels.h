@@ -263,3 +263,7 @@ void attnblock_pack_weights(const float* w_qkv, const float* b_qkv, int C, int h
 // diagnostics: 16 x 64-bit words per workgroup (start, projection done, wave 0 done, all done, then each wave's end), null = off
 void attnblock_debug_ts(unsigned long long* buf);
 int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, void* out, int B, int N, int C, int heads, hipStream_t s);
+
+// ---- on-box peak microbenchmarks (k_microbench.hip): the rates bench.py quotes its roofline fractions against besides the nominal ones ----
+int bench_peak_mfma(double seconds_target, double* tflops, double* ms_per_launch);   // pure v_mfma_f32_16x16x32_bf16, every CU, 2 waves / SIMD
+int bench_peak_copy(double gib, double* tb_per_s);                                    // 16-byte-per-lane copy: (read + written) bytes / s

@@ -485,6 +485,17 @@ static int build_vae_resblock(Net& n, const std::string& pre, int x, int cout, i
 // AttnBlock with num_heads=1 (autoencoder_unet.py:187-215; make_attn 'vanilla' :561-567)
 static int build_vae_attn(Net& n, const std::string& pre, int x, int* out) {
   const TensorDesc t = n.tensors[x];
+  // DDMI_VAE_ATTN_FLASH=1 (diagnostics): ONE fused q | k | v projection and the streaming attention kernel with a single 512-channel
+  // head (the video decoder's attention_mh<512> instantiation) instead of GEMM -> softmax -> transpose -> GEMM over a materialised
+  // [T][T] score matrix (67.6 GB per launch at the AFHQ decoder's 4096 tokens, B = 512).  Round 4 measured it (round-3 verdict item
+  // 9): the decoder took 683 ms per 512 latents against 432 ms - the generic kernel recomputes S per 256-channel value slice and
+  // runs its d = 512 QK^T from LDS at a fifth of the MFMA rate; the three GEMMs on the convolution kernels win.  Off by default.
+  static const bool flash = getenv("DDMI_VAE_ATTN_FLASH") && atoi(getenv("DDMI_VAE_ATTN_FLASH")) == 1;
+  if (flash && n.dt == DT_BF16 && !n.x3 && t.C <= 512 && t.C % 8 == 0) {
+    AttnW w;
+    DDMI_TRY(make_qkv_attn(n, pre, t.C, 1, false, &w));
+    return emit_attn_single(n, w, x, out);
+  }
   int gn, cq, ck, cv, cp;
   DDMI_TRY(n.make_gn(pre + "norm.", &gn));
   DDMI_TRY(n.make_conv(pre + "q.weight", pre + "q.bias", &cq));

@@ -344,6 +344,12 @@ int ddmi_op_attention_block(const float* x, const float* gamma, const float* bet
 int ddmi_debug_attn_fused(int mode);
 /* average device time (us) of one bf16 AttentionBlock with num_head_channels 32 on device-resident pseudo-random data */
 int ddmi_bench_attention_block(int B, int C, int H, int W, int iters, double* us_out, int* fused_used);
+/* On-box peak microbenchmarks: what this GPU sustains, beside the nominal 2.5 PFLOP/s / 8 TB/s the rooflines are
+ * quoted against.  peak_mfma: nothing but v_mfma_f32_16x16x32_bf16 on pseudo-random register operands, every CU, two waves per SIMD,
+ * for about `seconds_target` seconds -> dense bf16 TFLOP/s.  peak_copy: a 16-byte-per-lane device copy of `gib` GiB (needs 2 x that
+ * much free memory), five repetitions -> (bytes read + bytes written) per second in TB/s. */
+int ddmi_bench_peak_mfma(double seconds_target, double* tflops);
+int ddmi_bench_peak_copy(double gib, double* tb_per_s);
 /* timestep_embedding (util.py:150-170): t [B] int64 -> [B, dim] */
 int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim);
 

@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Plan-deterministic parity runs (round-3 verdict, item 3): convolution shapes take the plans SHIPPED with the package
+# (ddmi_amd/tuned/conv_plans_mi355x.txt, picked up by ddmi_amd._lib) and the heuristic plan where that file has none - never a
+# timing-based pick of the box the test happens to run on - so the bf16 rounding order, and the metrics behind every bf16
+# threshold, are the same on every box.  A test that wants the autotuner sets DDMI_TUNE_STRICT=0 itself (before the library loads).
+os.environ.setdefault("DDMI_TUNE_STRICT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -102,3 +102,43 @@ def test_attention_block_unserved_shapes_fall_back():
     assert_bf16_close(y2.numpy() - x2, (ref2 - torch.from_numpy(x2)).numpy(), what=tag)
     y3, used3 = attention_block_op(x, p, head_channels=16, fused=1)
     assert used3 == 0
+
+
+def test_autotuned_plans_agree_with_the_pinned_ones(tmp_path):
+    """The parity suite runs plan-deterministic (DDMI_TUNE_STRICT=1, tests/conftest.py); the timing-based autotuner that bench.py and
+    production finalizes use is exercised here in a child process: the toy UNet finalized with DDMI_TUNE_STRICT=0 writes a plan file,
+    its bf16 output agrees with the pinned-plan run within the bf16 tolerance (other tiles / split-K: another rounding order, same
+    network), and a second child that READS that plan file reproduces the first child's output bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from ddmi_amd.unet import UNetModel
+from helpers import named_state
+cfg = dict(image_size=16, in_channels=64, model_channels=64, out_channels=64, attention_resolutions=[2, 1], num_res_blocks=1,
+           channel_mult=[1, 2], num_head_channels=32)
+net = UNetModel(**cfg, numerics="bf16", max_batch=2, device="cuda:0")
+net.load_state_dict(named_state("autotune.unet", net.manifest()))
+net.finalize()
+g = torch.Generator().manual_seed(3)
+x = torch.randn((2, 64, 16, 16), generator=g).to("cuda:0")
+y = net(x, torch.tensor([7, 400], device="cuda:0"))
+np.save(sys.argv[1], y.float().cpu().numpy())
+''' % (root, root)
+    outs = {}
+    for tag, env in (("strict", {"DDMI_TUNE_STRICT": "1"}),
+                     ("tuned", {"DDMI_TUNE_STRICT": "0", "DDMI_TUNE_FILE": str(tmp_path / "plans.txt")}),
+                     ("replayed", {"DDMI_TUNE_STRICT": "1", "DDMI_TUNE_FILE": str(tmp_path / "plans.txt")})):
+        out = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", script, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    plans = open(tmp_path / "plans.txt").read().splitlines()
+    assert plans[0].startswith("v ") and len(plans) > 5                     # the autotuner ran and wrote one line per shape
+    assert np.array_equal(outs["tuned"], outs["replayed"])                  # a plan file pins the result bit for bit
+    assert_bf16_close(outs["tuned"], outs["strict"], what="autotuned vs pinned plans (toy UNet)", l2=2e-2)
