@@ -173,17 +173,27 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
     if (frag_out) {
       // Output in MFMA B-fragment order for the fused attention block (k_attnblock.hip): [16-token block][32-channel k-step][lane = 16 (c >> 3
       // & 3) + (token & 15)][8 channels], so that a wave of that kernel loads a whole fragment as ONE contiguous KiB (from the
-      // row-major tensor every 16-lane group of its loads touched 16 cache lines: 12 B/clk per CU, measured).  Here the lanes of a
-      // wave take the fragment's own (token, channel vector) map: the STORE is the contiguous KiB, the load pays the 16-line
-      // pattern - on a pass that needs ~12 B/clk per CU that is free, where scattered 16-byte stores cost the pass 2x.
-      const int lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6, lr = lane & 15, lg = lane >> 4;
-      const int KS = C >> 5, TB = HW >> 4;
+      // row-major tensor every 16-lane group of its loads touched 16 cache lines: 12 B/clk per CU, measured).
+      // A wave takes [16 tokens][64 channels] items: two loads of 8 whole 128-byte row pieces (lane = 8 (token & 7) + 16-byte piece), the
+      // affine transform on the lane's fixed 8 channels, then a transpose THROUGH LDS (padded: the 8 lanes of a ds_write_b128 group
+      // hit 32 different banks) into the two fragments, which leave as two contiguous-KiB stores.  (Round 4 first stored the
+      // fragments' scattered 16-byte pieces straight from the row-major lane map - the pass took 2x - and then loaded with the
+      // fragment's lane map, 16 cache lines per 16-lane group: +47 %.)
+      extern __shared__ double gn_dyn[];
+      constexpr int FRAG_PAD = 1088, ITEM_BYTES = 2 * FRAG_PAD, UF = 4;   // per k-step: 4 x (256 + 16) bytes
+      const int lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+      unsigned char* const scr = reinterpret_cast<unsigned char*>(gn_dyn) + (CHSTAT ? (size_t)2 * C * sizeof(double) : 0) + (size_t)wave * UF * ITEM_BYTES;
+      const int KP = C >> 6, TB = HW >> 4;
       const int per_tb = cdiv(TB, gridDim.x), tb0 = blockIdx.x * per_tb, tb1 = min(TB, tb0 + per_tb);
-      const int nchunk = (tb1 - tb0 + 7) >> 3;
+      const int nchunk = (tb1 - tb0 + UF - 1) / UF;
+      const int piece = lane & 7, trow = lane >> 3;
+      // LDS write position of (token t, piece): fragment piece >> 2, lane group piece & 3, row t
+      const int wr0 = (piece >> 2) * FRAG_PAD + (piece & 3) * 272 + trow * 16;
+      const int rd0 = (lane >> 4) * 272 + (lane & 15) * 16;
       typedef __attribute__((ext_vector_type(4))) unsigned int raw16;
-      for (int item = wave; item < nchunk * KS; item += NW) {   // item = (8 token blocks, one k-step): the lane's 8 channels are fixed
-        const int ks = item % KS, t0 = tb0 + (item / KS) * 8;
-        const int c0 = 32 * ks + 8 * lg;
+      for (int item = wave; item < nchunk * KP; item += NW) {   // item = (UF token blocks, one 64-channel pair of k-steps)
+        const int kp = item % KP, t0 = tb0 + (item / KP) * UF;
+        const int c0 = 64 * kp + 8 * piece;
         float sc[8], sh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -192,24 +202,40 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
           sc[i] = s;
           sh[i] = beta[c0 + i] - mr[g * 2] * s;
         }
-        const T* xb = x + ((int64_t)b * HW + lr) * C + c0;
-        T* yb = y + ((((int64_t)b * TB) * KS + ks) * 64 + lane) * 8;
-        raw16 raw[8];
+        const T* xb = x + ((int64_t)b * HW + trow) * C + c0;
+        raw16 raw[UF][2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (t0 + u < tb1) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const raw16*>(xb + (int64_t)(t0 + u) * 16 * C));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (t0 + u >= tb1) continue;
-          float t[8];
-          Vec16<T>::load(reinterpret_cast<const T*>(&raw[u]), t);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float q = t[j] * sc[j] + sh[j];
-            if (silu) q = q * __frcp_rn(1.0f + __expf(-q));
-            t[j] = q;
+        for (int u = 0; u < UF; ++u)
+          if (t0 + u < tb1) {
+            raw[u][0] = __builtin_nontemporal_load(reinterpret_cast<const raw16*>(xb + (int64_t)((t0 + u) * 16) * C));
+            raw[u][1] = __builtin_nontemporal_load(reinterpret_cast<const raw16*>(xb + (int64_t)((t0 + u) * 16 + 8) * C));
           }
-          Vec16<T>::store(yb + (int64_t)(t0 + u) * KS * 512, t);
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+          if (t0 + u >= tb1) continue;
+#pragma unroll
+          for (int hlf = 0; hlf < 2; ++hlf) {
+            float t[8];
+            Vec16<T>::load(reinterpret_cast<const T*>(&raw[u][hlf]), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float q = t[j] * sc[j] + sh[j];
+              if (silu) q = q * __frcp_rn(1.0f + __expf(-q));
+              t[j] = q;
+            }
+            Vec16<T>::store(reinterpret_cast<T*>(scr + u * ITEM_BYTES + wr0 + hlf * 128), t);
+          }
+        }
+        // same wave wrote and reads: LDS operations of a wave complete in order, no barrier
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+          if (t0 + u >= tb1) continue;
+          T* yb = y + ((((int64_t)b * TB + t0 + u) * (C >> 5) + 2 * kp) * 64 + lane) * 8;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const raw16 v = *reinterpret_cast<const raw16*>(scr + u * ITEM_BYTES + f * FRAG_PAD + rd0);
+            *reinterpret_cast<raw16*>(yb + f * 512) = v;
+          }
         }
       }
       return;
@@ -374,7 +400,8 @@ int launch_gn_stats(const void* x, int dt, double* stats, int B, int HW, int C, 
   return DDMI_OK;
 }
 
-static bool gn_frag_out_ok(int dt, int B, int HW, int C) { return dt == DT_BF16 && C % 32 == 0 && HW % 16 == 0; }
+static bool gn_frag_out_ok(int dt, int B, int HW, int C) { return dt == DT_BF16 && C % 64 == 0 && HW % 16 == 0; }
+static size_t gn_frag_scratch_bytes(int threads) { return (size_t)(threads / 64) * 4 * 2 * 1088; }   // per wave: UF items of two padded fragments
 
 int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const float* gamma, const float* beta,
                     float eps, int silu, int B, int HW, int C, hipStream_t s, const int* seg_hw, int nseg, const void* x2,
@@ -405,8 +432,8 @@ int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const f
     hipLaunchKernelGGL((gn_apply_kernel<float, false>), g, dim3(threads), 0, s, (const float*)x, (const float*)x2, C1, (float*)y, stats, sg, gamma,
                        beta, eps, silu, HW, C, NV, R, none, x3_out, 0);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), g, dim3(threads), 0, s, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma,
-                       beta, eps, silu, HW, C, NV, R, none, 0, frag_out);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), g, dim3(threads), frag_out ? gn_frag_scratch_bytes(threads) : 0, s, (const bf16_t*)x,
+                       (const bf16_t*)x2, C1, (bf16_t*)y, stats, sg, gamma, beta, eps, silu, HW, C, NV, R, none, 0, frag_out);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
@@ -426,7 +453,8 @@ int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, 
   sg.nseg = 1; sg.nsplit[0] = (int)g.x; sg.total_hw = HW;
   GnChstat ch{cs1, cs2, rows1, rows2};
   PROF_SCOPE("gn_apply", 0, 2.0 * B * HW * C * 2 + 8.0 * B * C * (HW / rows1), s);
-  hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), g, dim3(threads), (size_t)2 * C * sizeof(double), s, (const bf16_t*)x, (const bf16_t*)x2, C1,
+  hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), g, dim3(threads), (size_t)2 * C * sizeof(double) + (frag_out ? gn_frag_scratch_bytes(threads) : 0), s,
+                     (const bf16_t*)x, (const bf16_t*)x2, C1,
                      (bf16_t*)y, (const double*)nullptr, sg, gamma, beta, eps, silu, HW, C, NV, R, ch, 0, frag_out);
   HIP_TRY(hipGetLastError());
   return DDMI_OK;

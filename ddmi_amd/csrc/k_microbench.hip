@@ -85,26 +85,28 @@ int bench_peak_mfma(double seconds_target, double* tflops, double* ms_per_launch
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   float* out = nullptr;
   HIP_TRY(hipMalloc((void**)&out, (size_t)cus * 4 * 512 * sizeof(float)));
-  const int blocks = cus * 4;          // four rounds of one 512-thread workgroup per CU (a workgroup's 8 waves = two per SIMD)
+  const int blocks = cus * 4;          // four rounds of one 512-thread workgroup per CU (a workgroup's 8 waves = two per SIMD);
+  const int lds = 96 * 1024;           // 96 KB of (unused) dynamic LDS per workgroup keeps it at ONE workgroup per CU
   const int iters = 4096;              // 131 072 MFMAs per wave and launch: ~1 ms at the nominal rate
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(peak_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(512), 0, 0, out, iters);   // warm-up (clock ramp, code load)
+  hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(512), lds, 0, out, iters);   // warm-up (clock ramp, code load)
   hipError_t err = hipDeviceSynchronize();
   int launches = 0;
   float ms = 0.f;
   if (err == hipSuccess) {
     // first a short timed burst to size the run, then the run itself
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(512), 0, 0, out, iters);
+    hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(512), lds, 0, out, iters);
     (void)hipEventRecord(e1, 0);
     err = hipDeviceSynchronize();
     float one = 1.f;
     (void)hipEventElapsedTime(&one, e0, e1);
     launches = (int)std::max(3.0, std::min(400.0, seconds_target * 1e3 / std::max(one, 0.05f)));
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(512), 0, 0, out, iters);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(512), lds, 0, out, iters);
     (void)hipEventRecord(e1, 0);
     if (err == hipSuccess) err = hipDeviceSynchronize();
     (void)hipEventElapsedTime(&ms, e0, e1);
