@@ -13,7 +13,10 @@
 //              - the head's weights stream through a 2 x 12 KB LDS stage per 64-channel chunk by LDS-DMA from a host-packed image
 //                that already IS the swizzled LDS layout (a linear 12 KB copy), one chunk ahead of its MFMAs, one barrier per chunk
 //                (measured and dropped: a four-stage ring in the unwritten halves of the K / V rows, three chunks ahead - 24.1 vs 19.7 us
-//                per projection; the second pass's first chunk fetched under the first pass's last step - 20.1 vs 19.6);
+//                per projection; the second pass's first chunk fetched under the first pass's last step - 20.1 vs 19.6; x fragments
+//                ROLLING through the two register sets, each k-step's registers refilled with chunk c + 2 right behind its MFMAs -
+//                40.3 vs 37.2 us at 16x16 where the loop stayed clean, and hipcc's wait-count pass answers any ragged loop shape
+//                with vmcnt(0..7) waits behind the refills or, with the loads hidden in inline asm, with spills);
 //              - K and V land in LDS for all 1024 rows (2 x 64 KB, the attention kernel's row layouts); Q never leaves registers:
 //                the wave that projected a row is the wave that runs that row's queries (8 B fragments = 32 VGPRs).
 //   Phase B  attention_v2_kernel's lazy-maximum loop (k_attention.hip) over the LDS-resident K / V of the query's own sample:
