@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <math.h>
+#include <type_traits>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -42,6 +43,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 #endif
 #ifndef AB_PRIO
 #define AB_PRIO 1
+#endif
+#ifndef AB_BOUNDED
+#define AB_BOUNDED 1   // 0: always track the running maximum (A/B builds)
 #endif
 #define AB_ROWS 1024                 // token rows per workgroup
 #define AB_KV_BYTES (AB_ROWS * 64)   // one of K / V: [row][32 channels] bf16
@@ -99,6 +103,13 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
 
   // ================= Phase A: q | k | v projection ==================================================================
   bf16x8 qb[8];
+  // Bound on every score of this wave's queries, |q . k| <= |q| |k| (phase B): a row's |.|^2 is the sum of its four lanes' 8-channel
+  // partials, so sum over the four lane groups of (max over rows of the partial) bounds every row's - one reduction per wave at the end
+  // instead of two cross-lane sums per fragment (a bound up to 2x looser per factor; the margin it is compared with is 2^100)
+  float qmax2 = 0.f, kmax2 = 0.f;
+  // the bounded attention tiles (phase B) pay for these norms only where a round has many tiles: 32x32 (16 tiles per round: attention
+  // phase 41.4 -> 36.4 us); at 4 tiles or 1 the first, tracked, tile is most of the round and the norms cost more than they return
+  const bool bounded = AB_BOUNDED && a.N >= 512;
   const int wsw = ((lr >> 1) & 7);
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -184,10 +195,36 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
         v8[4 + j] = (bf16_t)(acc[tf][5][j] + bv[5][j]);
       }
       qb[p * 4 + tf] = q8;
+      if (bounded) {   // partial square norms of the ROUNDED q and k (what the MFMAs multiply) over the lane's 8 channels: running maxima
+        float qs = 0.f, ks2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float qv = (float)q8[e], kv = (float)k8[e];
+          qs = __builtin_fmaf(qv, qv, qs);
+          ks2 = __builtin_fmaf(kv, kv, ks2);
+        }
+        qmax2 = fmaxf(qmax2, qs);
+        kmax2 = fmaxf(kmax2, ks2);
+      }
       *reinterpret_cast<bf16x8*>(Ks + tok * 64 + ab_kswz(tok, lg) * 16) = k8;
       *reinterpret_cast<bf16x8*>(Vs + tok * 64 + ((lg ^ ab_vswz(tok)) << 4)) = v8;
     }
+    if (p == 1 && bounded) {   // max over the 16 rows of a lane group, then the sum over the four lane groups; the keys' goes to a slot
+      auto bound2 = [&](float t) {   // behind the weight stages (they may still be read by slower waves)
+        t = fmaxf(t, __shfl_xor(t, 1)); t = fmaxf(t, __shfl_xor(t, 2)); t = fmaxf(t, __shfl_xor(t, 4)); t = fmaxf(t, __shfl_xor(t, 8));
+        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+        return t;
+      };
+      qmax2 = bound2(qmax2);
+      kmax2 = bound2(kmax2);
+      if (lane == 0) reinterpret_cast<float*>(Wst + 2 * AB_WCHUNK)[wave] = kmax2;
+    }
     __syncthreads();   // the weight stages are free for the next pass; after the second pass: every K / V row is visible
+  }
+  float Kmax2 = 0.f;   // over all 1024 key rows of the group (a superset of any sample's keys: the bound only gets looser)
+  if (bounded) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) Kmax2 = fmaxf(Kmax2, reinterpret_cast<const float*>(Wst + 2 * AB_WCHUNK)[w]);
   }
 
   if (ts) { ts[1] = wall_clock64(); ts[13] = __builtin_amdgcn_s_memtime(); }
@@ -226,8 +263,11 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
     const unsigned char* vp[NDF];
 #pragma unroll
     for (int df = 0; df < NDF; ++df) vp[df] = Vs + keybase * RB + vbase + (((2 * df + (tp >> 1)) ^ vsw) << 4);
-#pragma unroll 1
-    for (int kt = 0; kt < ntiles; ++kt, kp += KT * RB, vp[0] += KT * RB, vp[1] += KT * RB) {
+    // One 64-key tile.  TRACK = false is the BOUNDED form: when |q| max|k| - the Cauchy-Schwarz bound on every score of a query, from the
+    // row norms the projection left behind - is within 2^100 of the reference maximum that the first tile set, no later score can
+    // overflow exp2 or the fp32 accumulators (1024 keys x 2^100 x |v|), and any reference is exact (the denominator accumulates the same
+    // p): the per-tile maximum, its compare / ballot and the rescale branch (46 of the tile's ~320 VALU instructions) are dropped.
+    auto tile = [&](auto TRACK, int kt) {
 #if AB_PRIO
       {
         const int prog = rnd * ntiles + kt, sw = (2 * (8 / QF) * ntiles + 1) / 3;
@@ -247,36 +287,38 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
           sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[rnd * QF + qf], f32x4{init, init, init, init}, 0, 0, 0);
         }
       }
-      float lmax[QF];
-      bool grow = kt == 0;
-#pragma unroll
-      for (int qf = 0; qf < QF; ++qf) {
-        float t = sc[qf][0][0];
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
-        lmax[qf] = t;
-        grow |= t > 6.0f;
-      }
-      if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // move the reference of every query of the wave to its running maximum
+      if constexpr (decltype(TRACK)::value) {
+        float lmax[QF];
+        bool grow = kt == 0;
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
-          float t = lmax[qf];
-          t = fmaxf(t, __shfl_xor(t, 16));
-          t = fmaxf(t, __shfl_xor(t, 32));
-          t = fmaxf(t, kt == 0 ? -1e30f : 0.f);
-          if (kt != 0) {
-            const float alpha = __builtin_amdgcn_exp2f(-t);
-#pragma unroll
-            for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
-            ol[qf][0] *= alpha;
-          }
-          m_run[qf] += t;
+          float t = sc[qf][0][0];
 #pragma unroll
           for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
+            for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
+          lmax[qf] = t;
+          grow |= t > 6.0f;
+        }
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // move the reference of every query of the wave to its running maximum
+#pragma unroll
+          for (int qf = 0; qf < QF; ++qf) {
+            float t = lmax[qf];
+            t = fmaxf(t, __shfl_xor(t, 16));
+            t = fmaxf(t, __shfl_xor(t, 32));
+            t = fmaxf(t, kt == 0 ? -1e30f : 0.f);
+            if (kt != 0) {
+              const float alpha = __builtin_amdgcn_exp2f(-t);
+#pragma unroll
+              for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+              ol[qf][0] *= alpha;
+            }
+            m_run[qf] += t;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
+          }
         }
       }
       bf16x8 pf[QF][2];
@@ -303,6 +345,23 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
           for (int qf = 0; qf < QF; ++qf) o[qf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][df], 0, 0, 0);
         }
       }
+      kp += KT * RB;
+      vp[0] += KT * RB;
+      vp[1] += KT * RB;
+    };
+    tile(std::true_type{}, 0);   // the first tile sets the reference to its true maximum
+    bool loose = !bounded;
+    if (bounded) {
+      const float bound = __builtin_sqrtf(qmax2 * Kmax2);
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) loose |= bound - m_run[qf] > 100.0f;
+    }
+    if (__builtin_amdgcn_ballot_w64(loose) == 0) {
+#pragma unroll 1
+      for (int kt = 1; kt < ntiles; ++kt) tile(std::false_type{}, kt);
+    } else {
+#pragma unroll 1
+      for (int kt = 1; kt < ntiles; ++kt) tile(std::true_type{}, kt);
     }
     // ---- output rows: LDS position 16 df + 4 lg + j of V holds channel 8 lg + 4 df + j (host permutation of the v rows), so the
     //      lane's two fragments are 8 consecutive channels = one 16-byte store -----------------------------------------------
@@ -395,7 +454,7 @@ int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, vo
   if (xcd_env == 0) k.xcd = 0;
   k.ts = g_ab_ts;
   const int gpad = k.xcd ? cdiv(k.groups, 8) * 8 : k.groups;
-  constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK;
+  constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK + 64;   // K | V, two weight stages, eight key-norm maxima
   static int qf_env = getenv("DDMI_ATTNBLOCK_QF") ? atoi(getenv("DDMI_ATTNBLOCK_QF")) : 4;   // 64 queries per wave and round: 63.0 vs 66.5 us per workgroup at 32x32
   auto k2 = attnblock_kernel<2>;
   auto k4 = attnblock_kernel<4>;

@@ -142,3 +142,25 @@ np.save(sys.argv[1], y.float().cpu().numpy())
     assert plans[0].startswith("v ") and len(plans) > 5                     # the autotuner ran and wrote one line per shape
     assert np.array_equal(outs["tuned"], outs["replayed"])                  # a plan file pins the result bit for bit
     assert_bf16_close(outs["tuned"], outs["strict"], what="autotuned vs pinned plans (toy UNet)", l2=2e-2)
+
+
+def test_attention_block_fused_with_scores_beyond_the_bound():
+    """The fused kernel drops the running-maximum bookkeeping of a round when |q| max|k| (Cauchy-Schwarz on the row norms its projection
+    leaves behind) is within 2^100 of the first tile's maximum, and keeps it otherwise.  A qkv projection scaled up until the logits
+    span several hundred (softmax close to one-hot, bound far above the threshold) must take the tracked path and still agree with the
+    five-launch form and the oracle; the same block at ordinary scale takes the bounded path (covered by the cases above)."""
+    B, Cc, H = 2, 448, 32
+    tag = "attnblock_loose"
+    p = _block_params(tag, Cc)
+    p["blk.qkv.weight"] = (p["blk.qkv.weight"] * 6.0).astype(np.float32)      # logits x 36: |s| log2 e / sqrt(d) reaches several hundred
+    x = iw.normal(tag, "x", (B, Cc, H, H), 0.0, 1.0)
+    ref = O.unet_attnblock(O.to_state(p), "blk.", torch.from_numpy(x), 32)
+    y_f, used = attention_block_op(x, p, fused=1)
+    y_u, _ = attention_block_op(x, p, fused=0)
+    assert used == 1 and np.isfinite(y_f.numpy()).all()
+    h_ref = (ref - torch.from_numpy(x)).numpy()
+    # near-one-hot softmax: a bf16 rounding of q or k can flip which key wins for a query, so the comparison is on the bulk - relative L2
+    # of the attention branch against the oracle no worse than the five-launch form's, and the two device forms close to each other
+    l2_f, l2_u = rel_l2(y_f.numpy() - x, h_ref), rel_l2(y_u.numpy() - x, h_ref)
+    assert l2_f < max(2.0 * l2_u, 5e-2), (l2_f, l2_u)
+    assert rel_l2(y_f.numpy() - x, y_u.numpy() - x) < max(2.0 * l2_u, 5e-2)
