@@ -316,6 +316,8 @@ class EmbProjFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if EmbProjFn.pre_backward is not None:   # the overlapped gradient all-reduce: see OverlappedGradReducer.before_late_writes
+            EmbProjFn.pre_backward()
         emb, Wall = ctx.saved_tensors
         B, E = emb.shape
         total = Wall.shape[0]
@@ -325,6 +327,9 @@ class EmbProjFn(torch.autograd.Function):
         dW = _matmul(ctx.tc, dy, 1, total, semb, E, 1, total, E, B)
         db = dy.sum(0)
         return (None, demb, None) + tuple(dW.split(ctx.sizes, 0)) + tuple(db.split(ctx.sizes, 0))
+
+
+EmbProjFn.pre_backward = None
 
 
 class EmbSliceFn(torch.autograd.Function):
@@ -483,6 +488,7 @@ class TrainUNetModel(nn.Module):
         self.model_channels, self.in_channels, self.out_channels = mc, in_channels, out_channels
         self._numerics, self._device, self._tc = numerics, device, None   # the native handle is created on first use
         self._rb = None
+        self._block_grad_cb = None   # set by LDMTrainStep for a step whose gradient all-reduce overlaps the backward
         self.time_embed = _seq(_Linear(mc, E), None, _Linear(E, E))
         self.input_blocks = nn.ModuleList([nn.Sequential(_Conv(in_channels, mc, 3))])
         chans, ch, ds = [mc], mc, 1
@@ -559,15 +565,27 @@ class TrainUNetModel(nn.Module):
         embs = self._project_embeddings(tc, emb)
         h = ToNHWC.apply(tc, x)
         hs = []
-        for block in self.input_blocks:
+        cb = self._block_grad_cb
+
+        def mark(t, key):
+            # the gradient of a block's INPUT exists once the block (and every other consumer of that tensor) has run its backward:
+            # the block's parameter gradients are final then (OverlappedGradReducer; the hook leaves the gradient alone)
+            if cb is not None and t.requires_grad:
+                t.register_hook(lambda g, k=key: cb(k))
+
+        for i, block in enumerate(self.input_blocks):
+            mark(h, f"input_blocks.{i}")
             h = self._run_block(tc, block, h, embs)
             hs.append(h)
+        mark(h, "middle_block")
         h = self._run_block(tc, self.middle_block, h, embs)
-        for block in self.output_blocks:
+        for j, block in enumerate(self.output_blocks):
             skip = hs.pop()                              # th.cat([h, hs.pop()], dim=1) in NHWC
             vec = 16 // h.element_size()
             h = CatFn.apply(tc, h, skip) if h.shape[-1] % vec == 0 and skip.shape[-1] % vec == 0 else torch.cat([h, skip], dim=-1)
+            mark(h, f"output_blocks.{j}")
             h = self._run_block(tc, block, h, embs)
+        mark(h, "out")
         h = self.out[2].run(tc, self.out[0].run(tc, h, silu=True))
         return ToNCHW.apply(tc, h)
 
@@ -615,6 +633,86 @@ def allreduce_gradients(flat_grad: torch.Tensor, world_size: int, bucket_bytes: 
     return flat_grad
 
 
+class OverlappedGradReducer:
+    """The gradient all-reduce of `allreduce_gradients`, issued WHILE the backward still runs (what DDP's bucketed reducer does for the
+    reference, tools/ldm/image.py:96, 165).  The flat slab makes it simple: the backward completes the slab from its END (the loss's
+    `mixing_logit`, `out`, the output blocks in reverse, the middle block, the input blocks in reverse, `time_embed`), so the completed part
+    is always one contiguous tail; every time another `bucket_bytes` of it are complete they go out as ONE asynchronous all-reduce (few,
+    large collectives: a ring over 7 xGMI links is bandwidth-bound per link) while the remaining blocks' backward kernels keep the GPU busy.
+
+    `ranges`: (lo, hi) element ranges in COMPLETION order - contiguous, descending.  `late`: (lo, hi) views inside those ranges that are
+    only written at the very end of the backward (the 22 `emb_layers` weights / biases: ONE stacked projection computes them, `EmbProjFn`,
+    and its backward runs after the last ResBlock's); they must be ZERO while their range goes out early (one micro-step per optimizer step)
+    and are reduced again, gathered into one buffer, in `finish()`.  Sums commute, so the result is the blocking all-reduce's - bit for bit
+    on two ranks (a + b), up to the ring's association order on more."""
+
+    def __init__(self, flat_grad: torch.Tensor, ranges, late=(), world_size: int = 1, bucket_bytes: int = 256 << 20):
+        self.g, self.world = flat_grad, int(world_size)
+        self.ranges = [(int(a), int(b)) for a, b in ranges]
+        for (a, b), (c, d) in zip(self.ranges, self.ranges[1:]):
+            assert d == a and c < d, "ranges must be contiguous and in descending (completion) order"
+        self.late = [(int(a), int(b)) for a, b in late]
+        self.bucket = max(1, int(bucket_bytes) // flat_grad.element_size())
+        self.top = self.ranges[0][1] if self.ranges else flat_grad.numel()
+        self.done_lo = self.top      # [done_lo, top) is complete
+        self.sent_lo = self.top      # [sent_lo, top) has been issued
+        self.next = 0
+        self.works = []
+        self.collectives = 0
+
+    def _active(self):
+        import torch.distributed as dist
+        return self.world > 1 and dist.is_initialized()
+
+    def _issue(self, lo, hi):
+        import torch.distributed as dist
+        if hi > lo:
+            self.works.append(dist.all_reduce(self.g[lo:hi], async_op=True))
+            self.collectives += 1
+
+    def range_done(self, idx: int):
+        """Range `idx` (and, the backward being ordered, every range before it) holds its final gradient - except the late views."""
+        if idx < self.next:
+            return
+        self.next = idx + 1
+        self.done_lo = self.ranges[idx][0]
+        if self._active() and self.sent_lo - self.done_lo >= self.bucket:
+            self._issue(self.done_lo, self.sent_lo)
+            self.sent_lo = self.done_lo
+
+    def before_late_writes(self):
+        """Called right before the backward writes the late views (EmbProjFn.backward): the collectives already issued cover them and
+        run in place - one still in flight would overwrite what the backward is about to add there.  Waiting costs nothing by then:
+        only the head of the slab is left to do."""
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def finish(self):
+        """After the backward: whatever is left of the slab (its head - `time_embed`, the first block - and anything below a bucket), then
+        the late views of the ranges that went out early, as one gathered collective."""
+        if not self._active():
+            return self.g
+        import torch.distributed as dist
+        early_lo = self.sent_lo
+        self._issue(0, self.sent_lo)                      # includes the late views that lie in it: final values, nothing to redo
+        self.sent_lo = 0
+        redo = [(a, b) for a, b in self.late if a >= early_lo]
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if redo:
+            # the early collective summed zeros there; the values written since are local: reduce them now
+            buf = torch.cat([self.g[a:b] for a, b in redo])
+            dist.all_reduce(buf)
+            self.collectives += 1
+            off = 0
+            for a, b in redo:
+                self.g[a:b].copy_(buf[off:off + b - a])
+                off += b - a
+        return self.g
+
+
 def ema_pytorch_plan(step: int, beta: float, update_every: int, update_after_step: int = 100, inv_gamma: float = 1.0,
                      power: float = 2.0 / 3.0, min_value: float = 0.0):
     """What the `step`-th call (0-based: the value of ema_pytorch's `step` buffer BEFORE its increment) of `EMA.update()` does:
@@ -647,7 +745,8 @@ class LDMTrainStep:
     1 / (world_size * gradient_accumulate_every) inside the fused AdamW kernel."""
 
     def __init__(self, unetconfig, ddpmconfig, numerics="bf16", lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
-                 gradient_accumulate_every=1, ema_decay=0.9999, ema_update_every=10, device="cuda:0", use_graph=False):
+                 gradient_accumulate_every=1, ema_decay=0.9999, ema_update_every=10, device="cuda:0", use_graph=False,
+                 overlap_allreduce=True, allreduce_bucket_bytes=256 << 20):
         cfg = dict(ddpmconfig)
         self.device = torch.device(device)
         self.model = TrainUNetModel(**dict(unetconfig), numerics=numerics, device=device)
@@ -676,6 +775,10 @@ class LDMTrainStep:
         self.epoch = 0               # the reference trainer's `step`: finished EPOCHS (tools/ldm/image.py:145, 205), set by the caller's loop
         self.current_iters = 0       # the reference's `current_iters`: micro-steps so far
         self.use_graph = bool(use_graph)     # replay the micro-step as a hipGraph (see _graphed_micro)
+        # gradient all-reduce overlapped with the backward (eager steps, one micro-step per optimizer step, more than one rank)
+        self.overlap_allreduce, self.allreduce_bucket_bytes = bool(overlap_allreduce), int(allreduce_bucket_bytes)
+        self._reducer: Optional[OverlappedGradReducer] = None
+        self._reduce_plan = None
         self._graphs: Dict[tuple, object] = {}
         self._graph_generation = 0
 
@@ -720,6 +823,47 @@ class LDMTrainStep:
         self.flat = FlatParams([p for _, p in self.named_parameters()], self.device)
         self.ema = self.flat.data.clone()
         return self
+
+    # ---- overlapped gradient all-reduce -----------------------------------------------------------------------------------
+    def reduce_plan(self):
+        """(block keys in the order the backward completes them, their slab ranges, the late views) for OverlappedGradReducer: the slab is
+        laid out in named_parameters() order - time_embed, input_blocks.*, middle_block, output_blocks.*, out, mixing_logit - and the
+        backward finishes it from the end.  `input_blocks.0` and `time_embed` (the head) are left to finish()."""
+        if self._reduce_plan is None:
+            off, spans, late = 0, {}, []
+            for k, p in self.named_parameters():
+                n = p.numel()
+                parts = k.split(".")
+                key = "mixing_logit" if k == "mixing_logit" else (".".join(parts[1:3]) if parts[1] in ("input_blocks", "output_blocks") else parts[1])
+                lo, hi = spans.get(key, (off, off))
+                assert hi == off, "a block's parameters are contiguous in the slab"
+                spans[key] = (lo, off + n)
+                if ".emb_layers." in k:
+                    late.append((off, off + n))
+                off += n
+            n_in = len(self.model.input_blocks)
+            n_out = len(self.model.output_blocks)
+            order = (["mixing_logit"] if "mixing_logit" in spans else []) + ["out"] + [f"output_blocks.{j}" for j in reversed(range(n_out))] + \
+                ["middle_block"] + [f"input_blocks.{i}" for i in reversed(range(1, n_in))]
+            self._reduce_plan = (order, [spans[k] for k in order], late)
+        return self._reduce_plan
+
+    def _begin_overlapped_reduce(self, world_size):
+        import torch.distributed as dist
+        ok = (self.overlap_allreduce and world_size > 1 and dist.is_initialized() and self.accum == 1 and not self.use_graph)
+        if not ok:
+            self._reducer = None
+            return
+        order, ranges, late = self.reduce_plan()
+        red = OverlappedGradReducer(self.flat.grad, ranges, late, world_size, self.allreduce_bucket_bytes)
+        index = {k: i for i, k in enumerate(order)}
+        self.model._block_grad_cb = lambda key: red.range_done(index[key]) if key in index else None
+        EmbProjFn.pre_backward = red.before_late_writes
+        self._reducer = red
+
+    def _end_overlapped_reduce(self):
+        self.model._block_grad_cb = None
+        EmbProjFn.pre_backward = None
 
     # ---- one micro-step -------------------------------------------------------------------------------------------------
     def _micro_body(self, z0, t, noise):
@@ -791,7 +935,11 @@ class LDMTrainStep:
 
     def optimizer_step(self, world_size: int = 1):
         """All-reduce (sum) of the gradient slab over the ranks, fused AdamW, then `ema.update()` (tools/ldm/image.py:171-174)."""
-        allreduce_gradients(self.flat.grad, world_size)
+        if self._reducer is not None:      # most of the slab went out during the backward: the head and the late views are left
+            self._reducer.finish()
+            self._reducer = None
+        else:
+            allreduce_gradients(self.flat.grad, world_size)
         self.opt_step += 1
         f = self.flat
         _lib.check(_lib.lib().ddmi_train_adamw(f.data.data_ptr(), f.grad.data_ptr(), f.exp_avg.data_ptr(), f.exp_avg_sq.data_ptr(), f.n,
@@ -919,7 +1067,11 @@ class LDMTrainStep:
 
     def train_step(self, z0, t=None, noise=None, world_size: int = 1):
         """The body of the reference's loop for one batch (tools/ldm/image.py:158-175)."""
-        loss = self.loss_and_backward(z0, t, noise)
+        self._begin_overlapped_reduce(world_size)
+        try:
+            loss = self.loss_and_backward(z0, t, noise)
+        finally:
+            self._end_overlapped_reduce()
         if self.micro % self.accum == 0:
             self.optimizer_step(world_size)
         return loss

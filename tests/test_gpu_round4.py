@@ -164,3 +164,47 @@ def test_attention_block_fused_with_scores_beyond_the_bound():
     l2_f, l2_u = rel_l2(y_f.numpy() - x, h_ref), rel_l2(y_u.numpy() - x, h_ref)
     assert l2_f < max(2.0 * l2_u, 5e-2), (l2_f, l2_u)
     assert rel_l2(y_f.numpy() - x, y_u.numpy() - x) < max(2.0 * l2_u, 5e-2)
+
+
+def test_block_gradients_are_final_when_the_block_input_hook_fires(golden):
+    """What the overlapped gradient all-reduce (ddmi_amd.train.OverlappedGradReducer) relies on: the hook on a block's INPUT tensor
+    fires after that block's backward, in slab-tail order (mixing_logit, out, output blocks reversed, middle, input blocks reversed),
+    and at that moment the block's slab range already holds its FINAL gradient - except the `emb_layers` views, which the stacked
+    embedding projection writes last.  Checked on the toy trainer by snapshotting the slab inside the callbacks of an eager step."""
+    from test_gpu_round3 import _g, _toy_trainer
+    from ddmi_amd.train import EmbProjFn
+    tr = _toy_trainer(golden).finalize()
+    order, ranges, late = tr.reduce_plan()
+    assert order[0] == "mixing_logit" and order[1] == "out" and order[-1] == "input_blocks.1"
+    assert all(b == c for (a, b), (c, d) in zip(ranges[1:], ranges[:-1]))      # contiguous, descending
+    assert ranges[0][1] == tr.flat.n and len(late) == 2 * len(tr.model._resblocks())
+    index = {k: i for i, k in enumerate(order)}
+    seen, snaps = [], {}
+
+    def cb(key):
+        if key in index and key not in snaps:
+            seen.append(key)
+            snaps[key] = tr.flat.grad.detach().clone()
+    late_mark = {}
+    tr.model._block_grad_cb = cb
+    EmbProjFn.pre_backward = lambda: late_mark.setdefault("n_seen", len(seen))
+    try:
+        x0, nz = _g("T1", "x_start", (2, 64, 8, 8)), _g("T1", "noise", (2, 64, 8, 8))
+        tr.loss_and_backward(x0, torch.tensor([3, 900]), nz)
+    finally:
+        tr.model._block_grad_cb = None
+        EmbProjFn.pre_backward = None
+    torch.cuda.synchronize()
+    final = tr.flat.grad.detach().clone()
+    assert seen == [k for k in order if k != "mixing_logit"]          # every hooked block, in completion order
+    assert late_mark["n_seen"] == len(seen)                           # the embedding projection's backward runs after the last hooked block
+    keep = torch.ones(tr.flat.n, dtype=torch.bool, device=final.device)
+    for a, b in late:
+        keep[a:b] = False
+    for key in seen:
+        lo = ranges[index[key]][0]                                    # everything from this block to the end of the slab is final ...
+        m = keep[lo:]
+        assert torch.equal(snaps[key][lo:][m], final[lo:][m]), key
+    first = snaps[seen[0]]
+    assert all(float(first[a:b].abs().max()) == 0.0 for a, b in late)  # ... and the late views are still zero while the ranges go out
+    assert any(float(final[a:b].abs().max()) > 0.0 for a, b in late)
