@@ -101,6 +101,8 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
   const float* const biasp = a.bias + h * 96;
   auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.x_bytes, 0x00020000);
 
+  float* const bias_lds = reinterpret_cast<float*>(Wst + 2 * AB_WCHUNK + 64);   // [96], visible after the first step's barrier
+  if (tid < 96) bias_lds[tid] = biasp[tid];
   // ================= Phase A: q | k | v projection ==================================================================
   bf16x8 qb[8];
   // Bound on every score of this wave's queries, |q . k| <= |q| |k| (phase B): a row's |.|^2 is the sum of its four lanes' 8-channel
@@ -178,9 +180,9 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
     }
     // ---- epilogue: + bias; Q -> B fragments in registers, K / V -> LDS rows (the weight rows were permuted on the host so that the
     //      two fragments of a pair hand a lane 8 consecutive positions) -----------------------------------------------------------
-    f32x4 bv[6];
+    f32x4 bv[6];   // from the LDS copy made at kernel start: a global load here sits on the critical path of both passes
 #pragma unroll
-    for (int cf = 0; cf < 6; ++cf) bv[cf] = *reinterpret_cast<const f32x4*>(biasp + cf * 16 + 4 * lg);
+    for (int cf = 0; cf < 6; ++cf) bv[cf] = *reinterpret_cast<const f32x4*>(bias_lds + cf * 16 + 4 * lg);
 #pragma unroll
     for (int tf = 0; tf < 4; ++tf) {
       const int tok = tok0 + tf * 16 + lr;
@@ -454,7 +456,7 @@ int launch_attnblock_qkv_attn(const void* x, const void* wp, const float* bp, vo
   if (xcd_env == 0) k.xcd = 0;
   k.ts = g_ab_ts;
   const int gpad = k.xcd ? cdiv(k.groups, 8) * 8 : k.groups;
-  constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK + 64;   // K | V, two weight stages, eight key-norm maxima
+  constexpr int lds = 2 * AB_KV_BYTES + 2 * AB_WCHUNK + 64 + 384;   // K | V, two weight stages, eight key-norm maxima, the head's 96 biases
   static int qf_env = getenv("DDMI_ATTNBLOCK_QF") ? atoi(getenv("DDMI_ATTNBLOCK_QF")) : 4;   // 64 queries per wave and round: 63.0 vs 66.5 us per workgroup at 32x32
   auto k2 = attnblock_kernel<2>;
   auto k4 = attnblock_kernel<4>;
