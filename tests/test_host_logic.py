@@ -216,3 +216,28 @@ def test_training_unet_has_the_reference_state_dict_layout(golden):
         got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         want = {k: tuple(s) for k, s in unet_manifest(**cfg)}
         assert got == want
+
+
+def test_bench_profile_lookups_and_bounded_cpu_samples():
+    """bench.py's bookkeeping that needs no GPU: a workload's `roofline.traffic` comes from the newest committed PMC summary OF THAT
+    WORKLOAD (profiles/*pmc_traffic_<suffix>*.json), live scope names resolve to the rocprof kernel names, and the CPU-baseline sampler
+    stops at its time budget but always takes one sample."""
+    import importlib.util
+    import os
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t_afhq, src_afhq = bench.pmc_traffic("conv_halo<bf16,256x224>", "afhq")
+    t_train, src_train = bench.pmc_traffic("conv_halo<bf16,256x224>", "train")
+    assert t_afhq and t_train and src_afhq["file"] != src_train["file"]
+    assert "pmc_traffic_b512" in src_afhq["file"] and "pmc_traffic_train" in src_train["file"]
+    assert bench.pmc_traffic("mlp3d_fused", "shapenet")[0] and bench.pmc_traffic("attention_mh", "sky")[0]
+    assert bench.pmc_traffic("attnblock_qkv_attn", "afhq")[0]                 # the fused AttentionBlock launch is in the b512 passes
+    assert bench.pmc_traffic("no_such_kernel", "afhq") == (None, None)         # a kernel the file does not hold: null, never a stale number
+    calls = []
+    mean, n = bench.timed_evals(lambda a: (calls.append(a), time.sleep(0.05)), [(1,), (2,), (3,)], budget_s=0.07)
+    assert n == 2 and calls == [1, 2] and 0.04 < mean < 0.2
+    mean, n = bench.timed_evals(lambda a: time.sleep(0.02), [(1,)], budget_s=0.0)
+    assert n == 1
