@@ -580,6 +580,202 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
   }
 }
 
+// =====================================================================================================
+// bf16x3 numerics (DDMI_PARITY_BF16X3, k_elementwise.hip / net.hip): fp32 tensors in and out, but both matrix products of the
+// attention as THREE bf16 MFMA products each - x = xh + xl with xh = bf16(x), xl = bf16(x - xh) (16 mantissa bits between them),
+// q.k ~ qh.kh + ql.kh + qh.kl and p.v likewise, fp32 accumulation, fp32 softmax - instead of the fp32 MFMA (1/16 of the bf16 rate)
+// the parity mode's attention ran on (16.5 of its 121 ms per UNet evaluation at B = 128).  The generic kernel's shape: 4 waves x 16
+// queries, the query on the MFMA lane; K and V^T tiles in LDS, each as a hi and a lo bf16 image.  Head dims <= 128.
+// =====================================================================================================
+__device__ __forceinline__ void x3_split(float x, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)x;
+  lo = (bf16_t)(x - (float)hi);
+}
+
+template <int D, int KT>
+__global__ void __launch_bounds__(256) attention_x3_kernel(AttnArgs a) {
+  constexpr int KROWB = D * 2;                 // one bf16 image row of K
+  constexpr int VROWB = (KT + 4) * 2;          // one bf16 image row of V^T: KT keys + 4 pad
+  constexpr int NF = KT / 16, NDF = D / 16, NKK = D / 32;
+  constexpr int KIMG = KT * KROWB, VIMG = D * VROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  unsigned char* const ksh = att_smem;
+  unsigned char* const ksl = att_smem + KIMG;
+  unsigned char* const vsh = att_smem + 2 * KIMG;
+  unsigned char* const vsl = att_smem + 2 * KIMG + VIMG;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+  const int d = a.d;
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  const int q_idx = blockIdx.x * ATT_QB + wave * 16 + lr;
+  const bool q_ok = q_idx < N;
+  const float sscale = a.scale * 1.44269504088896341f;
+
+  bf16x8 qh[NKK], ql[NKK];
+  {
+    int seg = 0;
+    int64_t r = att_row(a, b, q_ok ? q_idx : 0, &seg);
+    const float* qp = (const float*)a.qkv[seg] + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int c0 = kk * 32 + 8 * lg;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = q_ok && c0 + e < d ? qp[c0 + e] : 0.f;
+        bf16_t hi, lo;
+        x3_split(v, hi, lo);
+        qh[kk][e] = hi;
+        ql[kk][e] = lo;
+      }
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[NDF];
+#pragma unroll
+  for (int df = 0; df < NDF; ++df) o[df] = f32x4{0, 0, 0, 0};
+
+  const int ntiles = (N + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    constexpr int SL = D / 8;   // 8-channel groups per key row
+    for (int idx = tid; idx < KT * SL; idx += 256) {
+      const int key = idx / SL, slot = idx - key * SL;
+      const int kg = kt * KT + key;
+      int seg = 0;
+      int64_t r = att_row(a, b, kg < N ? kg : 0, &seg);
+      const float* base = (const float*)a.qkv[seg] + r * a.ld_qkv + h * a.hs_qkv + slot * 8;
+      const bool ok = kg < N && slot * 8 < d;
+      f32x4 k0 = ok ? *reinterpret_cast<const f32x4*>(base + a.k_off) : f32x4{0, 0, 0, 0};
+      f32x4 k1 = ok ? *reinterpret_cast<const f32x4*>(base + a.k_off + 4) : f32x4{0, 0, 0, 0};
+      f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(base + a.v_off) : f32x4{0, 0, 0, 0};
+      f32x4 v1 = ok ? *reinterpret_cast<const f32x4*>(base + a.v_off + 4) : f32x4{0, 0, 0, 0};
+      bf16x8 kh8, kl8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bf16_t hi, lo;
+        x3_split(e < 4 ? k0[e] : k1[e - 4], hi, lo);
+        kh8[e] = hi;
+        kl8[e] = lo;
+        x3_split(e < 4 ? v0[e] : v1[e - 4], hi, lo);
+        *reinterpret_cast<bf16_t*>(vsh + (8 * slot + e) * VROWB + key * 2) = hi;
+        *reinterpret_cast<bf16_t*>(vsl + (8 * slot + e) * VROWB + key * 2) = lo;
+      }
+      const int sw = att_swz<D>(key, slot) * 16;
+      *reinterpret_cast<bf16x8*>(ksh + key * KROWB + sw) = kh8;
+      *reinterpret_cast<bf16x8*>(ksl + key * KROWB + sw) = kl8;
+    }
+    __syncthreads();
+
+    f32x4 sc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      sc[f] = f32x4{0, 0, 0, 0};
+      const int row = 16 * f + lr;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int off = row * KROWB + att_swz<D>(row, 4 * kk + lg) * 16;
+        const bf16x8 kfh = *reinterpret_cast<const bf16x8*>(ksh + off);
+        const bf16x8 kfl = *reinterpret_cast<const bf16x8*>(ksl + off);
+        sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[kk], sc[f], 0, 0, 0);   // small terms first
+        sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh, ql[kk], sc[f], 0, 0, 0);
+        sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh, qh[kk], sc[f], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kg = kt * KT + 16 * f + 4 * lg + j;
+        const float v = kg < N ? sc[f][j] * sscale : -INFINITY;
+        sc[f][j] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = exp2f(sc[f][j] - m_new);
+        sc[f][j] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) o[df] *= alpha;
+
+#pragma unroll
+    for (int u = 0; u < KT / 32; ++u) {
+      bf16x8 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16_t hi, lo;
+        x3_split(sc[2 * u][j], hi, lo);
+        ph[j] = hi; pl[j] = lo;
+        x3_split(sc[2 * u + 1][j], hi, lo);
+        ph[4 + j] = hi; pl[4 + j] = lo;
+      }
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) {
+        const int voff = (16 * df + lr) * VROWB;
+        bf16x8 vfh, vfl;
+        {
+          const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vsh + voff + (32 * u + 4 * lg) * 2);
+          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vsh + voff + (32 * u + 16 + 4 * lg) * 2);
+          const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(vsl + voff + (32 * u + 4 * lg) * 2);
+          const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(vsl + voff + (32 * u + 16 + 4 * lg) * 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vfh[j] = a0[j]; vfh[4 + j] = a1[j];
+            vfl[j] = b0[j]; vfl[4 + j] = b1[j];
+          }
+        }
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph, o[df], 0, 0, 0);
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pl, o[df], 0, 0, 0);
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, ph, o[df], 0, 0, 0);
+      }
+    }
+  }
+
+  if (q_ok) {
+    const float inv = 1.0f / l_run;
+    int seg = 0;
+    int64_t r = att_row(a, b, q_idx, &seg);
+    float* op = (float*)a.out[seg] + r * a.ld_out + h * a.hs_out;
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) {
+      const int c0 = 16 * df + 4 * lg;
+      if (c0 >= d) continue;
+      *reinterpret_cast<f32x4*>(op + c0) = o[df] * inv;
+    }
+  }
+}
+
+template <int D>
+static int launch_attention_x3(const AttnArgs& a, hipStream_t s) {
+  constexpr int KT = 64;
+  constexpr int lds = 2 * KT * D * 2 + 2 * D * (KT + 4) * 2;
+  auto kern = attention_x3_kernel<D, KT>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  hipLaunchKernelGGL(kern, dim3(cdiv(N, ATT_QB), a.B * a.heads), dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <int D, int QF>
 static int launch_attention_v2(const AttnArgs& a_in, hipStream_t s) {
   constexpr int lds = 4 * 64 * D * 2;
@@ -651,6 +847,13 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
     return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);
   }
   DDMI_REQUIRE(!a.lse, "attention: the log-sum-exp output exists on the bf16 production kernel only");
+  static const bool x3_attn_off = getenv("DDMI_X3_ATTN") && atoi(getenv("DDMI_X3_ATTN")) == 0;   // diagnostics: the fp32-MFMA attention in bf16x3 handles
+  if (dt == DT_F32 && a.x3 && !x3_attn_off && a.d % 8 == 0 && a.d <= 128 && a.ld_qkv % 4 == 0 && a.hs_qkv % 4 == 0 && a.q_off % 4 == 0 &&
+      a.k_off % 4 == 0 && a.v_off % 4 == 0 && a.ld_out % 4 == 0 && a.hs_out % 4 == 0) {
+    if (a.d <= 32) return launch_attention_x3<32>(a, s);
+    if (a.d <= 64) return launch_attention_x3<64>(a, s);
+    return launch_attention_x3<128>(a, s);
+  }
   if (dt == DT_BF16) {
     if (a.d <= 32) return launch_attention_t<bf16_t, 32, 32, 64>(a, s);
     if (a.d <= 64) return launch_attention_t<bf16_t, 64, 64, 64>(a, s);

@@ -151,6 +151,7 @@ struct AttnArgs {
   int q_prescaled;     // q already carries softmax scale x log2 e (folded into the qkv projection's q rows, bf16 networks): see
                        // attention_v2_kernel LAZY
   int xcd_map;         // filled by the bf16 launcher: workgroup -> (sample, head, query tile) order (k_attention.hip)
+  int x3;              // fp32 tensors of a DDMI_PARITY_BF16X3 handle: both matrix products as three bf16 MFMA products (attention_x3_kernel)
   float* lse;          // optional [B][heads][N]: natural-log row log-sum-exp of the scaled scores, for the training backward
                        // (written by attention_v2_kernel only: launch_attention refuses it on the other paths)
 };

@@ -690,6 +690,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         const TensorDesc &ti = tensors[o.in], &to = tensors[o.out];
         AttnArgs a{};
         a.heads = o.heads; a.d = o.head_dim; a.scale = o.scale; a.q_prescaled = o.q_prescaled;
+        a.x3 = x3 ? 1 : 0;
         a.legacy_name = o.legacy_layout;
         a.ld_qkv = ti.C; a.ld_out = to.C;
         if (o.legacy_layout) {

@@ -208,3 +208,19 @@ def test_block_gradients_are_final_when_the_block_input_hook_fires(golden):
     first = snaps[seen[0]]
     assert all(float(first[a:b].abs().max()) == 0.0 for a, b in late)  # ... and the late views are still zero while the ranges go out
     assert any(float(final[a:b].abs().max()) > 0.0 for a, b in late)
+
+
+@pytest.mark.parametrize("case", [(2, 448, 32), (3, 64, 8), (2, 128, 16)])
+def test_attention_block_bf16x3_mode_keeps_the_parity_tolerance(case):
+    """DDMI_PARITY_BF16X3 handles run the attention's two matrix products as three bf16 MFMA products each (attention_x3_kernel), like
+    their convolutions: the AttentionBlock stays within the 1e-3 of the fp32 parity mode against the CPU oracle."""
+    B, Cc, H = case
+    tag = "attnblock_x3%s" % (case,)
+    p = _block_params(tag, Cc)
+    x = iw.normal(tag, "x", (B, Cc, H, H), 0.2, 1.0)
+    ref = O.unet_attnblock(O.to_state(p), "blk.", torch.from_numpy(x), 32)
+    y, used = attention_block_op(x, p, numerics="bf16x3", fused=1)
+    assert used == 0                                   # the fused launch is a bf16-handle arrangement
+    assert rel_err(y, ref) < TOL_FP32, rel_err(y, ref)
+    h_ref = (ref - torch.from_numpy(x)).numpy()
+    assert rel_l2(y.numpy() - x, h_ref) < TOL_FP32     # and on the attention branch alone (the residual does not hide it)
