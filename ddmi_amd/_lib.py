@@ -134,6 +134,7 @@ SYMBOLS = {
     "ddmi_bench_attention_block": (_I, [_I] * 5 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_op_attention_legacy_hd": (_I, [_VP, _VP, _I, _I, _I, _I, _I]),
     "ddmi_op_attention_mh": (_I, [_VP, _VP, _VP, _VP] + [_I] * 7),
+    "ddmi_op_attention_mh_prescaled": (_I, [_VP, _VP, _VP, _VP] + [_I] * 6),
     "ddmi_op_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _I, _I]),
     "ddmi_op_attention_legacy": (_I, [_VP, _VP, _I, _I, _I, _I]),
     "ddmi_op_timestep_embedding": (_I, [_VP, _VP, _I, _I]),

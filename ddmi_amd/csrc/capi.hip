@@ -827,8 +827,8 @@ int ddmi_op_attention_legacy(const float* qkv, float* out, int B, int heads, int
   return ddmi_op_attention_legacy_hd(qkv, out, B, heads, 32, T, numerics);
 }
 
-int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
-                         int seg0, int seg1, int numerics) {
+static int op_attention_mh_impl(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
+                                int seg0, int seg1, int numerics, int q_prescaled) {
   int dt;
   DDMI_TRY(numerics_to_dt(numerics, &dt));
   DDMI_REQUIRE(q && k && v && out && B > 0 && heads > 0 && d > 0 && N > 0, "op_attention_mh: bad arguments");
@@ -869,6 +869,7 @@ int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* 
   a.hs_qkv = d; a.hs_out = d;
   a.d = d; a.heads = heads; a.B = B;
   a.scale = 1.0f / sqrtf((float)d);
+  a.q_prescaled = q_prescaled;
   DDMI_TRY(launch_attention(a, dt, 0));
   off = 0;
   for (int s3 = 0; s3 < 3; ++s3) {
@@ -880,6 +881,16 @@ int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* 
   DDMI_TRY(launch_nhwc_to_nchw(on, dt, out, B, C, N, 0));
   HIP_TRY(hipDeviceSynchronize());
   return DDMI_OK;
+}
+
+int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
+                         int seg0, int seg1, int numerics) {
+  return op_attention_mh_impl(q, k, v, out, B, heads, d, N, seg0, seg1, numerics, 0);
+}
+
+int ddmi_op_attention_mh_prescaled(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
+                                   int seg0, int seg1) {
+  return op_attention_mh_impl(q, k, v, out, B, heads, d, N, seg0, seg1, DDMI_PERF_BF16, 1);
 }
 
 int ddmi_op_timestep_embedding(const int64_t* t, float* out, int B, int dim) {

@@ -22,7 +22,9 @@
 #include "kernels.h"
 #include "prof.h"
 #include <math.h>
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #define ATT_QB 64   // queries per workgroup
 
@@ -581,6 +583,275 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 }
 
 // =====================================================================================================
+// RESIDENT form (round 4; the tri-plane UNet's 16-head token attention, openaimodel.py:1148-1169: d = 16 over N = 2048 tokens and
+// d = 32 over 512 - 16 % of config 5's kernel time on the tiled kernel above, whose every 128-query workgroup re-streams the head's
+// whole K / V through LDS behind a barrier per 64 keys).  One workgroup = 8 waves = ONE (sample, head): K and V of the head are brought
+// into LDS once by LDS-DMA (N x d x 2 x 2 B = 128 KB at d = 16, N = 2048) and every wave runs N / 8 queries against them, four 16-query
+// fragments at a time - k_attnblock.hip's phase B: no global loads, no staging stores and no barrier inside the loop, the lazy
+// reference maximum, the BOUNDED tiles (|q| max|k| within 2^100 of the first tile's maximum: no per-tile maximum at all) and the
+// priority hand-over between the two waves of a SIMD.
+// d = 16 on the K = 32 MFMA: a K fragment read serves TWO 16-key blocks - lanes 0-31 hold the 16 channels of keys 0-15, lanes 32-63
+// those of keys 16-31 - against two images of the query fragment with the other half zeroed (q | 0 and 0 | q): the same MFMA count as
+// zero-padding the head dim, half the LDS reads, and the 32-byte K rows need no swizzle (a ds_read_b128 lane group covers 512
+// contiguous bytes, a transposed V read 256).
+// Requirements (else the tiled kernel): bf16, q pre-scaled (LAZY), d == 16 or 32 exactly, N a multiple of 512 with K + V <= 128 KB,
+// segments multiples of 64 tokens, no log-sum-exp output.
+// =====================================================================================================
+typedef __attribute__((address_space(3))) void att_lds_void;
+template <int D, bool SEG3>
+__global__ void __launch_bounds__(512) attention_res_kernel(AttnArgs a) {
+  using T = bf16_t;
+  constexpr int RB = D * 2, KT = 64, QF = 4, NDF = D / 16, SL = D / 8;
+  static_assert(D == 16 || D == 32, "resident attention: head dim 16 or 32");
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  unsigned char* const Ks = att_smem;
+  unsigned char* const Vs = att_smem + N * RB;
+  float* const red = reinterpret_cast<float*>(att_smem + 2 * N * RB);   // [8] per-wave maxima of |k|^2
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  // XCD x (= blockIdx.x % 8 under round-robin dispatch) owns the samples b = x (mod 8): the 16 heads of a sample interleave inside
+  // the same token rows (a 128-byte line holds four heads' 32-byte K at d = 16) and read them through one L2
+  const int L = blockIdx.x, slot = L >> 3;
+  const int bl = slot / a.heads, h = slot - bl * a.heads, b = bl * 8 + (L & 7);
+  if (b >= a.B) return;   // padded grid: workgroup-uniform, before any barrier
+
+  // ---- K | V of (b, h) -> LDS by LDS-DMA: one wave-instruction = 64 consecutive 16-byte pieces = 64 / SL keys of one segment ----
+  {
+    const int kpw = 64 / SL;                                  // keys per wave-instruction
+    const int key_l = lane / SL, ps = lane - key_l * SL;      // key inside the instruction's block, PHYSICAL slot of its LDS row
+    for (int it = wave; it < N / kpw; it += 8) {
+      int n = it * kpw, seg = 0;                              // wave-uniform: a block never straddles segments (multiples of 64)
+      if (SEG3) {
+        if (n >= a.seg_len[0]) { n -= a.seg_len[0]; seg = 1; if (n >= a.seg_len[1]) { n -= a.seg_len[1]; seg = 2; } }
+      }
+      const int sl = a.seg_len[seg];
+      const T* base = (const T*)a.qkv[seg] + (int64_t)b * sl * a.ld_qkv + h * a.hs_qkv;
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(sl * a.ld_qkv * 2), 0x00020000);
+      const int key = it * kpw + key_l;                       // LDS row
+      int ksl = ps, vsl = ps;                                 // logical slot that lives in physical slot ps (the swizzles are XORs)
+      if constexpr (D == 32) {
+        ksl = att_swz<32>(key, ps);
+        vsl = ps ^ att_vswz<32>(key);
+      }
+      const unsigned row = (unsigned)((n + key_l) * a.ld_qkv);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (att_lds_void*)(Ks + it * 1024), 16, (row + a.k_off + ksl * 8) * 2, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (att_lds_void*)(Vs + it * 1024), 16, (row + a.v_off + vsl * 8) * 2, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __syncthreads();
+  // ---- max over the keys of |k|^2 (the bounded tiles' Cauchy-Schwarz factor): thread t squares rows t, t + 512, ... -------------
+  {
+    float km = 0.f;
+    for (int key = tid; key < N; key += 512) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const bf16x8 kv = *reinterpret_cast<const bf16x8*>(Ks + key * RB + sl * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 = __builtin_fmaf((float)kv[e], (float)kv[e], s2);
+      }
+      km = fmaxf(km, s2);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) km = fmaxf(km, __shfl_xor(km, m));
+    if (lane == 0) red[wave] = km;
+  }
+  __syncthreads();
+  float Kmax2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) Kmax2 = fmaxf(Kmax2, red[w]);
+
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  const int tq = lr >> 2, tp = lr & 3;
+  const int vkey = 4 * lg + tq;
+  const int vsw = D == 32 ? att_vswz<32>(vkey) : 0;
+  const int vbase = vkey * RB + (tp & 1) * 8;
+  const int ntiles = N / KT;
+  const int qpw = N >> 3;               // queries per wave
+  const int rounds = qpw / (16 * QF);
+  auto row_of = [&](int n, int* seg) -> int64_t {
+    if constexpr (SEG3) return att_row(a, b, n, seg);
+    *seg = 0;
+    return (int64_t)b * a.seg_len[0] + n;
+  };
+
+#pragma unroll 1
+  for (int rnd = 0; rnd < rounds; ++rnd) {
+    const int q0 = wave * qpw + rnd * QF * 16;
+    // ---- Q fragments of the round (B operands); d = 16: the two half-zeroed images ------------------------------------------------
+    bf16x8 qa[QF], qz[QF];   // D = 32: qa only.  D = 16: qa = (q | 0) for the keys in lanes 0-31, qz = (0 | q) for those in lanes 32-63
+    float qmax2 = 0.f;
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      int seg = 0;
+      const int64_t r = row_of(q0 + qf * 16 + lr, &seg);
+      const T* qp = (const T*)(SEG3 ? a.qkv[seg] : a.qkv[0]) + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + (D == 32 ? 8 * lg : 8 * (lg & 1)));
+      float s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s2 = __builtin_fmaf((float)v[e], (float)v[e], s2);
+      if constexpr (D == 32) {
+        qa[qf] = v;
+      } else {
+        qa[qf] = lg < 2 ? v : bf16x8{};
+        qz[qf] = lg < 2 ? bf16x8{} : v;
+        s2 = lg < 2 ? s2 : 0.f;
+      }
+      qmax2 = fmaxf(qmax2, s2);
+    }
+    // |q|^2 of a row = the sum of its lane groups' partials <= the sum over the groups of each group's maximum over rows
+    qmax2 = fmaxf(qmax2, __shfl_xor(qmax2, 1)); qmax2 = fmaxf(qmax2, __shfl_xor(qmax2, 2));
+    qmax2 = fmaxf(qmax2, __shfl_xor(qmax2, 4)); qmax2 = fmaxf(qmax2, __shfl_xor(qmax2, 8));
+    qmax2 += __shfl_xor(qmax2, 16); qmax2 += __shfl_xor(qmax2, 32);
+
+    float m_run[QF];
+    f32x4 o[QF][NDF], ol[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      m_run[qf] = 0.f;
+      ol[qf] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+    }
+    // per-lane LDS cursors, advanced by one 64-key tile per trip
+    const unsigned char* kp = D == 32 ? Ks + lr * RB + att_swz<32>(lr, lg) * 16      // (the swizzle looks at row bits 2-3 only)
+                                      : Ks + lr * RB + (lg & 1) * 16 + (lg >> 1) * (16 * RB);
+    const unsigned char* vp[NDF];
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) vp[df] = Vs + vbase + (((2 * df + (tp >> 1)) ^ vsw) << 4);
+
+    auto tile = [&](auto TRACK, int kt) {
+      {   // the two waves of a SIMD (w, w + 4): the younger holds the priority for the first two thirds of its tiles (k_attnblock.hip)
+        const int prog = rnd * ntiles + kt, sw = (2 * rounds * ntiles + 1) / 3;
+        if (prog == 0 || prog == sw) {
+          if ((((wave >> 2) ^ (prog == 0 ? 0 : 1)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      f32x4 sc[QF][4];
+      if constexpr (D == 32) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + 16 * f * RB);
+#pragma unroll
+          for (int qf = 0; qf < QF; ++qf) {
+            const float init = -m_run[qf];
+            sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa[qf], f32x4{init, init, init, init}, 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int f2 = 0; f2 < 2; ++f2) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + 32 * f2 * RB);   // keys 32 f2 + (0-15 | 16-31)
+#pragma unroll
+          for (int qf = 0; qf < QF; ++qf) {
+            const float init = -m_run[qf];
+            sc[qf][2 * f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa[qf], f32x4{init, init, init, init}, 0, 0, 0);
+            sc[qf][2 * f2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qz[qf], f32x4{init, init, init, init}, 0, 0, 0);
+          }
+        }
+      }
+      if constexpr (decltype(TRACK)::value) {
+        float lmax[QF];
+        bool grow = kt == 0;
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          float t = sc[qf][0][0];
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
+          lmax[qf] = t;
+          grow |= t > 6.0f;
+        }
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // move the reference of every query of the wave to its running maximum
+#pragma unroll
+          for (int qf = 0; qf < QF; ++qf) {
+            float t = lmax[qf];
+            t = fmaxf(t, __shfl_xor(t, 16));
+            t = fmaxf(t, __shfl_xor(t, 32));
+            t = fmaxf(t, kt == 0 ? -1e30f : 0.f);
+            if (kt != 0) {
+              const float alpha = __builtin_amdgcn_exp2f(-t);
+#pragma unroll
+              for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+              ol[qf][0] *= alpha;
+            }
+            m_run[qf] += t;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
+          }
+        }
+      }
+      bf16x8 pf[QF][2];
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)__builtin_amdgcn_exp2f(sc[qf][f][j]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+          typedef short s16x4 __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vp[df] + (32 * u) * RB));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vp[df] + (32 * u + 16) * RB));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (the element-wise one miscompiles, above)
+#pragma unroll
+          for (int qf = 0; qf < QF; ++qf) o[qf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][df], 0, 0, 0);
+        }
+      }
+      kp += KT * RB;
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) vp[df] += KT * RB;
+    };
+    tile(std::true_type{}, 0);   // the first tile sets the reference to its true maximum
+    bool loose = false;
+    {
+      const float bound = __builtin_sqrtf(qmax2 * Kmax2);
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) loose |= !(bound - m_run[qf] <= 100.0f);
+    }
+    if (__builtin_amdgcn_ballot_w64(loose) == 0) {
+#pragma unroll 1
+      for (int kt = 1; kt < ntiles; ++kt) tile(std::false_type{}, kt);
+    } else {
+#pragma unroll 1
+      for (int kt = 1; kt < ntiles; ++kt) tile(std::true_type{}, kt);
+    }
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      const float inv = 1.0f / ol[qf][0];
+      int seg = 0;
+      const int64_t r = row_of(q0 + qf * 16 + lr, &seg);
+      T* op = (T*)(SEG3 ? a.out[seg] : a.out[0]) + r * a.ld_out + h * a.hs_out;
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) {
+        const f32x4 v = o[qf][df] * inv;
+        bf16x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x4*>(op + 16 * df + 4 * lg) = t;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 // bf16x3 numerics (DDMI_PARITY_BF16X3, k_elementwise.hip / net.hip): fp32 tensors in and out, but both matrix products of the
 // attention as THREE bf16 MFMA products each - x = xh + xl with xh = bf16(x), xl = bf16(x - xh) (16 mantissa bits between them),
 // q.k ~ qh.kh + ql.kh + qh.kl and p.v likewise, fp32 accumulation, fp32 softmax - instead of the fp32 MFMA (1/16 of the bf16 rate)
@@ -806,6 +1077,34 @@ static int launch_attention_v2(const AttnArgs& a_in, hipStream_t s) {
   return DDMI_OK;
 }
 
+static bool attention_res_ok(const AttnArgs& a, int N) {
+  static const bool off = getenv("DDMI_ATTN_RES") && atoi(getenv("DDMI_ATTN_RES")) == 0;   // diagnostics: the tiled kernel everywhere
+  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 16 && a.d != 32)) return false;
+  if (N % 512 != 0 || (int64_t)N * a.d * 4 > 128 * 1024) return false;
+  for (int s = 0; s < 3; ++s)
+    if (a.seg_len[s] % 64 != 0 || (int64_t)a.seg_len[s] * a.ld_qkv * 2 > 0x7FFFFFFFll) return false;
+  return a.ld_qkv % 8 == 0 && a.hs_qkv % 8 == 0 && a.q_off % 8 == 0 && a.k_off % 8 == 0 && a.v_off % 8 == 0;
+}
+
+template <int D>
+static int launch_attention_res(const AttnArgs& a, hipStream_t s) {
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  const int lds = 2 * N * D * 2 + 64;
+  auto kern1 = attention_res_kernel<D, false>;
+  auto kern3 = attention_res_kernel<D, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 64));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 64));
+    attr_set = true;
+  }
+  dim3 grid(a.heads * cdiv(a.B, 8) * 8);
+  if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(kern3, grid, dim3(512), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <typename T, int D, int DV, int KT>
 static int launch_attention_t(const AttnArgs& a, hipStream_t s) {
   constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -837,11 +1136,18 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   // 16-byte vector loads / 8-16-byte stores need every row, head and q/k/v block to start on a vector boundary
   a.vec_ok = (a.d % vn == 0 && a.ld_qkv % vn == 0 && a.hs_qkv % vn == 0 && a.q_off % vn == 0 && a.k_off % vn == 0 &&
               a.v_off % vn == 0 && a.ld_out % 4 == 0 && a.hs_out % 4 == 0) ? 1 : 0;
-  PROF_SCOPE(a.legacy_name ? "attention_legacy" : "attention_mh", 4.0 * a.B * a.heads * (double)N * N * a.d,
-             4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
+  // diagnostics (tools/prof_attn_shapes.py): DDMI_PROF_SHAPES=1 tags the profiler scope with the launch's shape
+  static const bool prof_shapes = getenv("DDMI_PROF_SHAPES") && atoi(getenv("DDMI_PROF_SHAPES")) == 1;
+  char pname[96];
+  snprintf(pname, sizeof pname, "%s", a.legacy_name ? "attention_legacy" : "attention_mh");
+  if (prof_shapes && prof_active())
+    snprintf(pname, sizeof pname, "%s[B%d,h%d,d%d,N%d%s]", a.legacy_name ? "attention_legacy" : "attention_mh", a.B, a.heads, a.d, N,
+             a.seg_len[1] + a.seg_len[2] ? ",seg3" : "");
+  PROF_SCOPE(pname, 4.0 * a.B * a.heads * (double)N * N * a.d, 4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
   static const int use_v2 = getenv("DDMI_ATTN_V1") ? 0 : 1;  // diagnostics: DDMI_ATTN_V1=1 pins the generic kernel
   if (dt == DT_BF16 && a.vec_ok && a.d % 4 == 0 && a.d <= 128 && use_v2) {
     const bool big = N >= 128;
+    if (attention_res_ok(a, N)) return a.d == 16 ? launch_attention_res<16>(a, s) : launch_attention_res<32>(a, s);
     if (a.d <= 32) return big ? launch_attention_v2<32, 2>(a, s) : launch_attention_v2<32, 1>(a, s);
     if (a.d <= 64) return big ? launch_attention_v2<64, 2>(a, s) : launch_attention_v2<64, 1>(a, s);
     return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);

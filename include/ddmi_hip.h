@@ -332,6 +332,13 @@ int ddmi_op_attention_legacy_hd(const float* qkv, float* out, int B, int heads, 
  * held in separate buffers internally (N - seg0 - seg1 is the third), the way the xy | xt | yt planes are. */
 int ddmi_op_attention_mh(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
                          int seg0, int seg1, int numerics);
+/* The same in the arrangement the bf16 NETWORKS run (models.hip `make_qkv_attn`: the softmax scale x log2 e is folded into the q rows of
+ * the qkv projection at finalize): q already carries d^-1/2 * log2(e), the scores are base-2 exponents and no scale is applied.  bf16
+ * only.  With d = 16 / 32, N a multiple of 512 (K + V of a head <= 128 KB) and segments that are multiples of 64 tokens this is the
+ * RESIDENT kernel (k_attention.hip `attention_res_kernel`: one workgroup per (sample, head), K / V in LDS once), else the tiled one;
+ * DDMI_ATTN_RES=0 in the environment pins the tiled kernel. */
+int ddmi_op_attention_mh_prescaled(const float* q, const float* k, const float* v, float* out, int B, int heads, int d, int N,
+                                   int seg0, int seg1);
 /* One AttentionBlock of the LDM UNet (openaimodel.py:279-325 with QKVAttentionLegacy :397-426), built the way the UNet handle
  * builds it: x + proj_out(attention(qkv(GroupNorm32(x)))); x, y [B, C, H, W]; wqkv [3C, C], wproj [C, C] (Conv1d weights with the
  * kernel dim dropped); head_channels = num_head_channels.  In bf16 mode, head dim 32 and H W in {64, 256, 1024} the qkv projection

@@ -224,3 +224,58 @@ def test_attention_block_bf16x3_mode_keeps_the_parity_tolerance(case):
     assert rel_err(y, ref) < TOL_FP32, rel_err(y, ref)
     h_ref = (ref - torch.from_numpy(x)).numpy()
     assert rel_l2(y.numpy() - x, h_ref) < TOL_FP32     # and on the attention branch alone (the residual does not hide it)
+
+
+def _attn_mh_prescaled(q, k, v, heads, seg0, seg1):
+    """q, k, v [B, heads*d, N] fp32 -> the bf16 network arrangement: q carries d^-1/2 log2(e) before it is rounded to bf16."""
+    L = _lib.lib()
+    _lib.init_device(0)
+    B, Cc, N = q.shape
+    d = Cc // heads
+    qs = (torch.from_numpy(q) * (math.log2(math.e) / math.sqrt(d))).numpy()
+    out = torch.empty((B, Cc, N), device=DEV, dtype=torch.float32)
+    _lib.check(L.ddmi_op_attention_mh_prescaled(_dev(qs).data_ptr(), _dev(k).data_ptr(), _dev(v).data_ptr(), out.data_ptr(), B, heads, d, N,
+                                                seg0, seg1))
+    return out.cpu()
+
+
+# (B, heads, d, N, seg0, seg1): the tri-plane UNet's two resident levels (d = 16 over 1024 | 512 | 512 tokens, d = 32 over 256 | 128 | 128),
+# one segment, a batch that does not fill the 8 XCD classes, and shapes the resident kernel must REFUSE (N not a multiple of 512, a segment
+# that is not a multiple of 64, d = 64): those run the tiled kernel through the same entry point
+ATTN_RES_CASES = [(2, 16, 16, 2048, 1024, 512), (3, 16, 32, 512, 256, 128), (9, 2, 16, 512, 512, 0), (1, 3, 32, 1024, 1024, 0),
+                  (1, 2, 16, 1024, 448, 320), (1, 2, 32, 384, 128, 128), (2, 2, 64, 512, 256, 128)]
+
+
+@pytest.mark.parametrize("case", ATTN_RES_CASES)
+def test_resident_attention_matches_the_oracle_and_the_tiled_kernel(case, monkeypatch):
+    """`attention_res_kernel` (one workgroup per (sample, head), K / V in LDS once, bounded tiles, the d = 16 two-block K fragments) against
+    the CPU oracle's softmax(q k^T / sqrt(d)) v and against the tiled kernel on the same pre-scaled bf16 inputs."""
+    B, heads, d, N, seg0, seg1 = case
+    tag = "attres%s" % (case,)
+    q = iw.normal(tag, "q", (B, heads * d, N), 0.0, 1.2)
+    k = iw.normal(tag, "k", (B, heads * d, N), 0.0, 1.2)
+    v = iw.normal(tag, "v", (B, heads * d, N))
+    q[0, 0:d, N // 3] *= 3.0                     # one query far above the first tile's reference
+    k[B - 1, d:2 * d, N - 5] *= 6.0              # one key whose norm sets the Cauchy-Schwarz bound (and wins late in the sequence)
+    ref = O.sdpa_heads(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), heads)
+    y = _attn_mh_prescaled(q, k, v, heads, seg0, seg1)
+    assert rel_err(y, ref) < 2e-2, rel_err(y, ref)
+    assert rel_l2(y.numpy(), ref.numpy()) < 1e-2
+    import subprocess, sys, os
+    # the tiled kernel in a fresh process (DDMI_ATTN_RES is read once per process)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_round4 as T\n"
+            "from ddmi_amd import initweights as iw\n"
+            "case = %r; B, heads, d, N, seg0, seg1 = case; tag = 'attres%%s' %% (case,)\n"
+            "q = iw.normal(tag, 'q', (B, heads * d, N), 0.0, 1.2); k = iw.normal(tag, 'k', (B, heads * d, N), 0.0, 1.2); v = iw.normal(tag, 'v', (B, heads * d, N))\n"
+            "q[0, 0:d, N // 3] *= 3.0; k[B - 1, d:2 * d, N - 5] *= 6.0\n"
+            "np.save(sys.argv[1], T._attn_mh_prescaled(q, k, v, heads, seg0, seg1).numpy())\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), case))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "tiled.npy")
+        env = dict(os.environ, DDMI_ATTN_RES="0")
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        tiled = np.load(path)
+    assert rel_l2(y.numpy(), tiled) < 6e-3, rel_l2(y.numpy(), tiled)   # same bf16 inputs, another reference maximum / summation order

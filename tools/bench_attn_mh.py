@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The tri-plane UNet's token attention (16 heads over the xy | xt | yt tokens of a sample) at its four levels: kernel time from the
-library's HIP-event scope, scores per ns and TFLOP/s (4 N^2 d per head)."""
+library's HIP-event scope, scores per ns and TFLOP/s (4 N^2 d per head).  `bench_attn_mh.py B prescaled` runs the bf16 networks' arrangement
+(q pre-scaled: the lazy loop, and the resident kernel at the d = 16 / 32 levels unless DDMI_ATTN_RES=0)."""
 import os
 import sys
 
@@ -13,6 +14,7 @@ LEVELS = [(16, 16, 2048, 1024, 512), (16, 32, 512, 256, 128), (16, 64, 128, 64, 
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    prescaled = len(sys.argv) > 2 and sys.argv[2] == "prescaled"
     dev = "cuda:0"
     _lib.init_device(0)
     L = _lib.lib()
@@ -28,12 +30,16 @@ if __name__ == "__main__":
                 _lib.profile_enable(1)
             _lib.check(L.ddmi_train_q_sample(z.data_ptr(), z.data_ptr(), one.data_ptr(), one.data_ptr(), z.clone().data_ptr(), 1, 64,
                                              _lib.stream_ptr()))   # opens the profiler's sampling window
-            _lib.check(L.ddmi_op_attention_mh(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, d, N, s0, s1,
-                                              _lib.numerics_code("bf16")))
+            if prescaled:
+                _lib.check(L.ddmi_op_attention_mh_prescaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, d, N, s0, s1))
+            else:
+                _lib.check(L.ddmi_op_attention_mh(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, d, N, s0, s1,
+                                                  _lib.numerics_code("bf16")))
         torch.cuda.synchronize()
         prof = _lib.profile_collect()
         _lib.profile_enable(0)
         p = prof.get("attention_mh")
         us = 1e3 * p["total_ms"] / p["launches"]
         scores = B * heads * N * N
-        print(f"B={B} heads={heads} d={d:3d} N={N:5d}: {us:9.1f} us  {scores / us / 1e3:7.2f} scores/ns  {4.0 * scores * d / us / 1e6:7.1f} TFLOP/s", flush=True)
+        clk = scores / us / 1e3 / 1024 / 2.2   # scores per clock and SIMD at 2.2 GHz
+        print(f"B={B} heads={heads} d={d:3d} N={N:5d}: {us:9.1f} us  {scores / us / 1e3:7.2f} scores/ns  {4.0 * scores * d / us / 1e6:7.1f} TFLOP/s  {clk:5.2f} scores/clk/SIMD", flush=True)
