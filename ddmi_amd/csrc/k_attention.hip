@@ -598,6 +598,7 @@ __global__ void __launch_bounds__(256) attention_v2_kernel(AttnArgs a) {
 // segments multiples of 64 tokens, no log-sum-exp output.
 // =====================================================================================================
 typedef __attribute__((address_space(3))) void att_lds_void;
+typedef __attribute__((address_space(3))) unsigned char* att_lds_u8;
 template <int D, bool SEG3>
 __global__ void __launch_bounds__(512) attention_res_kernel(AttnArgs a) {
   using T = bf16_t;
@@ -852,6 +853,263 @@ __global__ void __launch_bounds__(512) attention_res_kernel(AttnArgs a) {
 }
 
 // =====================================================================================================
+// STREAMING form for long sequences (round 4; the video decoder's inter-plane attention, autoencoder_unet.py:404-534: 8 heads of
+// d = 64 over 73 728 tokens and d = 128 over 20 480 - a fifth of config 5's step on the tiled kernel above, at 1.4 / 0.33 scores per
+// clock and SIMD).  Same loop as the resident form, but K / V cannot stay: one workgroup = 8 waves = 128 QF queries of one (sample,
+// head) - four times the tiled kernel's, so a head's K / V stream through L2 a quarter as often - and the 64-key tiles come through a
+// THREE-stage LDS ring by LDS-DMA: no registers, no ds_write and no per-key row arithmetic in the loop (the tiled kernel's staging is
+// two global loads + two ds_write_b128 + the three-segment row map per thread and tile, beside a VALU-bound softmax).  A tile never
+// straddles a segment (segments are multiples of 64 tokens), so the row map is one scalar decision per tile; the per-lane source
+// offsets (key row, swizzled slot) are two registers per operand for the whole kernel.  One barrier per tile: behind it the DMA of
+// tile t + 2 is issued into the stage tile t - 1 was read from.
+// Requirements (else the tiled kernel): bf16, q pre-scaled (LAZY), d == 64 (QF = 4) or 128 (QF = 2), N a multiple of 128 QF and >= 2048,
+// segments multiples of 64 tokens, no log-sum-exp output.
+// =====================================================================================================
+template <int D, int QF, bool SEG3>
+__global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
+  using T = bf16_t;
+  constexpr int RB = D * 2, KT = 64, NDF = D / 16, NKK = D / 32, SL = D / 8, NS = 3;
+  constexpr int TILE = KT * RB, STAGE = 2 * TILE;
+  constexpr int KPP = 1024 / RB;            // keys per DMA wave-instruction (64 lanes x 16 B)
+  constexpr int DPW = (TILE / 1024) / 8;    // DMA instructions per wave, tile and operand: 1 at D = 64, 2 at D = 128
+  static_assert(D == 64 || D == 128, "streaming attention: head dim 64 or 128");
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];   // [NS][K tile | V tile]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  int q_tile, b, h;
+  {   // attention_v2_kernel's XCD-aware order: all query tiles of a (sample, head) on one XCD, so its K / V stream is an L2 hit for
+      // the workgroups that run beside each other
+    const int tiles = N / (128 * QF);
+    const int L = blockIdx.x, slot = L >> 3;
+    if (a.xcd_map == 0) {
+      const int per_sample = tiles * a.heads;
+      const int bl = slot / per_sample, rem = slot - bl * per_sample;
+      h = rem / tiles;
+      q_tile = rem - h * tiles;
+      b = bl * 8 + (L & 7);
+    } else if (a.xcd_map == 1) {
+      const int ul = slot / tiles;
+      q_tile = slot - ul * tiles;
+      const int bh = ul * 8 + (L & 7);
+      b = bh / a.heads;
+      h = bh - b * a.heads;
+    } else {
+      const int bh = L / tiles;
+      q_tile = L - bh * tiles;
+      b = bh / a.heads;
+      h = bh - b * a.heads;
+    }
+    if (b >= a.B) return;   // padded grid: workgroup-uniform, before any barrier
+  }
+  auto row_of = [&](int n, int* seg) -> int64_t {
+    if constexpr (SEG3) return att_row(a, b, n, seg);
+    *seg = 0;
+    return (int64_t)b * a.seg_len[0] + n;
+  };
+
+  // ---- per-lane DMA source offsets inside a tile (bytes from the tile's first key row): lane -> (key, PHYSICAL slot) ------------
+  // (scalars, not a [DPW] array: with the DMA's offset operand read from an array element the host pass of hipcc 7.2 silently drops the
+  // kernel's handle - an undefined symbol when the library is loaded, no diagnostic)
+  auto lane_off = [&](int piece, int op_off, bool is_v) -> unsigned {
+    const int key = piece * KPP + lane / SL, ps = lane % SL;
+    const int sl = is_v ? (ps ^ att_vswz<D>(key)) : att_swz<D>(key, ps);
+    return (unsigned)((key * a.ld_qkv + op_off + sl * 8) * 2);
+  };
+  const unsigned lane_k0 = lane_off(wave, a.k_off, false), lane_v0 = lane_off(wave, a.v_off, true);
+  const unsigned lane_k1 = DPW > 1 ? lane_off(wave + 8, a.k_off, false) : 0u, lane_v1 = DPW > 1 ? lane_off(wave + 8, a.v_off, true) : 0u;
+  // one descriptor per segment, based at (sample b, head h)
+  auto seg_rsrc = [&](int sg) -> const T* {
+    return a.qkv[sg] ? (const T*)a.qkv[sg] + (int64_t)b * a.seg_len[sg] * a.ld_qkv + h * a.hs_qkv : nullptr;
+  };
+  const auto rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)seg_rsrc(0), 0, (unsigned)(a.seg_len[0] * a.ld_qkv * 2), 0x00020000);
+  const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)seg_rsrc(1), 0, (unsigned)(a.seg_len[1] * a.ld_qkv * 2), 0x00020000);
+  const auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)seg_rsrc(2), 0, (unsigned)(a.seg_len[2] * a.ld_qkv * 2), 0x00020000);
+  const int ntiles = N / KT;
+  // ---- Q fragments (B operands), loaded once - BEFORE the first DMAs: vmcnt retires in order, so the loop's "all but the youngest
+  //      tile" wait covers them, and hipcc's wait-count pass sees them complete before the loop (issued after the DMAs it put a
+  //      vmcnt(0) for the last fragment INSIDE the loop, behind the DMA of tile t + 2: every tile waited for its prefetch) ---------
+  const int q0 = q_tile * (128 * QF) + wave * (16 * QF);
+  bf16x8 qb[QF][NKK];
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    int seg = 0;
+    const int64_t r = row_of(q0 + qf * 16 + lr, &seg);
+    const T* qp = (const T*)(SEG3 ? a.qkv[seg] : a.qkv[0]) + r * a.ld_qkv + a.q_off + h * a.hs_qkv;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qb[qf][kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32 + 8 * lg);
+  }
+
+  float m_run[QF];
+  f32x4 o[QF][NDF], ol[QF];
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    m_run[qf] = 0.f;
+    ol[qf] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+  }
+  const int tq = lr >> 2, tp = lr & 3;
+  const int vkey = 4 * lg + tq;
+  const int vsw = att_vswz<D>(vkey);                  // (unchanged by + 16 / + 32 key rows)
+  const int vbase = vkey * RB + (tp & 1) * 8;
+  int kofs[NKK];                                      // K fragment of key block f: + 16 f rows (the swizzle term does not depend on f)
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) kofs[kk] = lr * RB + att_swz<D>(lr, 4 * kk + lg) * 16;
+
+  // The loop starts two trips early: trips -2 and -1 only issue the DMAs of tiles 0 and 1 (ONE issue site, written out in the loop body:
+  // as a lambda called from three places, the host pass of hipcc 7.2 silently dropped the kernel's handle - an undefined symbol when
+  // the library is loaded, no diagnostic)
+  int stage = 0;
+#pragma unroll 1
+  for (int kt = -2; kt < ntiles; ++kt) {
+    if (kt >= 0) {
+      // vmcnt retires in order: with tile kt + 1's DMAs the youngest, "at most 2 DPW outstanding" means tile kt (and Q) have landed
+      if (kt + 1 < ntiles) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * DPW));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt - 1
+    }
+    if (kt + 2 < ntiles) {   // tile kt + 2 -> the stage tile kt - 1 was read from
+      int n = (kt + 2) * KT, seg = 0;   // wave-uniform
+      if (SEG3) {
+        if (n >= a.seg_len[0]) { n -= a.seg_len[0]; seg = 1; if (n >= a.seg_len[1]) { n -= a.seg_len[1]; seg = 2; } }
+      }
+      const int soff = n * a.ld_qkv * 2;   // the tile's first key row: the scalar offset of the load
+      int s2 = kt < 0 ? kt + 2 : stage + 2;
+      s2 = s2 >= NS ? s2 - NS : s2;
+      unsigned char* st = att_smem + s2 * STAGE;
+#pragma unroll
+      for (int i = 0; i < DPW; ++i) {
+        att_lds_void* kd = (att_lds_void*)(st + (wave + 8 * i) * 1024);
+        att_lds_void* vd = (att_lds_void*)(st + TILE + (wave + 8 * i) * 1024);
+        const unsigned lk = i == 0 ? lane_k0 : lane_k1, lv = i == 0 ? lane_v0 : lane_v1;
+        if (!SEG3 || seg == 0) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, kd, 16, lk, soff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, vd, 16, lv, soff, 0, 0);
+        } else if (seg == 1) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, kd, 16, lk, soff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, vd, 16, lv, soff, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, kd, 16, lk, soff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, vd, 16, lv, soff, 0, 0);
+        }
+      }
+    }
+    if (kt < 0) continue;
+    const unsigned char* kb = att_smem + stage * STAGE;
+    const unsigned char* vb = kb + TILE;
+    f32x4 sc[QF][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) {
+        const float init = -m_run[qf];
+        sc[qf][f] = f32x4{init, init, init, init};
+      }
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kofs[kk] + 16 * f * RB);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[qf][kk], sc[qf][f], 0, 0, 0);
+      }
+    }
+    {   // lazy reference maximum (attention_v2_kernel LAZY)
+      float lmax[QF];
+      bool grow = kt == 0;
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) {
+        float t = sc[qf][0][0];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
+        lmax[qf] = t;
+        grow |= t > 6.0f;
+      }
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          float t = lmax[qf];
+          t = fmaxf(t, __shfl_xor(t, 16));
+          t = fmaxf(t, __shfl_xor(t, 32));
+          t = fmaxf(t, kt == 0 ? -1e30f : 0.f);
+          if (kt != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(-t);
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) o[qf][df] *= alpha;
+            ol[qf][0] *= alpha;
+          }
+          m_run[qf] += t;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
+        }
+      }
+    }
+    bf16x8 pf[QF][2];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)__builtin_amdgcn_exp2f(sc[qf][f][j]);
+    // V^T fragments by transposed LDS reads - as INLINE ASM: for the builtin hipcc's wait-count pass assumes the read may alias the
+    // LDS-DMA in flight (tile t + 2, issued above) and puts a vmcnt(0) in front of it, i.e. every tile waits for its own prefetch.
+    // The asm reads are invisible to that pass, so their lgkmcnt wait is written out too (a second asm that "produces" the registers).
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const unsigned vaddr = (unsigned)(__SIZE_TYPE__)(att_lds_u8)(vb + vbase);   // 32-bit LDS address
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      s16x4 lo[NDF], hi[NDF];
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) {
+        const unsigned ad = vaddr + (unsigned)(((2 * df + (tp >> 1)) ^ vsw) << 4);
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(lo[df]), "=&v"(hi[df]) : "v"(ad), "n"((32 * u) * RB), "n"((32 * u + 16) * RB) : "memory");
+      }
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
+      if constexpr (NDF == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
+                     "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]));
+#pragma unroll
+      for (int df = 0; df < NDF; ++df) {
+        s16x8 both = __builtin_shufflevector(lo[df], hi[df], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (the element-wise one miscompiles, above)
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) o[qf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][df], 0, 0, 0);
+      }
+    }
+    stage = stage + 1 == NS ? 0 : stage + 1;
+  }
+
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    const float inv = 1.0f / ol[qf][0];
+    int seg = 0;
+    const int64_t r = row_of(q0 + qf * 16 + lr, &seg);
+    T* op = (T*)(SEG3 ? a.out[seg] : a.out[0]) + r * a.ld_out + h * a.hs_out;
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) {
+      const f32x4 v = o[qf][df] * inv;
+      bf16x4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x4*>(op + 16 * df + 4 * lg) = t;
+    }
+  }
+}
+
+// =====================================================================================================
 // bf16x3 numerics (DDMI_PARITY_BF16X3, k_elementwise.hip / net.hip): fp32 tensors in and out, but both matrix products of the
 // attention as THREE bf16 MFMA products each - x = xh + xl with xh = bf16(x), xl = bf16(x - xh) (16 mantissa bits between them),
 // q.k ~ qh.kh + ql.kh + qh.kl and p.v likewise, fp32 accumulation, fp32 softmax - instead of the fp32 MFMA (1/16 of the bf16 rate)
@@ -1080,7 +1338,9 @@ static int launch_attention_v2(const AttnArgs& a_in, hipStream_t s) {
 static bool attention_res_ok(const AttnArgs& a, int N) {
   static const bool off = getenv("DDMI_ATTN_RES") && atoi(getenv("DDMI_ATTN_RES")) == 0;   // diagnostics: the tiled kernel everywhere
   if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 16 && a.d != 32)) return false;
-  if (N % 512 != 0 || (int64_t)N * a.d * 4 > 128 * 1024) return false;
+  // N >= 1024: at 512 tokens a workgroup is one round of four fragments and the K / V fill is not amortised (d = 32, N = 512, B = 256 x 16
+  // heads: 339 us against the tiled kernel's 319)
+  if (N < 1024 || N % 512 != 0 || (int64_t)N * a.d * 4 > 128 * 1024) return false;
   for (int s = 0; s < 3; ++s)
     if (a.seg_len[s] % 64 != 0 || (int64_t)a.seg_len[s] * a.ld_qkv * 2 > 0x7FFFFFFFll) return false;
   return a.ld_qkv % 8 == 0 && a.hs_qkv % 8 == 0 && a.q_off % 8 == 0 && a.k_off % 8 == 0 && a.v_off % 8 == 0;
@@ -1099,6 +1359,37 @@ static int launch_attention_res(const AttnArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.heads * cdiv(a.B, 8) * 8);
+  if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(kern3, grid, dim3(512), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
+static bool attention_stream_ok(const AttnArgs& a, int N) {
+  static const bool off = getenv("DDMI_ATTN_STREAM") && atoi(getenv("DDMI_ATTN_STREAM")) == 0;   // diagnostics: the tiled kernel
+  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 64 && a.d != 128)) return false;
+  if (N < 2048 || N % (a.d == 64 ? 512 : 256) != 0) return false;
+  for (int s = 0; s < 3; ++s)
+    if (a.seg_len[s] % 64 != 0 || (int64_t)a.seg_len[s] * a.ld_qkv * 2 > 0x7FFFFFFFll) return false;
+  return a.ld_qkv % 8 == 0 && a.hs_qkv % 8 == 0 && a.q_off % 8 == 0 && a.k_off % 8 == 0 && a.v_off % 8 == 0;
+}
+
+template <int D, int QF>
+static int launch_attention_stream(const AttnArgs& a_in, hipStream_t s) {
+  constexpr int lds = 3 * 2 * 64 * D * 2;
+  auto kern1 = attention_stream_kernel<D, QF, false>;
+  auto kern3 = attention_stream_kernel<D, QF, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int N = a_in.seg_len[0] + a_in.seg_len[1] + a_in.seg_len[2];
+  AttnArgs a = a_in;
+  const int tiles = N / (128 * QF), BH = a.B * a.heads;
+  a.xcd_map = (a.B % 8 == 0 || a.B >= 64) ? 0 : BH >= 8 ? 1 : 2;
+  dim3 grid(a.xcd_map == 0 ? tiles * a.heads * (cdiv(a.B, 8) * 8) : a.xcd_map == 1 ? tiles * (cdiv(BH, 8) * 8) : tiles * BH);
   if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(512), lds, s, a);
   else hipLaunchKernelGGL(kern3, grid, dim3(512), lds, s, a);
   HIP_TRY(hipGetLastError());
@@ -1148,6 +1439,7 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   if (dt == DT_BF16 && a.vec_ok && a.d % 4 == 0 && a.d <= 128 && use_v2) {
     const bool big = N >= 128;
     if (attention_res_ok(a, N)) return a.d == 16 ? launch_attention_res<16>(a, s) : launch_attention_res<32>(a, s);
+    if (attention_stream_ok(a, N)) return a.d == 64 ? launch_attention_stream<64, 4>(a, s) : launch_attention_stream<128, 2>(a, s);
     if (a.d <= 32) return big ? launch_attention_v2<32, 2>(a, s) : launch_attention_v2<32, 1>(a, s);
     if (a.d <= 64) return big ? launch_attention_v2<64, 2>(a, s) : launch_attention_v2<64, 1>(a, s);
     return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);

@@ -234,22 +234,27 @@ def _attn_mh_prescaled(q, k, v, heads, seg0, seg1):
     d = Cc // heads
     qs = (torch.from_numpy(q) * (math.log2(math.e) / math.sqrt(d))).numpy()
     out = torch.empty((B, Cc, N), device=DEV, dtype=torch.float32)
-    _lib.check(L.ddmi_op_attention_mh_prescaled(_dev(qs).data_ptr(), _dev(k).data_ptr(), _dev(v).data_ptr(), out.data_ptr(), B, heads, d, N,
-                                                seg0, seg1))
+    qd, kd, vd = _dev(qs), _dev(k), _dev(v)      # (held: a temporary's memory would be handed to the next one)
+    _lib.check(L.ddmi_op_attention_mh_prescaled(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), B, heads, d, N, seg0, seg1))
     return out.cpu()
 
 
 # (B, heads, d, N, seg0, seg1): the tri-plane UNet's two resident levels (d = 16 over 1024 | 512 | 512 tokens, d = 32 over 256 | 128 | 128),
 # one segment, a batch that does not fill the 8 XCD classes, and shapes the resident kernel must REFUSE (N not a multiple of 512, a segment
 # that is not a multiple of 64, d = 64): those run the tiled kernel through the same entry point
-ATTN_RES_CASES = [(2, 16, 16, 2048, 1024, 512), (3, 16, 32, 512, 256, 128), (9, 2, 16, 512, 512, 0), (1, 3, 32, 1024, 1024, 0),
-                  (1, 2, 16, 1024, 448, 320), (1, 2, 32, 384, 128, 128), (2, 2, 64, 512, 256, 128)]
+ATTN_RES_CASES = [(2, 16, 16, 2048, 1024, 512), (3, 16, 32, 512, 256, 128), (9, 2, 16, 1024, 1024, 0), (1, 3, 32, 1024, 1024, 0),
+                  (2, 2, 32, 1024, 512, 256), (1, 2, 16, 1024, 448, 320), (1, 2, 32, 384, 128, 128), (2, 2, 64, 512, 256, 128),
+                  # the STREAMING kernel (d = 64 / 128, N >= 2048): three segments, one segment, a batch of 8 (sample-per-XCD order),
+                  # fewer than 8 (sample, head) pairs (plain order), and N = 2304 that d = 64 must refuse (not a multiple of 512)
+                  (1, 8, 64, 4096, 2048, 1024), (2, 1, 128, 2048, 1024, 512), (8, 1, 64, 2048, 2048, 0), (1, 2, 128, 2560, 1280, 640),
+                  (1, 2, 64, 2304, 1024, 640)]
 
 
 @pytest.mark.parametrize("case", ATTN_RES_CASES)
 def test_resident_attention_matches_the_oracle_and_the_tiled_kernel(case, monkeypatch):
-    """`attention_res_kernel` (one workgroup per (sample, head), K / V in LDS once, bounded tiles, the d = 16 two-block K fragments) against
-    the CPU oracle's softmax(q k^T / sqrt(d)) v and against the tiled kernel on the same pre-scaled bf16 inputs."""
+    """`attention_res_kernel` (one workgroup per (sample, head), K / V in LDS once, bounded tiles, the d = 16 two-block K fragments) and
+    `attention_stream_kernel` (512 / 256 queries per workgroup, K / V tiles through a three-stage LDS-DMA ring) against the CPU oracle's
+    softmax(q k^T / sqrt(d)) v and against the tiled kernel on the same pre-scaled bf16 inputs."""
     B, heads, d, N, seg0, seg1 = case
     tag = "attres%s" % (case,)
     q = iw.normal(tag, "q", (B, heads * d, N), 0.0, 1.2)
@@ -274,7 +279,7 @@ def test_resident_attention_matches_the_oracle_and_the_tiled_kernel(case, monkey
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "tiled.npy")
-        env = dict(os.environ, DDMI_ATTN_RES="0")
+        env = dict(os.environ, DDMI_ATTN_RES="0", DDMI_ATTN_STREAM="0")
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         tiled = np.load(path)
