@@ -862,17 +862,23 @@ __global__ void __launch_bounds__(512) attention_res_kernel(AttnArgs a) {
 // straddles a segment (segments are multiples of 64 tokens), so the row map is one scalar decision per tile; the per-lane source
 // offsets (key row, swizzled slot) are two registers per operand for the whole kernel.  One barrier per tile: behind it the DMA of
 // tile t + 2 is issued into the stage tile t - 1 was read from.
-// Requirements (else the tiled kernel): bf16, q pre-scaled (LAZY), d == 64 (QF = 4) or 128 (QF = 2), N a multiple of 128 QF and >= 2048,
-// segments multiples of 64 tokens, no log-sum-exp output.
+// d = 256 / 512 (the decoder's deepest inter-plane levels: 6 144 and 2 048 tokens; 64 - 160 TFLOP/s on the generic kernel, which
+// recomputes S per 256-channel value slice): QF = 1, 32-key tiles, the V^T fragments read in groups of four; at d = 512 a stage is 64 KB
+// and the ring has two (the DMA of tile t + 1 flies under tile t).
+// Requirements (else the tiled kernels): bf16, q pre-scaled (LAZY), d == 64 (QF = 4), 128 (QF = 2), 256 or 512 (QF = 1), N a multiple of
+// 128 QF and >= 2048, segments multiples of 64 tokens, no log-sum-exp output.
 // =====================================================================================================
-template <int D, int QF, bool SEG3>
+template <int D, int QF, int KT, int NS, bool SEG3>
 __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   using T = bf16_t;
-  constexpr int RB = D * 2, KT = 64, NDF = D / 16, NKK = D / 32, SL = D / 8, NS = 3;
+  constexpr int RB = D * 2, NDF = D / 16, NKK = D / 32, SL = D / 8;
+  constexpr int NF = KT / 16, NU = KT / 32;   // 16-key score blocks / 32-key PV steps per tile
   constexpr int TILE = KT * RB, STAGE = 2 * TILE;
   constexpr int KPP = 1024 / RB;            // keys per DMA wave-instruction (64 lanes x 16 B)
-  constexpr int DPW = (TILE / 1024) / 8;    // DMA instructions per wave, tile and operand: 1 at D = 64, 2 at D = 128
-  static_assert(D == 64 || D == 128, "streaming attention: head dim 64 or 128");
+  constexpr int DPW = (TILE / 1024) / 8;    // DMA instructions per wave, tile and operand: 1 (d = 64), 2 (d = 128, 256), 4 (d = 512)
+  constexpr int PD = NS - 1;                // tiles in flight ahead of the one being consumed
+  static_assert((D == 64 || D == 128 || D == 256 || D == 512) && (KT == 64 || KT == 32) && DPW >= 1 && DPW <= 4 && (NS == 2 || NS == 3),
+                "streaming attention: unsupported tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];   // [NS][K tile | V tile]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -920,6 +926,8 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   };
   const unsigned lane_k0 = lane_off(wave, a.k_off, false), lane_v0 = lane_off(wave, a.v_off, true);
   const unsigned lane_k1 = DPW > 1 ? lane_off(wave + 8, a.k_off, false) : 0u, lane_v1 = DPW > 1 ? lane_off(wave + 8, a.v_off, true) : 0u;
+  const unsigned lane_k2 = DPW > 2 ? lane_off(wave + 16, a.k_off, false) : 0u, lane_v2 = DPW > 2 ? lane_off(wave + 16, a.v_off, true) : 0u;
+  const unsigned lane_k3 = DPW > 2 ? lane_off(wave + 24, a.k_off, false) : 0u, lane_v3 = DPW > 2 ? lane_off(wave + 24, a.v_off, true) : 0u;
   // one descriptor per segment, based at (sample b, head h)
   auto seg_rsrc = [&](int sg) -> const T* {
     return a.qkv[sg] ? (const T*)a.qkv[sg] + (int64_t)b * a.seg_len[sg] * a.ld_qkv + h * a.hs_qkv : nullptr;
@@ -958,36 +966,36 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   const int vkey = 4 * lg + tq;
   const int vsw = att_vswz<D>(vkey);                  // (unchanged by + 16 / + 32 key rows)
   const int vbase = vkey * RB + (tp & 1) * 8;
-  int kofs[NKK];                                      // K fragment of key block f: + 16 f rows (the swizzle term does not depend on f)
-#pragma unroll
-  for (int kk = 0; kk < NKK; ++kk) kofs[kk] = lr * RB + att_swz<D>(lr, 4 * kk + lg) * 16;
+  // K fragment (key block f, k-step kk): row 16 f + lr, logical slot 4 kk + lg.  The swizzle term depends on lr only (every template:
+  // (row >> 1) & 7 or row & 15 of a row 16 f + lr), so  address = k0 ^ (kk << 6) + 16 f RB  with ONE register k0
+  const int k0 = lr * RB + att_swz<D>(lr, lg) * 16;
 
-  // The loop starts two trips early: trips -2 and -1 only issue the DMAs of tiles 0 and 1 (ONE issue site, written out in the loop body:
-  // as a lambda called from three places, the host pass of hipcc 7.2 silently dropped the kernel's handle - an undefined symbol when
-  // the library is loaded, no diagnostic)
+  // The loop starts PD trips early: those trips only issue the DMAs of the first PD tiles (ONE issue site, in the loop body)
   int stage = 0;
 #pragma unroll 1
-  for (int kt = -2; kt < ntiles; ++kt) {
+  for (int kt = -PD; kt < ntiles; ++kt) {
     if (kt >= 0) {
-      // vmcnt retires in order: with tile kt + 1's DMAs the youngest, "at most 2 DPW outstanding" means tile kt (and Q) have landed
-      if (kt + 1 < ntiles) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * DPW));
+      // vmcnt retires in order: with the DMAs of the PD - 1 tiles behind tile kt the youngest, "at most (PD - 1) 2 DPW outstanding"
+      // means tile kt (and Q) have landed
+      if (PD > 1 && kt + 1 < ntiles) __builtin_amdgcn_s_waitcnt(0x0F70 | ((PD - 1) * 2 * DPW));
       else __builtin_amdgcn_s_waitcnt(0x0F70);
       __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt - 1
     }
-    if (kt + 2 < ntiles) {   // tile kt + 2 -> the stage tile kt - 1 was read from
-      int n = (kt + 2) * KT, seg = 0;   // wave-uniform
+    if (kt + PD < ntiles) {   // tile kt + PD -> the stage tile kt - 1 was read from
+      int n = (kt + PD) * KT, seg = 0;   // wave-uniform
       if (SEG3) {
         if (n >= a.seg_len[0]) { n -= a.seg_len[0]; seg = 1; if (n >= a.seg_len[1]) { n -= a.seg_len[1]; seg = 2; } }
       }
       const int soff = n * a.ld_qkv * 2;   // the tile's first key row: the scalar offset of the load
-      int s2 = kt < 0 ? kt + 2 : stage + 2;
+      int s2 = kt < 0 ? kt + PD : stage + PD;
       s2 = s2 >= NS ? s2 - NS : s2;
       unsigned char* st = att_smem + s2 * STAGE;
 #pragma unroll
       for (int i = 0; i < DPW; ++i) {
         att_lds_void* kd = (att_lds_void*)(st + (wave + 8 * i) * 1024);
         att_lds_void* vd = (att_lds_void*)(st + TILE + (wave + 8 * i) * 1024);
-        const unsigned lk = i == 0 ? lane_k0 : lane_k1, lv = i == 0 ? lane_v0 : lane_v1;
+        const unsigned lk = i == 0 ? lane_k0 : i == 1 ? lane_k1 : i == 2 ? lane_k2 : lane_k3;
+        const unsigned lv = i == 0 ? lane_v0 : i == 1 ? lane_v1 : i == 2 ? lane_v2 : lane_v3;
         if (!SEG3 || seg == 0) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, kd, 16, lk, soff, 0, 0);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, vd, 16, lv, soff, 0, 0);
@@ -1003,9 +1011,9 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
     if (kt < 0) continue;
     const unsigned char* kb = att_smem + stage * STAGE;
     const unsigned char* vb = kb + TILE;
-    f32x4 sc[QF][4];
+    f32x4 sc[QF][NF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NF; ++f) {
 #pragma unroll
       for (int qf = 0; qf < QF; ++qf) {
         const float init = -m_run[qf];
@@ -1013,7 +1021,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
       }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kofs[kk] + 16 * f * RB);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (k0 ^ (kk << 6)) + 16 * f * RB);
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[qf][kk], sc[qf][f], 0, 0, 0);
       }
@@ -1025,7 +1033,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
       for (int qf = 0; qf < QF; ++qf) {
         float t = sc[qf][0][0];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
           for (int j = 0; j < 4; ++j) t = fmaxf(t, sc[qf][f][j]);
         lmax[qf] = t;
@@ -1046,47 +1054,48 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
           }
           m_run[qf] += t;
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
+          for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sc[qf][f][j] -= t;
         }
       }
     }
-    bf16x8 pf[QF][2];
+    bf16x8 pf[QF][NU];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int j = 0; j < 4; ++j) pf[qf][f >> 1][(f & 1) * 4 + j] = (bf16_t)__builtin_amdgcn_exp2f(sc[qf][f][j]);
     // V^T fragments by transposed LDS reads - as INLINE ASM: for the builtin hipcc's wait-count pass assumes the read may alias the
-    // LDS-DMA in flight (tile t + 2, issued above) and puts a vmcnt(0) in front of it, i.e. every tile waits for its own prefetch.
-    // The asm reads are invisible to that pass, so their lgkmcnt wait is written out too (a second asm that "produces" the registers).
+    // LDS-DMA in flight (the tiles fetched ahead, issued above) and puts a vmcnt(0) in front of it, i.e. every tile waits for its own
+    // prefetch.  The asm reads are invisible to that pass, so their lgkmcnt wait is written out too (a second asm that "produces" the
+    // registers).  Four channel fragments (eight reads) per group: at d = 512 a tile's V^T is 32 fragments.
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const unsigned vaddr = (unsigned)(__SIZE_TYPE__)(att_lds_u8)(vb + vbase);   // 32-bit LDS address
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      s16x4 lo[NDF], hi[NDF];
-#pragma unroll
-      for (int df = 0; df < NDF; ++df) {
-        const unsigned ad = vaddr + (unsigned)(((2 * df + (tp >> 1)) ^ vsw) << 4);
-        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                     : "=&v"(lo[df]), "=&v"(hi[df]) : "v"(ad), "n"((32 * u) * RB), "n"((32 * u + 16) * RB) : "memory");
-      }
+    for (int u = 0; u < NU; ++u) {
 #pragma unroll
       for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
-      if constexpr (NDF == 4)
+#pragma unroll
+      for (int c = 0; c < NDF / 4; ++c) {
+        s16x4 lo[4], hi[4];
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+          const int df = 4 * c + d4;
+          const unsigned ad = vaddr + (unsigned)(((2 * df + (tp >> 1)) ^ vsw) << 4);
+          asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                       : "=&v"(lo[d4]), "=&v"(hi[d4]) : "v"(ad), "n"((32 * u) * RB), "n"((32 * u + 16) * RB) : "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
-                     "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]));
 #pragma unroll
-      for (int df = 0; df < NDF; ++df) {
-        s16x8 both = __builtin_shufflevector(lo[df], hi[df], 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (the element-wise one miscompiles, above)
+        for (int d4 = 0; d4 < 4; ++d4) {
+          s16x8 both = __builtin_shufflevector(lo[d4], hi[d4], 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (the element-wise one miscompiles, above)
 #pragma unroll
-        for (int qf = 0; qf < QF; ++qf) o[qf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][df], 0, 0, 0);
+          for (int qf = 0; qf < QF; ++qf) o[qf][4 * c + d4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qf][u], o[qf][4 * c + d4], 0, 0, 0);
+        }
       }
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
@@ -1365,20 +1374,24 @@ static int launch_attention_res(const AttnArgs& a, hipStream_t s) {
   return DDMI_OK;
 }
 
+static int attention_stream_qf(int d) { return d == 64 ? 4 : d == 128 ? 2 : 1; }
 static bool attention_stream_ok(const AttnArgs& a, int N) {
-  static const bool off = getenv("DDMI_ATTN_STREAM") && atoi(getenv("DDMI_ATTN_STREAM")) == 0;   // diagnostics: the tiled kernel
-  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 64 && a.d != 128)) return false;
-  if (N < 2048 || N % (a.d == 64 ? 512 : 256) != 0) return false;
+  static const bool off = getenv("DDMI_ATTN_STREAM") && atoi(getenv("DDMI_ATTN_STREAM")) == 0;   // diagnostics: the tiled kernels
+  static const bool big_off = getenv("DDMI_ATTN_STREAM_BIG") && atoi(getenv("DDMI_ATTN_STREAM_BIG")) == 0;   // ... for d = 256 / 512 only
+  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 64 && a.d != 128 && a.d != 256 && a.d != 512)) return false;
+  if (a.d >= 256 && big_off) return false;
+  if (N < 2048 || N % (128 * attention_stream_qf(a.d)) != 0) return false;
   for (int s = 0; s < 3; ++s)
     if (a.seg_len[s] % 64 != 0 || (int64_t)a.seg_len[s] * a.ld_qkv * 2 > 0x7FFFFFFFll) return false;
   return a.ld_qkv % 8 == 0 && a.hs_qkv % 8 == 0 && a.q_off % 8 == 0 && a.k_off % 8 == 0 && a.v_off % 8 == 0;
 }
 
-template <int D, int QF>
+template <int D, int QF, int KT, int NS>
 static int launch_attention_stream(const AttnArgs& a_in, hipStream_t s) {
-  constexpr int lds = 3 * 2 * 64 * D * 2;
-  auto kern1 = attention_stream_kernel<D, QF, false>;
-  auto kern3 = attention_stream_kernel<D, QF, true>;
+  constexpr int lds = NS * 2 * KT * D * 2;
+  static_assert(lds <= 160 * 1024, "streaming attention: the stage ring exceeds the LDS");
+  auto kern1 = attention_stream_kernel<D, QF, KT, NS, false>;
+  auto kern3 = attention_stream_kernel<D, QF, KT, NS, true>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1436,10 +1449,15 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
              a.seg_len[1] + a.seg_len[2] ? ",seg3" : "");
   PROF_SCOPE(pname, 4.0 * a.B * a.heads * (double)N * N * a.d, 4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
   static const int use_v2 = getenv("DDMI_ATTN_V1") ? 0 : 1;  // diagnostics: DDMI_ATTN_V1=1 pins the generic kernel
+  if (dt == DT_BF16 && use_v2 && attention_stream_ok(a, N)) {
+    if (a.d == 64) return launch_attention_stream<64, 4, 64, 3>(a, s);
+    if (a.d == 128) return launch_attention_stream<128, 2, 64, 3>(a, s);
+    if (a.d == 256) return launch_attention_stream<256, 1, 32, 3>(a, s);
+    return launch_attention_stream<512, 1, 32, 2>(a, s);
+  }
   if (dt == DT_BF16 && a.vec_ok && a.d % 4 == 0 && a.d <= 128 && use_v2) {
     const bool big = N >= 128;
     if (attention_res_ok(a, N)) return a.d == 16 ? launch_attention_res<16>(a, s) : launch_attention_res<32>(a, s);
-    if (attention_stream_ok(a, N)) return a.d == 64 ? launch_attention_stream<64, 4>(a, s) : launch_attention_stream<128, 2>(a, s);
     if (a.d <= 32) return big ? launch_attention_v2<32, 2>(a, s) : launch_attention_v2<32, 1>(a, s);
     if (a.d <= 64) return big ? launch_attention_v2<64, 2>(a, s) : launch_attention_v2<64, 1>(a, s);
     return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);

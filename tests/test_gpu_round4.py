@@ -247,7 +247,9 @@ ATTN_RES_CASES = [(2, 16, 16, 2048, 1024, 512), (3, 16, 32, 512, 256, 128), (9, 
                   # the STREAMING kernel (d = 64 / 128, N >= 2048): three segments, one segment, a batch of 8 (sample-per-XCD order),
                   # fewer than 8 (sample, head) pairs (plain order), and N = 2304 that d = 64 must refuse (not a multiple of 512)
                   (1, 8, 64, 4096, 2048, 1024), (2, 1, 128, 2048, 1024, 512), (8, 1, 64, 2048, 2048, 0), (1, 2, 128, 2560, 1280, 640),
-                  (1, 2, 64, 2304, 1024, 640)]
+                  (1, 2, 64, 2304, 1024, 640),
+                  # d = 256 (32-key tiles, three stages) and d = 512 (two 64 KB stages), QF = 1
+                  (1, 2, 256, 2048, 1024, 512), (1, 1, 512, 2048, 2048, 0), (2, 1, 512, 2176, 1152, 512)]
 
 
 @pytest.mark.parametrize("case", ATTN_RES_CASES)
@@ -279,7 +281,7 @@ def test_resident_attention_matches_the_oracle_and_the_tiled_kernel(case, monkey
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "tiled.npy")
-        env = dict(os.environ, DDMI_ATTN_RES="0", DDMI_ATTN_STREAM="0")
+        env = dict(os.environ, DDMI_ATTN_RES="0", DDMI_ATTN_STREAM="0")   # (d >= 256: the generic kernel)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         tiled = np.load(path)

@@ -22,7 +22,7 @@ if __name__ == "__main__":
     one = torch.ones((1,), device=dev)
     levels = LEVELS
     if len(sys.argv) > 3 and sys.argv[3] == "decoder":   # VideoDecoder_light's inter-plane attention at decode batch 4 (B is the decode batch)
-        levels = [(8, 64, 73728, 32768, 20480), (8, 128, 20480, 8192, 6144)]
+        levels = [(8, 64, 73728, 32768, 20480), (8, 128, 20480, 8192, 6144), (8, 256, 6144, 2048, 2048), (8, 512, 2048, 1024, 512)]
     for heads, d, N, s0, s1 in levels:
         C = heads * d
         q, k, v = (torch.randn((B, C, N), device=dev) for _ in range(3))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Attention launches of config 5 (sky) by SHAPE: one sampling step + decode + MLPVideo at the bench leg's batch with every launch timed
-(DDMI_PROF_SHAPES=1 tags the profiler scope of `launch_attention` with B / heads / d / N), sorted by total time."""
+(DDMI_PROF_SHAPES=1 tags the profiler scope of `launch_attention` with B / heads / d / N), sorted by total time.
+`prof_attn_shapes.py B nfe unet` times the sampling loop alone."""
 import os
 import sys
 
@@ -26,14 +27,19 @@ if __name__ == "__main__":
     pipe.generate(list(range(B)), base_seed=0)
     torch.cuda.synchronize()
     _lib.profile_enable(1)
-    pipe.generate(list(range(B)), base_seed=1)
+    if len(sys.argv) > 3 and sys.argv[3] == "unet":   # the sampling loop only (no decode / MLPVideo)
+        from ddmi_amd.pipeline import sample_seed
+        seeds = torch.tensor([sample_seed(1, i) for i in range(B)], dtype=torch.int64, device="cuda:0")
+        pipe.ddpm.sample([B, a.embed_dim, pipe.unet.seq_len], seeds=seeds, device="cuda:0")
+    else:
+        pipe.generate(list(range(B)), base_seed=1)
     torch.cuda.synchronize()
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
     tot = sum(v["total_ms"] for v in prof.values())
     print(f"B={B} nfe={nfe}: {tot:.1f} ms of kernel time ({nfe} UNet evaluations + {B} decodes)")
     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
-        if v["total_ms"] / tot < 0.002:
+        if v["total_ms"] / tot < 0.002 and not k.startswith("attention"):
             continue
         us = 1e3 * v["total_ms"] / v["launches"]
         tf = v["flops"] / v["total_ms"] / 1e9 if v.get("flops") else 0.0
