@@ -1675,6 +1675,15 @@ static bool halo_ok(const ConvArgs& a) {
   if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Hout == a.Hin && a.Wout == a.Win)) return false;
   return conv_halo_shape_ok(a.Hin, a.Win);
 }
+// diagnostics (tools/prof_attn_shapes.py): DDMI_PROF_SHAPES=1 appends the convolution's shape to the profiler scope's name
+static std::string conv_prof_name(const std::string& base, const ConvK& k) {
+  static const bool on = getenv("DDMI_PROF_SHAPES") && atoi(getenv("DDMI_PROF_SHAPES")) == 1;
+  if (!on || !prof_active()) return base;
+  char buf[128];
+  snprintf(buf, sizeof buf, "[M%d,%dx%d,Cin%d,Cout%d,k%d,s%d,u%d]", k.M, k.Hout, k.Wout, k.Cin, k.Cout, k.KH, k.stride, k.ups);
+  return base + buf;
+}
+
 // a launch with a folded skip connection exists on the halo kernel only: the tuned / heuristic tile when it is one, else the
 // halo configuration that fits Cout
 static int skip_fold_cfg(const ConvArgs& a) { return a.Cout > 128 ? 19 : 20; }
@@ -1789,7 +1798,7 @@ static int launch_cfg(ConvK k, int splitk, int batch, hipStream_t s) {
     conv_work(k, batch, sizeof(T), &flops, &bytes);
     static const std::string name = std::string("conv_igemm<") + (sizeof(T) == 2 ? "bf16" : "f32") + "," +
                                     std::to_string(BM) + "x" + std::to_string(BN) + ">";
-    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    PROF_SCOPE(conv_prof_name(name, k).c_str(), flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), 2 * stage, s, k);
   }
   HIP_TRY(hipGetLastError());
@@ -1864,7 +1873,7 @@ static int launch_ring(ConvK k, int splitk, int batch, hipStream_t s) {
     conv_work(k, batch, 2, &flops, &bytes);
     static const std::string name = "conv_ring<bf16," + std::to_string(BM) + "x" + std::to_string(BN) + ",k" +
                                     std::to_string(KPS * 32) + "x" + std::to_string(NST) + (ILV ? ",ilv>" : ">");
-    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    PROF_SCOPE(conv_prof_name(name, k).c_str(), flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
@@ -1892,7 +1901,7 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
     double flops, bytes;
     conv_work(k, batch, 2, &flops, &bytes);
     static const std::string name = "conv_pipe<bf16," + std::to_string(BM) + "x" + std::to_string(BN) + ">";
-    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    PROF_SCOPE(conv_prof_name(name, k).c_str(), flops, bytes, s);
     if (k.paired) hipLaunchKernelGGL(kern_paired, grid, dim3(WM * WN * 64), lds, s, k);
     else hipLaunchKernelGGL(kern_plain, grid, dim3(WM * WN * 64), lds, s, k);
   }
@@ -1937,7 +1946,7 @@ static int launch_gemm1x1(ConvK k, hipStream_t s) {
     double flops, bytes;
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_gemm1x1<bf16,256x" + std::to_string(BN) + ",persistent>";
-    PROF_SCOPE(name.c_str(), flops, bytes, s);
+    PROF_SCOPE(conv_prof_name(name, k).c_str(), flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
@@ -1961,7 +1970,7 @@ static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
     double flops, bytes;
     conv_work(k, batch, 2, &flops, &bytes);
     static const std::string name2 = "conv_halo_up4<bf16,256x" + std::to_string(BN) + ">";
-    PROF_SCOPE(name2.c_str(), flops, bytes, s);
+    PROF_SCOPE(conv_prof_name(name2, k).c_str(), flops, bytes, s);
     k.ts = nullptr;
     hipLaunchKernelGGL(kern2, grid, dim3(WM * WN * 64), lds, s, k);
     HIP_TRY(hipGetLastError());
@@ -1980,7 +1989,7 @@ static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_halo<bf16,256x" + std::to_string(BN) + ">";
     static const std::string name_skip = "conv_halo+skip<bf16,256x" + std::to_string(BN) + ">";
-    PROF_SCOPE(k.x2 ? name_skip.c_str() : name.c_str(), flops, bytes, s);
+    PROF_SCOPE(conv_prof_name(k.x2 ? name_skip : name, k).c_str(), flops, bytes, s);
     k.ts = conv_ts_buffer((int)grid.x);
     if (k.x2) hipLaunchKernelGGL(kern_skip, grid, dim3(WM * WN * 64), lds, s, k);
     else hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);

@@ -39,7 +39,7 @@ if __name__ == "__main__":
     tot = sum(v["total_ms"] for v in prof.values())
     print(f"B={B} nfe={nfe}: {tot:.1f} ms of kernel time ({nfe} UNet evaluations + {B} decodes)")
     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
-        if v["total_ms"] / tot < 0.002 and not k.startswith("attention"):
+        if v["total_ms"] / tot < (0.004 if len(sys.argv) > 3 else 0.002) and not k.startswith("attention"):
             continue
         us = 1e3 * v["total_ms"] / v["launches"]
         tf = v["flops"] / v["total_ms"] / 1e9 if v.get("flops") else 0.0
