@@ -879,7 +879,8 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   constexpr int PD = NS - 1;                // tiles in flight ahead of the one being consumed
   static_assert((D == 64 || D == 128 || D == 256 || D == 512) && (KT == 64 || KT == 32) && DPW >= 1 && DPW <= 4 && (NS == 2 || NS == 3),
                 "streaming attention: unsupported tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];   // [NS][K tile | V tile]
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];   // [NS][K tile | V tile] | redo flag
+  int* const redo = reinterpret_cast<int*>(att_smem + NS * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -910,6 +911,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
     }
     if (b >= a.B) return;   // padded grid: workgroup-uniform, before any barrier
   }
+  if (tid == 0) *redo = 0;   // (visible behind the first tile's barrier)
   auto row_of = [&](int n, int* seg) -> int64_t {
     if constexpr (SEG3) return att_row(a, b, n, seg);
     *seg = 0;
@@ -955,13 +957,6 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
-#pragma unroll
-  for (int qf = 0; qf < QF; ++qf) {
-    m_run[qf] = 0.f;
-    ol[qf] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
-  }
   const int tq = lr >> 2, tp = lr & 3;
   const int vkey = 4 * lg + tq;
   const int vsw = att_vswz<D>(vkey);                  // (unchanged by + 16 / + 32 key rows)
@@ -970,6 +965,22 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   // (row >> 1) & 7 or row & 15 of a row 16 f + lr), so  address = k0 ^ (kk << 6) + 16 f RB  with ONE register k0
   const int k0 = lr * RB + att_swz<D>(lr, lg) * 16;
 
+  // OPTIMISTIC reference maximum.  The lazy loop moves a query's reference only when a score exceeds it by 2^6, but it still LOOKS at
+  // every score: 32 v_max3 + compare + ballot per tile and wave beside a VALU-bound softmax.  Any reference within ~2^100 of the true
+  // maximum is exact (p and the sums are floating point, the denominator accumulates the same p), so the first pass takes the FIRST
+  // tile's maximum and never looks again; a score that outgrows it by more than 2^127 turns its p, and with it the row sum, into inf
+  // (or the sum outgrows fp32): the row sums are checked once at the end, and if any wave of the workgroup saw one out of range the whole
+  // workgroup runs the pass again with the tracked maximum (the K / V tiles are the workgroup's: the decision is made together).
+  // (one copy of the loop, a run-time flag: as a generic lambda instantiated twice the kernel needed 40 more registers)
+#pragma unroll 1
+  for (int track_all = D >= 256 ? 1 : 0; track_all < 2; ++track_all) {   // d >= 256 is MFMA- / LDS-bound: tracked from the start
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    m_run[qf] = 0.f;
+    ol[qf] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+  }
   // The loop starts PD trips early: those trips only issue the DMAs of the first PD tiles (ONE issue site, in the loop body)
   int stage = 0;
 #pragma unroll 1
@@ -1026,7 +1037,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
         for (int qf = 0; qf < QF; ++qf) sc[qf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qb[qf][kk], sc[qf][f], 0, 0, 0);
       }
     }
-    {   // lazy reference maximum (attention_v2_kernel LAZY)
+    if (track_all != 0 || kt == 0) {   // lazy reference maximum (attention_v2_kernel LAZY)
       float lmax[QF];
       bool grow = kt == 0;
 #pragma unroll
@@ -1099,6 +1110,14 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
       }
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
+  }
+  if (track_all != 0) break;
+  bool bad = false;
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) bad |= !(ol[qf][0] < 1e30f);   // inf, NaN, or within 2^27 of the fp32 range (|v| headroom for o)
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *redo = 1;
+  __syncthreads();   // also: every wave is done with the last tiles before a second pass refills the ring
+  if (*redo == 0) break;
   }
 
 #pragma unroll
@@ -1388,7 +1407,7 @@ static bool attention_stream_ok(const AttnArgs& a, int N) {
 
 template <int D, int QF, int KT, int NS>
 static int launch_attention_stream(const AttnArgs& a_in, hipStream_t s) {
-  constexpr int lds = NS * 2 * KT * D * 2;
+  constexpr int lds = NS * 2 * KT * D * 2 + 64;
   static_assert(lds <= 160 * 1024, "streaming attention: the stage ring exceeds the LDS");
   auto kern1 = attention_stream_kernel<D, QF, KT, NS, false>;
   auto kern3 = attention_stream_kernel<D, QF, KT, NS, true>;

@@ -286,3 +286,24 @@ def test_resident_attention_matches_the_oracle_and_the_tiled_kernel(case, monkey
         assert r.returncode == 0, r.stderr[-2000:]
         tiled = np.load(path)
     assert rel_l2(y.numpy(), tiled) < 6e-3, rel_l2(y.numpy(), tiled)   # same bf16 inputs, another reference maximum / summation order
+
+
+@pytest.mark.parametrize("case", [(1, 2, 64, 2048, 1024, 512), (1, 1, 128, 2048, 2048, 0)])
+def test_streaming_attention_second_pass_when_a_late_key_outgrows_the_first_tile(case):
+    """The streaming kernel's first pass keeps the FIRST tile's maximum as the reference and never looks at the scores again; here the
+    keys of the first tiles are tiny and a few late keys score ~2^500 above them (p = exp2 overflows, the row sum is inf): the workgroup
+    must notice at the end and run the tracked pass, and the result is the oracle's (the late keys take all the weight)."""
+    B, heads, d, N, seg0, seg1 = case
+    tag = "attredo%s" % (case,)
+    q = iw.normal(tag, "q", (B, heads * d, N), 0.0, 1.0)
+    k = iw.normal(tag, "k", (B, heads * d, N), 0.0, 0.05)
+    v = iw.normal(tag, "v", (B, heads * d, N))
+    q[:, :d, :] = 6.0 + 0.1 * q[:, :d, :]            # head 0: every query points along +1 ...
+    k[:, :d, N - 70:N - 60] = 5.0                     # ... and ten keys of the LAST tiles align with it: q.k / sqrt(d) ~ 240 (d = 64)
+    ref = O.sdpa_heads(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), heads)
+    y = _attn_mh_prescaled(q, k, v, heads, seg0, seg1)
+    assert bool(torch.isfinite(y).all())
+    assert rel_l2(y.numpy(), ref.numpy()) < 1e-2, rel_l2(y.numpy(), ref.numpy())
+    # head 0's output is the mean of the ten late keys' values (to bf16 accuracy), not of the early ones
+    want = torch.from_numpy(v[:, :d, N - 70:N - 60]).mean(dim=2, keepdim=True)
+    assert float((y[:, :d, :] - want).abs().max()) < 0.05
