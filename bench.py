@@ -133,6 +133,11 @@ def _profile_entry(glob_pat, live_name):
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
+        ms = re.match(r"attention_mh\[B\d+,h\d+,d(\d+),N(\d+)", live_name)   # the sky leg's shape-tagged scopes -> the instantiation that shape runs
+        if ms:
+            d, n = int(ms.group(1)), int(ms.group(2))
+            live_name = (f"attention_res_kernel<{d}," if d in (16, 32) and 1024 <= n and n * d * 4 <= 128 * 1024 else
+                         f"attention_stream_kernel<{d}," if d in (64, 128, 256, 512) and n >= 2048 else "attention_mh")
         alias = {"mlp2d_fused": "mlp2d_v2_kernel", "mlp3d_fused": "mlp3d_v2_kernel", "mlpvideo_fused": "mlpv_v2_kernel",
                  "attention_legacy": "attention_v2_kernel", "attention_mh": "attention_", "attnblock_qkv_attn": "attnblock_kernel",
                  "wgrad_tn": "wgrad_tn_kernel"}
@@ -182,6 +187,15 @@ def measured_peaks():
         from ddmi_amd import _lib
         _MEASURED_PEAKS = _lib.measured_peaks(mfma_seconds=1.0, copy_gib=2.0)
     return _MEASURED_PEAKS
+
+
+def dump_prof(name, prof):
+    """Diagnostics: DDMI_PROF_DUMP=<dir> writes the whole profiler record of a leg (with DDMI_PROF_SHAPES=1: per launch shape) to <dir>/prof_<leg>.json."""
+    d = os.environ.get("DDMI_PROF_DUMP")
+    if d and int(os.environ.get("RANK", "0")) == 0:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"prof_{name}.json"), "w") as f:
+            json.dump(prof, f)
 
 
 def roofline_of(prof, pick, workload="afhq"):
@@ -263,6 +277,7 @@ def run_afhq(args, rank, local_rank, world, dev):
     phase_ms = {"sampling_loop": ev[0].elapsed_time(ev[1]), "decode": ev[1].elapsed_time(ev[2]),
                 "mlp_clamp_gather": ev[2].elapsed_time(ev[3])}
     prof = _lib.profile_collect()
+    dump_prof("afhq", prof)
     _lib.profile_enable(0)
     assert out is not None and out.shape == (world * B, 3, 256, 256) and bool(torch.isfinite(out).all())
     nranks = D.group_size(dev)
@@ -446,6 +461,7 @@ def run_shapenet(args, rank, local_rank, world, dev):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     prof = _lib.profile_collect()
+    dump_prof("shapenet", prof)
     nranks = D.group_size(dev)
     # MLP-only time of the dense 128^3 grid (SURVEY 8d asks for it): every launch timed
     z = torch.randn((1, *pipe.latent_shape), device=dev)
@@ -540,6 +556,10 @@ def run_sky(args, rank, local_rank, world, dev):
         pipe.generate([0], base_seed=args.seed)   # lazy one-time setup out of the timed region
     for w in range(args.warmup):
         one_step(w)
+    # "attention_mh" is five kernels here, on shapes from 32 to 73 728 tokens: the profiled launches carry their shape in the scope name
+    # (k_attention.hip), so that `roofline` names ONE launch shape and its instantiation's PMC traffic
+    prev_shapes = os.environ.get("DDMI_PROF_SHAPES")
+    os.environ.setdefault("DDMI_PROF_SHAPES", "2")
     _lib.profile_enable(25)
     D.barrier()
     torch.cuda.synchronize()
@@ -551,7 +571,10 @@ def run_sky(args, rank, local_rank, world, dev):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     prof = _lib.profile_collect()
+    dump_prof("sky", prof)
     _lib.profile_enable(0)
+    if prev_shapes is None:
+        os.environ.pop("DDMI_PROF_SHAPES", None)
     assert out.shape == (world * B, 3, 16, 256, 256) and bool(torch.isfinite(out).all())
     nranks = D.group_size(dev)
     # decode + MLPVideo of one clip, every launch timed
@@ -636,6 +659,7 @@ def run_train(args, rank, local_rank, world, dev):
     one_step()
     torch.cuda.synchronize()
     prof = _lib.profile_collect()
+    dump_prof("train", prof)
     _lib.profile_enable(0)
     nranks = D.group_size(dev)
     if rank != 0:

@@ -1459,11 +1459,12 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   // 16-byte vector loads / 8-16-byte stores need every row, head and q/k/v block to start on a vector boundary
   a.vec_ok = (a.d % vn == 0 && a.ld_qkv % vn == 0 && a.hs_qkv % vn == 0 && a.q_off % vn == 0 && a.k_off % vn == 0 &&
               a.v_off % vn == 0 && a.ld_out % 4 == 0 && a.hs_out % 4 == 0) ? 1 : 0;
-  // diagnostics (tools/prof_attn_shapes.py): DDMI_PROF_SHAPES=1 tags the profiler scope with the launch's shape
-  static const bool prof_shapes = getenv("DDMI_PROF_SHAPES") && atoi(getenv("DDMI_PROF_SHAPES")) == 1;
+  // DDMI_PROF_SHAPES >= 1 tags the profiler scope with the launch's shape (tools/prof_attn_shapes.py; bench.py's sky leg, whose
+  // "attention_mh" is five kernels on shapes three orders of magnitude apart: its roofline entry names ONE of them)
+  // (read per profiled launch, not once: bench.py switches it on for one workload leg of a longer process; 2 = attention only)
   char pname[96];
   snprintf(pname, sizeof pname, "%s", a.legacy_name ? "attention_legacy" : "attention_mh");
-  if (prof_shapes && prof_active())
+  if (prof_active() && getenv("DDMI_PROF_SHAPES") && atoi(getenv("DDMI_PROF_SHAPES")) >= 1)
     snprintf(pname, sizeof pname, "%s[B%d,h%d,d%d,N%d%s]", a.legacy_name ? "attention_legacy" : "attention_mh", a.B, a.heads, a.d, N,
              a.seg_len[1] + a.seg_len[2] ? ",seg3" : "");
   PROF_SCOPE(pname, 4.0 * a.B * a.heads * (double)N * N * a.d, 4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);

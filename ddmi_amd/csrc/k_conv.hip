@@ -1677,8 +1677,7 @@ static bool halo_ok(const ConvArgs& a) {
 }
 // diagnostics (tools/prof_attn_shapes.py): DDMI_PROF_SHAPES=1 appends the convolution's shape to the profiler scope's name
 static std::string conv_prof_name(const std::string& base, const ConvK& k) {
-  static const bool on = getenv("DDMI_PROF_SHAPES") && atoi(getenv("DDMI_PROF_SHAPES")) == 1;
-  if (!on || !prof_active()) return base;
+  if (!prof_active() || !getenv("DDMI_PROF_SHAPES") || atoi(getenv("DDMI_PROF_SHAPES")) != 1) return base;
   char buf[128];
   snprintf(buf, sizeof buf, "[M%d,%dx%d,Cin%d,Cout%d,k%d,s%d,u%d]", k.M, k.Hout, k.Wout, k.Cin, k.Cout, k.KH, k.stride, k.ups);
   return base + buf;
