@@ -875,10 +875,13 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
   constexpr int NF = KT / 16, NU = KT / 32;   // 16-key score blocks / 32-key PV steps per tile
   constexpr int TILE = KT * RB, STAGE = 2 * TILE;
   constexpr int KPP = 1024 / RB;            // keys per DMA wave-instruction (64 lanes x 16 B)
-  constexpr int DPW = (TILE / 1024) / 8;    // DMA instructions per wave, tile and operand: 1 (d = 64), 2 (d = 128, 256), 4 (d = 512)
+  constexpr int PIECES = TILE / 1024;       // DMA wave-instructions per operand tile
+  constexpr bool SPLIT = PIECES == 4;       // d = 32: a tile is 4 + 4 pieces - waves 0-3 fetch K, waves 4-7 fetch V, one instruction each
+  constexpr int DPW = SPLIT ? 1 : PIECES / 8;   // DMA instructions per wave, tile and operand: 1 (d = 64), 2 (d = 128, 256), 4 (d = 512)
+  constexpr int DW = SPLIT ? 1 : 2 * DPW;   // DMA instructions per wave and tile
   constexpr int PD = NS - 1;                // tiles in flight ahead of the one being consumed
-  static_assert((D == 64 || D == 128 || D == 256 || D == 512) && (KT == 64 || KT == 32) && DPW >= 1 && DPW <= 4 && (NS == 2 || NS == 3),
-                "streaming attention: unsupported tile");
+  static_assert((D == 32 || D == 64 || D == 128 || D == 256 || D == 512) && (KT == 64 || KT == 32) && (SPLIT || (PIECES % 8 == 0 && DPW <= 4)) &&
+                (NS == 2 || NS == 3), "streaming attention: unsupported tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];   // [NS][K tile | V tile] | redo flag
   int* const redo = reinterpret_cast<int*>(att_smem + NS * STAGE);
 
@@ -926,7 +929,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
     const int sl = is_v ? (ps ^ att_vswz<D>(key)) : att_swz<D>(key, ps);
     return (unsigned)((key * a.ld_qkv + op_off + sl * 8) * 2);
   };
-  const unsigned lane_k0 = lane_off(wave, a.k_off, false), lane_v0 = lane_off(wave, a.v_off, true);
+  const unsigned lane_k0 = lane_off(SPLIT ? (wave & 3) : wave, a.k_off, false), lane_v0 = lane_off(SPLIT ? (wave & 3) : wave, a.v_off, true);
   const unsigned lane_k1 = DPW > 1 ? lane_off(wave + 8, a.k_off, false) : 0u, lane_v1 = DPW > 1 ? lane_off(wave + 8, a.v_off, true) : 0u;
   const unsigned lane_k2 = DPW > 2 ? lane_off(wave + 16, a.k_off, false) : 0u, lane_v2 = DPW > 2 ? lane_off(wave + 16, a.v_off, true) : 0u;
   const unsigned lane_k3 = DPW > 2 ? lane_off(wave + 24, a.k_off, false) : 0u, lane_v3 = DPW > 2 ? lane_off(wave + 24, a.v_off, true) : 0u;
@@ -986,9 +989,9 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
 #pragma unroll 1
   for (int kt = -PD; kt < ntiles; ++kt) {
     if (kt >= 0) {
-      // vmcnt retires in order: with the DMAs of the PD - 1 tiles behind tile kt the youngest, "at most (PD - 1) 2 DPW outstanding"
+      // vmcnt retires in order: with the DMAs of the PD - 1 tiles behind tile kt the youngest, "at most (PD - 1) DW outstanding"
       // means tile kt (and Q) have landed
-      if (PD > 1 && kt + 1 < ntiles) __builtin_amdgcn_s_waitcnt(0x0F70 | ((PD - 1) * 2 * DPW));
+      if (PD > 1 && kt + 1 < ntiles) __builtin_amdgcn_s_waitcnt(0x0F70 | ((PD - 1) * DW));
       else __builtin_amdgcn_s_waitcnt(0x0F70);
       __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt - 1
     }
@@ -1001,6 +1004,13 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
       int s2 = kt < 0 ? kt + PD : stage + PD;
       s2 = s2 >= NS ? s2 - NS : s2;
       unsigned char* st = att_smem + s2 * STAGE;
+      if constexpr (SPLIT) {   // one instruction per wave: K piece (waves 0-3) or V piece (waves 4-7)
+        att_lds_void* dd = (att_lds_void*)(st + (wave >> 2) * TILE + (wave & 3) * 1024);
+        const unsigned lo = wave < 4 ? lane_k0 : lane_v0;
+        if (!SEG3 || seg == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dd, 16, lo, soff, 0, 0);
+        else if (seg == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dd, 16, lo, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, dd, 16, lo, soff, 0, 0);
+      } else {
 #pragma unroll
       for (int i = 0; i < DPW; ++i) {
         att_lds_void* kd = (att_lds_void*)(st + (wave + 8 * i) * 1024);
@@ -1017,6 +1027,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, kd, 16, lk, soff, 0, 0);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, vd, 16, lv, soff, 0, 0);
         }
+      }
       }
     }
     if (kt < 0) continue;
@@ -1090,18 +1101,18 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
 #pragma unroll
       for (int qf = 0; qf < QF; ++qf) ol[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qf][u], ol[qf], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < NDF / 4; ++c) {
+      for (int c = 0; c < (NDF + 3) / 4; ++c) {
         s16x4 lo[4], hi[4];
 #pragma unroll
         for (int d4 = 0; d4 < 4; ++d4) {
-          const int df = 4 * c + d4;
+          const int df = NDF >= 4 ? 4 * c + d4 : (d4 & (NDF - 1));   // (d = 32: two fragments; the group's other two slots re-read them)
           const unsigned ad = vaddr + (unsigned)(((2 * df + (tp >> 1)) ^ vsw) << 4);
           asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                        : "=&v"(lo[d4]), "=&v"(hi[d4]) : "v"(ad), "n"((32 * u) * RB), "n"((32 * u + 16) * RB) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
 #pragma unroll
-        for (int d4 = 0; d4 < 4; ++d4) {
+        for (int d4 = 0; d4 < (NDF >= 4 ? 4 : NDF); ++d4) {
           s16x8 both = __builtin_shufflevector(lo[d4], hi[d4], 0, 1, 2, 3, 4, 5, 6, 7);
           const bf16x8 vf = __builtin_bit_cast(bf16x8, both);   // whole-vector reinterpretation (the element-wise one miscompiles, above)
 #pragma unroll
@@ -1393,11 +1404,11 @@ static int launch_attention_res(const AttnArgs& a, hipStream_t s) {
   return DDMI_OK;
 }
 
-static int attention_stream_qf(int d) { return d == 64 ? 4 : d == 128 ? 2 : 1; }
+static int attention_stream_qf(int d) { return d <= 64 ? 4 : d == 128 ? 2 : 1; }
 static bool attention_stream_ok(const AttnArgs& a, int N) {
   static const bool off = getenv("DDMI_ATTN_STREAM") && atoi(getenv("DDMI_ATTN_STREAM")) == 0;   // diagnostics: the tiled kernels
   static const bool big_off = getenv("DDMI_ATTN_STREAM_BIG") && atoi(getenv("DDMI_ATTN_STREAM_BIG")) == 0;   // ... for d = 256 / 512 only
-  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 64 && a.d != 128 && a.d != 256 && a.d != 512)) return false;
+  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 32 && a.d != 64 && a.d != 128 && a.d != 256 && a.d != 512)) return false;
   if (a.d >= 256 && big_off) return false;
   if (N < 2048 || N % (128 * attention_stream_qf(a.d)) != 0) return false;
   for (int s = 0; s < 3; ++s)
@@ -1470,6 +1481,7 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   PROF_SCOPE(pname, 4.0 * a.B * a.heads * (double)N * N * a.d, 4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
   static const int use_v2 = getenv("DDMI_ATTN_V1") ? 0 : 1;  // diagnostics: DDMI_ATTN_V1=1 pins the generic kernel
   if (dt == DT_BF16 && use_v2 && attention_stream_ok(a, N)) {
+    if (a.d == 32) return launch_attention_stream<32, 4, 64, 3>(a, s);   // (N > 1024: below that the resident kernel, checked first)
     if (a.d == 64) return launch_attention_stream<64, 4, 64, 3>(a, s);
     if (a.d == 128) return launch_attention_stream<128, 2, 64, 3>(a, s);
     if (a.d == 256) return launch_attention_stream<256, 1, 32, 3>(a, s);

@@ -109,8 +109,10 @@ struct ConvArgs {
 };
 // the 3x3 / stride 1 shapes the halo kernel (and with it the folded skip connection) serves
 bool conv_halo_shape_ok(int H, int W);
-// whether a bf16 network may fold the softmax scale into its qkv projection for head dim d (the shapes attention_v2_kernel serves)
-inline bool attention_prescale_ok(int dt, int d) { return dt == DT_BF16 && d % 8 == 0 && d <= 128; }
+// whether a bf16 network may fold the softmax scale into its qkv projection for head dim d (every bf16 attention kernel then takes the
+// score as the base-2 exponent: launch_attention sets scale x log2 e = 1; d <= 128: the lazy tiled / resident / streaming kernels,
+// 256 / 512: the streaming kernel - the video decoder's deepest inter-plane levels - or the generic one)
+inline bool attention_prescale_ok(int dt, int d) { return dt == DT_BF16 && d % 8 == 0 && d <= 512; }
 // bump when the meaning of (cfg, order) changes: plan files written for other tables are ignored (net.hip)
 #define CONV_PLAN_VERSION 3
 struct ConvPlan { int cfg = 0, order = 0, splitk = 0; float us = 0.f; };  // result of conv_autotune (0 = heuristic)

@@ -249,7 +249,9 @@ ATTN_RES_CASES = [(2, 16, 16, 2048, 1024, 512), (3, 16, 32, 512, 256, 128), (9, 
                   (1, 8, 64, 4096, 2048, 1024), (2, 1, 128, 2048, 1024, 512), (8, 1, 64, 2048, 2048, 0), (1, 2, 128, 2560, 1280, 640),
                   (1, 2, 64, 2304, 1024, 640),
                   # d = 256 (32-key tiles, three stages) and d = 512 (two 64 KB stages), QF = 1
-                  (1, 2, 256, 2048, 1024, 512), (1, 1, 512, 2048, 2048, 0), (2, 1, 512, 2176, 1152, 512)]
+                  (1, 2, 256, 2048, 1024, 512), (1, 1, 512, 2048, 2048, 0), (2, 1, 512, 2176, 1152, 512),
+                  # d = 32 beyond the resident kernel's 1024 tokens: streaming, waves 0-3 fetch K and waves 4-7 V
+                  (2, 3, 32, 2048, 1024, 512), (1, 2, 32, 2560, 2560, 0)]
 
 
 @pytest.mark.parametrize("case", ATTN_RES_CASES)

@@ -10,7 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ddmi_amd import _lib  # noqa: E402
 
-LEVELS = [(16, 16, 2048, 1024, 512), (16, 32, 512, 256, 128), (16, 64, 128, 64, 32), (16, 96, 32, 16, 8)]   # heads, d, N, seg0, seg1
+LEVELS = [(16, 16, 2048, 1024, 512), (16, 32, 2048, 1024, 512), (16, 32, 512, 256, 128), (16, 64, 512, 256, 128), (16, 64, 128, 64, 32),
+          (16, 96, 32, 16, 8)]   # heads, d, N, seg0, seg1 (configs/ldm/skytimelapse.yaml at 16 x 256^2: tools/prof_attn_shapes.py lists them)
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
