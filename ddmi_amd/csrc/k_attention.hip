@@ -853,6 +853,221 @@ __global__ void __launch_bounds__(512) attention_res_kernel(AttnArgs a) {
 }
 
 // =====================================================================================================
+// RESIDENT form for d = 16 on the 32 x 32 x 16 MFMA (the tri-plane UNet's first attention level, 11 % of config 5's step on the 16 x 16 x 32
+// form above).  K = 16 IS the head dim, so nothing is padded, and the shape's 32 rows leave room for what the 16 x 16 form needed extra
+// MFMAs for:
+//   S^T = K . Q^T      ONE MFMA per 32 keys x 32 queries (A = 32 key rows of 32 B straight from LDS: lane (key l & 31, half l >> 5)
+//                      reads its 16 B - a contiguous KiB, no swizzle; B = the query fragment, loaded once)
+//   O^T = V^T . P^T    A = [16 channels of V^T | a ROW OF ONES | 15 zero rows] x 16 keys: the row of ones delivers the softmax
+//                      denominator as row 16 of the same product - two MFMAs per 32 keys carry the output AND the row sums.  P^T is the
+//                      score accumulator itself (registers 8 s .. 8 s + 7 -> k-step s, cdna_hip_programming.md "accumulator tile as
+//                      the next MFMA's operand"); the V^T fragment comes by two transposed reads per k-step whose lanes 16-31 / 48-63
+//                      (rows 16-31 of A) point at a constant LDS table [1, 0, ..., 0] per 32-byte row instead of V - no select.
+// Per 1024 scores: 3 MFMAs of 32 cycles (8 of 16 before) that hold the vector issue for 24 cycles (64 before) beside the same 16
+// exponentials per lane.  And with every score of a query within 2^100 of ZERO (|q| max|k| <= 100: the Cauchy-Schwarz bound the
+// 16 x 16 form compares with its first tile) no reference maximum is needed at all: p = exp2(s), C = 0.  Rounds whose bound is larger
+// run a tracked loop (p = exp2(s - m), m moved lazily).
+// Requirements (else the 16 x 16 form): d == 16, N a multiple of 1024 and <= 2048, the resident form's others.
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <bool SEG3>
+__global__ void __launch_bounds__(512) attention_res16_kernel(AttnArgs a) {
+  using T = bf16_t;
+  constexpr int RB = 32, QF = 4;   // four 32-query fragments per wave and round
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  unsigned char* const Ks = att_smem;
+  unsigned char* const Vs = att_smem + N * RB;
+  float* const red = reinterpret_cast<float*>(att_smem + 2 * N * RB);   // [8] per-wave maxima of |k|^2
+  unsigned char* const tab = att_smem + 2 * N * RB + 256;               // 1280 B of 32-byte rows [1, 0 x 15] (256-byte aligned)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hf = lane >> 5;
+  const int L = blockIdx.x, slot = L >> 3;
+  const int bl = slot / a.heads, h = slot - bl * a.heads, b = bl * 8 + (L & 7);
+  if (b >= a.B) return;   // padded grid: workgroup-uniform, before any barrier
+
+  for (int e = tid; e < 640; e += 512) reinterpret_cast<bf16_t*>(tab)[e] = (bf16_t)((e & 15) == 0 ? 1.0f : 0.0f);
+  // ---- K | V of (b, h) -> LDS by LDS-DMA (attention_res_kernel's fill at d = 16: 32 keys per wave-instruction, natural rows) ----------
+  {
+    const int key_l = lane >> 1, ps = lane & 1;
+    for (int it = wave; it < N / 32; it += 8) {
+      int n = it * 32, seg = 0;
+      if (SEG3) {
+        if (n >= a.seg_len[0]) { n -= a.seg_len[0]; seg = 1; if (n >= a.seg_len[1]) { n -= a.seg_len[1]; seg = 2; } }
+      }
+      const int sl = a.seg_len[seg];
+      const T* base = (const T*)a.qkv[seg] + (int64_t)b * sl * a.ld_qkv + h * a.hs_qkv;
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(sl * a.ld_qkv * 2), 0x00020000);
+      const unsigned row = (unsigned)((n + key_l) * a.ld_qkv);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (att_lds_void*)(Ks + it * 1024), 16, (row + a.k_off + ps * 8) * 2, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (att_lds_void*)(Vs + it * 1024), 16, (row + a.v_off + ps * 8) * 2, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __syncthreads();
+  {
+    float km = 0.f;
+    for (int key = tid; key < N; key += 512) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const bf16x8 kv = *reinterpret_cast<const bf16x8*>(Ks + key * RB + sl * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 = __builtin_fmaf((float)kv[e], (float)kv[e], s2);
+      }
+      km = fmaxf(km, s2);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) km = fmaxf(km, __shfl_xor(km, m));
+    if (lane == 0) red[wave] = km;
+  }
+  __syncthreads();
+  float Kmax2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) Kmax2 = fmaxf(Kmax2, red[w]);
+
+  auto row_of = [&](int n, int* seg) -> int64_t {
+    if constexpr (SEG3) return att_row(a, b, n, seg);
+    *seg = 0;
+    return (int64_t)b * a.seg_len[0] + n;
+  };
+  // transposed-read lane roles: 16-lane group g = lane >> 4; groups 0 / 2 (rows 0-15 of A, halves 0 / 1) read V, groups 1 / 3 the table.
+  // A read of half hf touches V rows 4 hf + tq (+ 8 jj + 16 s + 32 tile): banks 0-31 for hf = 0, 32-63 for hf = 1 (128-byte windows) -
+  // the table lanes of the same 32-lane half use the OTHER bank half (table + 128 for hf = 0).
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  const bool real = ((lane >> 4) & 1) == 0;
+  const unsigned char* const v0 = real ? Vs + (4 * hf + tq) * RB + tp * 8 : tab + (hf == 0 ? 128 : 0) + tq * RB + tp * 8;
+  const int vstep = real ? 32 * RB : 0;   // per 32-key tile
+  const int ntiles = N / 32, qpw = N >> 3, rounds = qpw / (32 * QF);
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#pragma unroll 1
+  for (int rnd = 0; rnd < rounds; ++rnd) {
+    const int q0 = wave * qpw + rnd * (32 * QF);
+    bf16x8 qb[QF];
+    float qmax2 = 0.f;
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      int seg = 0;
+      const int64_t rr = row_of(q0 + qf * 32 + r, &seg);
+      const T* qp = (const T*)(SEG3 ? a.qkv[seg] : a.qkv[0]) + rr * a.ld_qkv + a.q_off + h * a.hs_qkv;
+      qb[qf] = *reinterpret_cast<const bf16x8*>(qp + 8 * hf);
+      float s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s2 = __builtin_fmaf((float)qb[qf][e], (float)qb[qf][e], s2);
+      qmax2 = fmaxf(qmax2, s2);
+    }
+    // |q|^2 of a row = its two halves' partials <= the sum over the halves of each half's maximum over rows
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) qmax2 = fmaxf(qmax2, __shfl_xor(qmax2, m));
+    qmax2 += __shfl_xor(qmax2, 32);
+    const bool plain = __builtin_sqrtf(qmax2 * Kmax2) <= 100.0f;   // every score of the round within 2^100 of zero (false for NaN)
+
+    f32x16 o[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qf][e] = 0.f;
+    const unsigned char* kp = Ks + r * RB + hf * 16;
+    const unsigned char* vp = v0;
+    {   // the two waves of a SIMD (w, w + 4): the younger holds the priority for the first two thirds of the rounds' tiles (k_attnblock.hip)
+      if (rnd == 0) { if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    }
+    auto pv = [&](const bf16x8 (&pa)[QF], const bf16x8 (&pb)[QF]) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vp + 512 * s2));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vp + 512 * s2 + 256));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) o[qf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, s2 == 0 ? pa[qf] : pb[qf], o[qf], 0, 0, 0);
+      }
+    };
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+#pragma unroll 1
+      for (int kt = 0; kt < ntiles; ++kt) {
+        if (rnd * ntiles + kt == (2 * rounds * ntiles + 1) / 3) { if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp);
+        bf16x8 pa[QF], pb[QF];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          f32x16 z;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) z[e] = 0.f;
+          const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[qf], z, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pa[qf][e] = (bf16_t)__builtin_amdgcn_exp2f(sc[e]);
+            pb[qf][e] = (bf16_t)__builtin_amdgcn_exp2f(sc[8 + e]);
+          }
+        }
+        pv(pa, pb);
+        kp += 32 * RB;
+        vp += vstep;
+      }
+    } else {
+      // tracked: a per-query reference m (both halves of a query's lane pair hold the same), moved when a tile's maximum exceeds it by 2^6
+      float m_run[QF];
+#pragma unroll 1
+      for (int kt = 0; kt < ntiles; ++kt) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp);
+        bf16x8 pa[QF], pb[QF];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          f32x16 z;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) z[e] = 0.f;
+          const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[qf], z, 0, 0, 0);
+          float t = sc[0];
+#pragma unroll
+          for (int e = 1; e < 16; ++e) t = fmaxf(t, sc[e]);
+          t = fmaxf(t, __shfl_xor(t, 32));
+          if (kt == 0) {
+            m_run[qf] = t;
+          } else if (__builtin_amdgcn_ballot_w64(t > m_run[qf] + 6.0f) != 0) {
+            const float mn = fmaxf(m_run[qf], t);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qf] - mn);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qf][e] *= alpha;
+            m_run[qf] = mn;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pa[qf][e] = (bf16_t)__builtin_amdgcn_exp2f(sc[e] - m_run[qf]);
+            pb[qf][e] = (bf16_t)__builtin_amdgcn_exp2f(sc[8 + e] - m_run[qf]);
+          }
+        }
+        pv(pa, pb);
+        kp += 32 * RB;
+        vp += vstep;
+      }
+    }
+    // ---- output: row 16 of O^T (register 8 of the half-0 lane) is the denominator; the lane holds channels 4 hf + e and 8 + 4 hf + e ----
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+      const float den = __shfl(o[qf][8], r);
+      const float inv = 1.0f / den;
+      int seg = 0;
+      const int64_t rr = row_of(q0 + qf * 32 + r, &seg);
+      T* op = (T*)(SEG3 ? a.out[seg] : a.out[0]) + rr * a.ld_out + h * a.hs_out;
+      bf16x4 t0, t1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t0[e] = (bf16_t)(o[qf][e] * inv);
+        t1[e] = (bf16_t)(o[qf][4 + e] * inv);
+      }
+      *reinterpret_cast<bf16x4*>(op + 4 * hf) = t0;
+      *reinterpret_cast<bf16x4*>(op + 8 + 4 * hf) = t1;
+    }
+  }
+}
+
+// =====================================================================================================
 // STREAMING form for long sequences (round 4; the video decoder's inter-plane attention, autoencoder_unet.py:404-534: 8 heads of
 // d = 64 over 73 728 tokens and d = 128 over 20 480 - a fifth of config 5's step on the tiled kernel above, at 1.4 / 0.33 scores per
 // clock and SIMD).  Same loop as the resident form, but K / V cannot stay: one workgroup = 8 waves = 128 QF queries of one (sample,
@@ -1385,6 +1600,24 @@ static bool attention_res_ok(const AttnArgs& a, int N) {
   return a.ld_qkv % 8 == 0 && a.hs_qkv % 8 == 0 && a.q_off % 8 == 0 && a.k_off % 8 == 0 && a.v_off % 8 == 0;
 }
 
+static int launch_attention_res16(const AttnArgs& a, hipStream_t s) {
+  const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
+  const int lds = 2 * N * 32 + 256 + 1280;
+  auto kern1 = attention_res16_kernel<false>;
+  auto kern3 = attention_res16_kernel<true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 256 + 1280));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 256 + 1280));
+    attr_set = true;
+  }
+  dim3 grid(a.heads * cdiv(a.B, 8) * 8);
+  if (a.seg_len[1] + a.seg_len[2] == 0) hipLaunchKernelGGL(kern1, grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(kern3, grid, dim3(512), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}
+
 template <int D>
 static int launch_attention_res(const AttnArgs& a, hipStream_t s) {
   const int N = a.seg_len[0] + a.seg_len[1] + a.seg_len[2];
@@ -1489,7 +1722,11 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   }
   if (dt == DT_BF16 && a.vec_ok && a.d % 4 == 0 && a.d <= 128 && use_v2) {
     const bool big = N >= 128;
-    if (attention_res_ok(a, N)) return a.d == 16 ? launch_attention_res<16>(a, s) : launch_attention_res<32>(a, s);
+    if (attention_res_ok(a, N)) {
+      static const bool res16_off = getenv("DDMI_ATTN_RES16") && atoi(getenv("DDMI_ATTN_RES16")) == 0;   // diagnostics: the 16 x 16 x 32 form at d = 16
+      if (a.d == 16 && N % 1024 == 0 && !res16_off) return launch_attention_res16(a, s);
+      return a.d == 16 ? launch_attention_res<16>(a, s) : launch_attention_res<32>(a, s);
+    }
     if (a.d <= 32) return big ? launch_attention_v2<32, 2>(a, s) : launch_attention_v2<32, 1>(a, s);
     if (a.d <= 64) return big ? launch_attention_v2<64, 2>(a, s) : launch_attention_v2<64, 1>(a, s);
     return big ? launch_attention_v2<128, 2>(a, s) : launch_attention_v2<128, 1>(a, s);
