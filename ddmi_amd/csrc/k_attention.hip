@@ -27,6 +27,14 @@
 #include <type_traits>
 
 #define ATT_QB 64   // queries per workgroup
+// A/B builds (tools/build_variant.sh): static priority of one half of the streaming kernel's waves (1: waves 4-7, 2: waves 0-3);
+// 0 drops the priority hand-over of the d = 16 resident kernel's two waves per SIMD
+#ifndef ATT_STREAM_PRIO
+#define ATT_STREAM_PRIO 0
+#endif
+#ifndef ATT_RES16_PRIO
+#define ATT_RES16_PRIO 1
+#endif
 
 // 16-byte slot swizzle of the bf16 K tile, conflict-free for the four ds_read_b128 lane groups at every row size:
 // 64-byte rows (D = 32): slot ^ {0,2,3,1}[(row>>2)&3];  128-byte rows: slot ^ ((row>>1)&7);  >= 256-byte rows: every
@@ -975,7 +983,7 @@ __global__ void __launch_bounds__(512) attention_res16_kernel(AttnArgs a) {
     const unsigned char* kp = Ks + r * RB + hf * 16;
     const unsigned char* vp = v0;
     {   // the two waves of a SIMD (w, w + 4): the younger holds the priority for the first two thirds of the rounds' tiles (k_attnblock.hip)
-      if (rnd == 0) { if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      if (ATT_RES16_PRIO && rnd == 0) { if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     }
     auto pv = [&](const bf16x8 (&pa)[QF], const bf16x8 (&pb)[QF]) {
 #pragma unroll
@@ -991,7 +999,7 @@ __global__ void __launch_bounds__(512) attention_res16_kernel(AttnArgs a) {
     if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
 #pragma unroll 1
       for (int kt = 0; kt < ntiles; ++kt) {
-        if (rnd * ntiles + kt == (2 * rounds * ntiles + 1) / 3) { if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        if (ATT_RES16_PRIO && rnd * ntiles + kt == (2 * rounds * ntiles + 1) / 3) { if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp);
         bf16x8 pa[QF], pb[QF];
 #pragma unroll
@@ -1170,6 +1178,11 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(AttnArgs a) {
     for (int kk = 0; kk < NKK; ++kk) qb[qf][kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32 + 8 * lg);
   }
 
+#if ATT_STREAM_PRIO == 1
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#elif ATT_STREAM_PRIO == 2
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
   float m_run[QF];
   f32x4 o[QF][NDF], ol[QF];
   bf16x8 ones;
