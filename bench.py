@@ -133,15 +133,17 @@ def _profile_entry(glob_pat, live_name):
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
-        ms = re.match(r"attention_mh\[B\d+,h\d+,d(\d+),N(\d+)", live_name)   # the sky leg's shape-tagged scopes -> the instantiation that shape runs
-        if ms:
-            d, n = int(ms.group(1)), int(ms.group(2))
-            live_name = (f"attention_res_kernel<{d}," if d in (16, 32) and 1024 <= n and n * d * 4 <= 128 * 1024 else
-                         f"attention_stream_kernel<{d}," if d in (64, 128, 256, 512) and n >= 2048 else "attention_mh")
         alias = {"mlp2d_fused": "mlp2d_v2_kernel", "mlp3d_fused": "mlp3d_v2_kernel", "mlpvideo_fused": "mlpv_v2_kernel",
                  "attention_legacy": "attention_v2_kernel", "attention_mh": "attention_", "attnblock_qkv_attn": "attnblock_kernel",
                  "wgrad_tn": "wgrad_tn_kernel"}
-        pat = re.compile(re.escape(alias.get(live_name, live_name.split("<")[0])))
+        key = alias.get(live_name, live_name.split("<")[0])
+        ms = re.match(r"attention_mh\[B\d+,h\d+,d(\d+),N(\d+)", live_name)   # the sky leg's shape-tagged scopes -> the instantiation that shape runs
+        if ms:                                                                  # (k_attention.hip `launch_attention`)
+            d, n = int(ms.group(1)), int(ms.group(2))
+            resident = d in (16, 32) and 1024 <= n and n % 512 == 0 and n * d * 4 <= 128 * 1024
+            key = ("attention_res16_kernel" if resident and d == 16 and n % 1024 == 0 else f"attention_res_kernel<{d}," if resident else
+                   f"attention_stream_kernel<{d}," if d in (32, 64, 128, 256, 512) and n >= 2048 else "attention_v2_kernel" if d <= 128 else "attention_mh_kernel")
+        pat = re.compile(re.escape(key))
     with open(files[-1]) as f:
         doc = json.load(f)
     for name, v in doc["kernels"].items():

@@ -235,6 +235,11 @@ def test_bench_profile_lookups_and_bounded_cpu_samples():
     assert "pmc_traffic_b512" in src_afhq["file"] and "pmc_traffic_train" in src_train["file"]
     assert bench.pmc_traffic("mlp3d_fused", "shapenet")[0] and bench.pmc_traffic("attention_mh", "sky")[0]
     assert bench.pmc_traffic("attnblock_qkv_attn", "afhq")[0]                 # the fused AttentionBlock launch is in the b512 passes
+    # the sky leg's shape-tagged attention scopes resolve to the instantiation that shape runs (k_attention.hip `launch_attention`)
+    t64, _ = bench.pmc_traffic("attention_mh[B8,h8,d64,N73728,seg3]", "sky")
+    t512, _ = bench.pmc_traffic("attention_mh[B8,h8,d512,N2048,seg3]", "sky")
+    t16, _ = bench.pmc_traffic("attention_mh[B256,h16,d16,N2048,seg3]", "sky")
+    assert t64 and t512 and t16 and t64 > 4 * t512 and len({t64, t512, t16}) == 3
     assert bench.pmc_traffic("no_such_kernel", "afhq") == (None, None)         # a kernel the file does not hold: null, never a stale number
     calls = []
     mean, n = bench.timed_evals(lambda a: (calls.append(a), time.sleep(0.05)), [(1,), (2,), (3,)], budget_s=0.07)
