@@ -19,6 +19,15 @@
 // Template: D = head dim rounded up to {32, 64, 128, 256, 512} (channels >= d are zero-filled), DV = value / output
 // channels handled by one workgroup (blockIdx.z walks the slices; S is recomputed per slice), KT = keys per LDS tile.
 // bf16 path: v_mfma_f32_16x16x32_bf16, fp32 softmax/accumulate.  fp32 (parity) path: v_mfma_f32_16x16x4_f32.
+//
+// The kernels of this file, by who runs where (launch_attention, bf16 with q pre-scaled unless noted):
+//   attention_mh_kernel      the generic form above: fp32 handles, odd head dims / token counts, d > 128 off the streaming shapes
+//   attention_v2_kernel      d <= 128, 128 (QF = 2) or 64 queries per workgroup, K / V tiles re-staged through LDS; the only one with the
+//                            log-sum-exp output (training forward) and the eager maximum (q not pre-scaled)
+//   attention_res_kernel     d = 16 / 32, 1024 <= N <= 128 KB / 4d: K / V of a (sample, head) resident in LDS (round 4)
+//   attention_res16_kernel   d = 16, N a multiple of 1024: the same on the 32 x 32 x 16 MFMA, denominator as a row of V^T P^T (round 4)
+//   attention_stream_kernel  d = 32 .. 512, N >= 2048: 128 QF queries per workgroup, LDS-DMA ring (round 4)
+//   attention_x3_kernel      bf16x3 parity handles: fp32 tensors, three bf16 MFMA products per matrix product (round 4)
 #include "kernels.h"
 #include "prof.h"
 #include <math.h>
