@@ -431,7 +431,9 @@ def run_shapenet(args, rank, local_rank, world, dev):
     from ddmi_amd.config import load_ldm_args
     from ddmi_amd.occupancy import occupancy_grid_logits
     from ddmi_amd.pipeline import OccupancyPipeline
-    B = args.batch or 1024   # the small nets need the batch to fill the chip: 99.3 shapes/s at 512, 105.7 at 1024, 108.3 at 2048 (round 3, one box)
+    # the small nets need the batch to fill the chip (16 x 16 latents: 4096 chains are the 1 M-row GEMMs the AFHQ UNet runs at 512): 99.3 shapes/s
+    # at 512, 105.7 at 1024, 108.3 at 2048 (round 3, one box); round 4: 107-108 at 1024, 111.7 at 2048, 114.6 at 4096 (36 s per step)
+    B = args.batch or 4096
     a = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "shapenet.yaml"))
     ddpmconfig = dict(a.ddpmconfig, timesteps=args.nfe, sampling_timesteps=args.nfe, ddim_sampling_eta=1.0)
     pipe = OccupancyPipeline(a.unetconfig, a.ddconfig, a.mlpconfig, ddpmconfig, a.embed_dim, threshold=0.2, resolution0=128,
@@ -722,7 +724,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
-    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 1024, sky 256, train 128)")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 4096, sky 256, train 128)")
     ap.add_argument("--no-graph", action="store_true", help="train workload: eager launches instead of the hipGraph replay")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
