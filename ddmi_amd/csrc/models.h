@@ -24,12 +24,14 @@ struct UNet {
 int unet_finalize(UNet& u);
 // weight bundles of the blocks shared by the image and video networks (created once, emitted per tensor)
 struct ResW { int gn1 = -1, c1 = -1, gn2 = -1, c2 = -1, cs = -1, cs2 = -1, emb_off = -1; float eps = 1e-5f;
-              int cs_full = -1; };   // cs_full: the un-split 1x1 skip_connection (folded into c2's launch where the shape allows)
+              int cs_full = -1;      // cs_full: the un-split 1x1 skip_connection (folded into c2's launch where the shape allows)
+              int emb_rep = 1; };    // 4: the embedding rows are repeated for the four pixels of a 2 x 2 image (Net::op_conv, dense form)
 struct AttnW { int gn = -1, cqkv = -1, cp = -1, heads = 1, head_dim = 0, legacy = 0; float eps = 1e-5f, scale = 1.f;
                int q_prescaled = 0;      // the projection's q rows carry scale x log2 e (bf16 networks, k_attention.hip LAZY)
                int fused = -1; };        // Net::attnblocks index: qkv projection + attention in one launch where the shape allows
 // split > 0: the input will be the channel concat of a `split`-channel tensor and another one (emit_resblock_cat)
-int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split = 0);
+// emb_rep = 4: the block will only run on a 2 x 2 image of a bf16 network (Net::px4_ok): its embedding rows are appended four times
+int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split = 0, int emb_rep = 1);
 int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out);
 int make_vae_resblock(Net& n, const std::string& pre, int cin, int cout, ResW* w);
 int emit_resblock(Net& n, const ResW& w, int x, int* out);

@@ -22,7 +22,7 @@ static bool in_list(const int* v, int n, int x) {
 //   h = conv3(SiLU(GN(x))) + emb_proj ; h = conv3(SiLU(GN(h))) ; out = skip(x) + h
 // Weights are created once (make_*) and may be emitted on several tensors (the video UNet runs every block on the
 // xy plane and on the stacked xt / yt planes with the same weights).
-int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split) {
+int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW* w, int split, int emb_rep) {
   Net& n = u.net;
   w->eps = 1e-5f;
   DDMI_TRY(n.make_gn(pre + "in_layers.0.", &w->gn1));
@@ -34,8 +34,11 @@ int make_unet_resblock(UNet& u, const std::string& pre, int cin, int cout, ResW*
   if (!ew || !eb) return ddmi_fail(DDMI_ERR_MISSING_WEIGHT, "missing weight '" + pre + "emb_layers.1.*'");
   DDMI_REQUIRE(ew->shape.size() == 2 && ew->shape[0] == cout && ew->shape[1] == u.emb_dim, "emb_layers shape mismatch at " + pre);
   w->emb_off = (int)u.emb_b_host.size();
-  u.emb_w_host.insert(u.emb_w_host.end(), ew->data.begin(), ew->data.end());
-  u.emb_b_host.insert(u.emb_b_host.end(), eb->data.begin(), eb->data.end());
+  w->emb_rep = emb_rep;
+  for (int r = 0; r < emb_rep; ++r) {   // (4: one copy of the rows per pixel of the 2 x 2 image, the dense convolution's channel order)
+    u.emb_w_host.insert(u.emb_w_host.end(), ew->data.begin(), ew->data.end());
+    u.emb_b_host.insert(u.emb_b_host.end(), eb->data.begin(), eb->data.end());
+  }
   DDMI_TRY(n.make_gn(pre + "out_layers.0.", &w->gn2));
   DDMI_TRY(n.make_conv(pre + "out_layers.3.weight", pre + "out_layers.3.bias", &w->c2));
   w->cs = w->cs2 = -1;
@@ -74,7 +77,7 @@ int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out) {
     sk = n.op_conv(x2, w.cs2, 1, 0, sk, -1);
   }
   int a = n.op_gn(x1, w.gn1, 1, w.eps, x2);
-  int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off);
+  int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off, 1.f, w.emb_rep == 4);
   int b = n.op_gn(h, w.gn2, 1, w.eps);
   if (fold) return n.op_conv_skip(b, w.c2, x1, x2, w.cs_full, out);
   *out = n.op_conv(b, w.c2, 1, 0, sk, -1);
@@ -87,7 +90,7 @@ int emit_resblock(Net& n, const ResW& w, int x, int* out) {
   int skip = x;
   if (w.cs >= 0 && !fold) skip = n.op_conv(x, w.cs, 1, 0, -1, -1);
   int a = n.op_gn(x, w.gn1, 1, w.eps);
-  int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off);
+  int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off, 1.f, w.emb_rep == 4);
   int b = n.op_gn(h, w.gn2, 1, w.eps);
   if (fold) return n.op_conv_skip(b, w.c2, x, -1, w.cs, out);
   *out = n.op_conv(b, w.c2, 1, 0, skip, -1);
@@ -96,7 +99,7 @@ int emit_resblock(Net& n, const ResW& w, int x, int* out) {
 
 static int build_resblock(UNet& u, const std::string& pre, int x, int cout, int* out) {
   ResW w;
-  DDMI_TRY(make_unet_resblock(u, pre, u.net.tensors[x].C, cout, &w));
+  DDMI_TRY(make_unet_resblock(u, pre, u.net.tensors[x].C, cout, &w, 0, u.net.px4_ok(x) ? 4 : 1));
   return emit_resblock(u.net, w, x, out);
 }
 
@@ -334,7 +337,7 @@ int unet_finalize(UNet& u) {
       static const bool no_cat = !(getenv("DDMI_KEEP_CONCAT") && getenv("DDMI_KEEP_CONCAT")[0] == '1');  // diagnostics
       if (ta.C + tb.C != cout && no_cat) {  // th.cat([h, hs.pop()], 1) is read in place (dual-source GN, split skip conv)
         ResW w;
-        DDMI_TRY(make_unet_resblock(u, pre + "0.", ta.C + tb.C, cout, &w, ta.C));
+        DDMI_TRY(make_unet_resblock(u, pre + "0.", ta.C + tb.C, cout, &w, ta.C, n.px4_ok(h) ? 4 : 1));
         DDMI_TRY(emit_resblock_cat(n, w, h, skip, &h));
       } else {
         Op cat;

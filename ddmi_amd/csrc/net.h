@@ -27,6 +27,13 @@ struct ConvW {
   void* w_x3 = nullptr;   // bf16x3 numerics: [Cout][tap][wh | wh | wl] bf16 (launch_pack_conv_weight_x3); w stays null then
   void* w_up4 = nullptr;  // bf16 parity form for a fused x2 upsample (launch_pack_conv_up4), made by plan() when an op
   bool want_up4 = false;  // asked for it (op_conv only marks: it returns a tensor id, not a status)
+  // bf16 DENSE form of a 3x3 / pad 1 convolution on a 2 x 2 image (the lowest level of the occupancy UNet): every output pixel sees
+  // every input pixel through exactly one tap, so the convolution IS the 1x1 convolution [B][4 Cin] -> [B][4 Cout] with
+  // W4[(po, co)][(pi, ci)] = W[co][ci][yi - yo + 1][xi - xo + 1] over the same NHWC memory - 32 B Cin Cout FLOPs instead of the 72 the
+  // 3x3 form spends (5 of every 9 taps multiply padding).  Marked by op_conv, packed by plan() (pack_px4_weights)
+  void* w_px4 = nullptr;
+  float* bias_px4 = nullptr;   // the bias repeated for the four pixels
+  bool want_px4 = false;
   std::string wkey;       // state-dict key of the raw fp32 weight (make_conv), valid until finalize drops the host copies
 };
 
@@ -62,6 +69,8 @@ struct Op {
   float eps = 1e-5f;
   int stride = 1, pad = 0, ups = 0;
   int emb_off = -1;
+  int px4 = 0;         // OP_CONV: runs as the dense 1x1 form of a 3x3 convolution on a 2 x 2 image (ConvW::w_px4); emb_off then points at
+                       // embedding rows repeated for the four pixels
   int heads = 0;
   int head_dim = 0;    // OP_ATTN_MH
   int q_prescaled = 0;    // OP_ATTN_MH: q already carries softmax scale x log2 e (AttnW::q_prescaled)
@@ -133,12 +142,15 @@ struct Net {
   // w [3C][C], b [3C]: QKVAttentionLegacy order, q rows pre-scaled (make_unet_attnblock)
   int make_attnblock(const std::vector<float>& w, const std::vector<float>& b, int C, int heads, int* idx);
   int op_gn(int in, int gn, int silu, float eps, int in2 = -1);  // in2 >= 0: GroupNorm of the channel concat [in | in2]
-  int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f);
+  // emb_px4: the rows at emb_off are repeated four times (make_unet_resblock emb_rep = 4), as the dense 2 x 2 form needs them
+  int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f, bool emb_px4 = false);
+  bool px4_ok(int in) const;   // a 3x3 / stride 1 convolution on tensor `in` may take the dense 2 x 2 form (bf16, 2 x 2 image, one plane)
   // conv3x3(in) + conv1x1([skip_in | skip_in2]) in one launch; false when this network / shape cannot fold (caller emits the two ops)
   bool can_fold_skip(int in, int conv) const;
   int op_conv_skip(int in, int conv, int skip_in, int skip_in2, int skip_conv, int* out);
   int make_conv_host(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<float>* bias, int* idx);
   int pack_up4_weights();  // parity-form weights of the marked upsample convolutions (called by plan)
+  int pack_px4_weights();  // dense 2 x 2 form of the marked convolutions (called by plan)
   void mark_x3_images();         // bf16x3: GroupNorm outputs consumed only by x3 convolutions are produced as x3 images (called by plan)
   void attach_channel_stats();  // pairs GroupNorm inputs with the convolutions that produce them (called by plan)
   int plan();   // liveness + arena + workspaces

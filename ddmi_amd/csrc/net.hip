@@ -183,10 +183,21 @@ int Net::op_gn(int in, int gn, int silu, float eps, int in2) {
   return o.out;
 }
 
-int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale) {
+bool Net::px4_ok(int in) const {
+  static const bool off = getenv("DDMI_CONV_PX4") && atoi(getenv("DDMI_CONV_PX4")) == 0;   // diagnostics: the 3x3 kernels at the 2 x 2 level too
+  const TensorDesc& t = tensors[in];
+  return !off && dt == DT_BF16 && !x3 && t.H == 2 && t.W == 2 && t.bmul == 1;
+}
+
+int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale, bool emb_px4) {
   const TensorDesc& t = tensors[in];
   ConvW& c = convs[conv];
   int pad = c.K / 2;
+  // 3x3 on a 2 x 2 image: the dense 1x1 form (ConvW::w_px4).  Needs the raw weights at plan() (a state-dict key) and channel counts
+  // the vector epilogues take; an embedding addend only when the caller repeated its rows for the four pixels
+  const bool px4 = px4_ok(in) && c.K == 3 && stride == 1 && ups == 0 && !c.wkey.empty() && c.Cin % 8 == 0 && c.Cout % 8 == 0 &&
+                   (emb_off < 0 || emb_px4);
+  if (px4) c.want_px4 = true;
   // x2 nearest upsample + 3x3 conv in the bf16 network: four 2x2 parity convolutions on the source grid (k_conv.hip).
   // Only marked here - op_conv returns a TENSOR id, so nothing that can fail lives in it; plan() packs the weights.
   static const bool up4 = !(getenv("DDMI_CONV_UP4") && atoi(getenv("DDMI_CONV_UP4")) == 0);
@@ -204,6 +215,7 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
   o.ups = ups;
   o.res = res;
   o.emb_off = emb_off;
+  o.px4 = px4 ? 1 : 0;
   o.scale = scale;
   ops.push_back(o);
   return o.out;
@@ -253,6 +265,12 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   if (o.ups == 1 && c.w_up4 && o.res < 0 && o.emb_off < 0) {  // parity form: same output, 2x2 taps on the source grid
     a->w = c.w_up4; a->ups = 3; a->KH = a->KW = 2; a->pad = 1;
   }
+  if (o.px4 && c.w_px4) {   // dense form on the 2 x 2 image: [B][1][1][4 Cin] -> [B][1][1][4 Cout] over the same memory
+    a->w = c.w_px4; a->bias = c.bias_px4;
+    a->Hin = a->Win = a->Hout = a->Wout = 1;
+    a->Cin = 4 * c.Cin; a->Cout = 4 * c.Cout;
+    a->KH = a->KW = 1; a->pad = 0;
+  }
   a->out_scale = o.scale;
   a->splitk = 1;
   if (o.skip_conv >= 0) {
@@ -272,6 +290,47 @@ static ConvArgs x3_launch_args(const ConvArgs& f, const void* x3_in, const void*
   a.out_scale = 1.f;
   a.force_ws = 1; a.splitk_ws = ws;
   return a;
+}
+
+// dense 2 x 2 form [4 Cout][4 Cin] of the convolutions op_conv marked (want_px4), from the raw fp32 weights (rounded once)
+int Net::pack_px4_weights() {
+  for (ConvW& c : convs) {
+    if (!c.want_px4 || c.w_px4) continue;
+    const HostTensor* raw = c.wkey.empty() ? nullptr : find(c.wkey);
+    DDMI_REQUIRE(raw && raw->numel() == (int64_t)c.Cout * c.Cin * 9, "dense 2x2 convolution: the raw 3x3 weight is gone");
+    const int Ci = c.Cin, Co = c.Cout;
+    std::vector<float> w4((size_t)16 * Co * Ci);
+    for (int po = 0; po < 4; ++po)
+      for (int co = 0; co < Co; ++co)
+        for (int pi = 0; pi < 4; ++pi) {
+          const int kh = (pi >> 1) - (po >> 1) + 1, kw = (pi & 1) - (po & 1) + 1;   // input pixel = output pixel + (tap - 1)
+          const float* src = raw->data.data() + ((size_t)co * Ci) * 9 + kh * 3 + kw;
+          float* dst = w4.data() + ((size_t)(po * Co + co) * 4 + pi) * Ci;
+          for (int ci = 0; ci < Ci; ++ci) dst[ci] = src[(size_t)ci * 9];
+        }
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, w4.size() * sizeof(float)));
+    const size_t bytes = w4.size() * dt_size(dt);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { (void)hipFree(tmp); return ddmi_fail(DDMI_ERR_HIP, "weight alloc failed"); }
+    dev_allocs.push_back(p);
+    e = hipMemcpy(tmp, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? launch_pack_conv_weight(tmp, p, dt, 4 * Co, 4 * Ci, 1, 1, 0) : ddmi_fail(DDMI_ERR_HIP, "weight upload failed");
+    hipError_t e2 = hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    DDMI_TRY(rc);
+    HIP_TRY(e2);
+    weight_bytes += bytes;
+    c.w_px4 = p;
+    if (c.bias) {
+      std::vector<float> b(Co), b4((size_t)4 * Co);
+      HIP_TRY(hipMemcpy(b.data(), c.bias, Co * sizeof(float), hipMemcpyDeviceToHost));
+      for (int po = 0; po < 4; ++po) std::copy(b.begin(), b.end(), b4.begin() + (size_t)po * Co);
+      DDMI_TRY(dev_upload(b4.data(), (int64_t)b4.size(), &c.bias_px4));
+    }
+  }
+  return DDMI_OK;
 }
 
 // parity-form weights [4][Cout][4][Cin] of the convolutions op_conv marked (want_up4); every failure is returned
@@ -346,6 +405,7 @@ void Net::attach_channel_stats() {
 
 int Net::plan() {
   DDMI_TRY(pack_up4_weights());
+  DDMI_TRY(pack_px4_weights());
   attach_channel_stats();
   mark_x3_images();
   const int nops = (int)ops.size();
@@ -607,7 +667,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
       case OP_CONV: {
         ConvArgs a;
         fill_conv_args(*this, o, B, &a);
-        DDMI_REQUIRE(tensors[o.in].C == a.Cin, "conv input channel mismatch");
+        DDMI_REQUIRE(tensors[o.in].C == convs[o.conv].Cin, "conv input channel mismatch");
         a.x = plane_ptr(o.in, o.in_boff);
         if (o.out_nchw) a.y_nchw = (float*)ext[o.ext];
         else a.y = plane_ptr(o.out, o.out_boff);
