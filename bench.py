@@ -636,7 +636,10 @@ def run_train(args, rank, local_rank, world, dev):
     from ddmi_amd import dist as D
     from ddmi_amd import initweights as iw
     from ddmi_amd.train import LDMTrainStep
-    B = args.batch or 128   # 732 samples/s at 64, 829 at 128, 867 at 256
+    # round 2: 732 samples/s at 64, 829 at 128, 867 at 256; round 4 (one box): 951 at 128, 956 at 192, 999 at 256, 990 at 384, 1 012 at 512 (191 GB of
+    # the 288 in use: saved activations of the backward) - the leg runs 512 (the reference's own per-GPU batch is 4 with gradient accumulation: any batch
+    # here is a throughput choice; tests/ pin the step at 2 .. 128)
+    B = args.batch or 512
     tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev,
                       use_graph=not args.no_graph)
     st = {"model." + k: v for k, v in iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
@@ -724,7 +727,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
-    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 4096, sky 256, train 128)")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 4096, sky 256, train 512)")
     ap.add_argument("--no-graph", action="store_true", help="train workload: eager launches instead of the hipGraph replay")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
