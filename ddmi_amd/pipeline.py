@@ -273,10 +273,12 @@ class OccupancyPipeline:
         return self
 
     def generate(self, indices: Sequence[int], base_seed: int = 777, return_latent: bool = False, rng: str = "philox",
-                 reseed: bool = True):
+                 reseed: bool = True, sink=None):
         """One TriMesh per GLOBAL sample index (per-sample noise streams, so the set does not depend on batching or on the
         number of GPUs); meshes are extracted one latent at a time, as the reference does (tools/ldm/occupancy.py:216-217).
-        `rng` as in ImagePipeline.generate."""
+        `rng` as in ImagePipeline.generate.  `sink`: a callable that takes each finished mesh (in index order) instead of the
+        returned list - the way to run thousands of chains per call without holding every mesh in host memory (the reference
+        writes each .obj as it is made); the list returned is then empty."""
         import torch
         assert rng in ("philox", "reference"), rng
         B = len(indices)
@@ -305,6 +307,7 @@ class OccupancyPipeline:
                 grid.record_stream(side)
                 return self.mesh_gen.mesh_from_grid(grid)[0]
 
+        keep = meshes.append if sink is None else sink
         for j0 in range(0, B, self.decode_batch):
             planes = self.vae.decode(z[j0:j0 + self.decode_batch].contiguous())
             for j in range(planes[0][0].shape[0]):
@@ -313,8 +316,8 @@ class OccupancyPipeline:
                 ready = torch.cuda.Event()
                 ready.record(main)
                 if pending is not None:
-                    meshes.append(finish(pending))
+                    keep(finish(pending))
                 pending = (grid, ready)
         if pending is not None:
-            meshes.append(finish(pending))
+            keep(finish(pending))
         return (meshes, z) if return_latent else meshes

@@ -160,6 +160,11 @@ def test_occupancy_pipeline_is_batch_invariant(golden):
     batched = pipe3.generate([5, 6, 7], base_seed=11)
     for m, ref in zip(batched, meshes):
         assert same(m.vertices, ref.vertices) and same(m.faces, ref.faces)
+    # `sink`: every mesh handed over as it is finished, in index order, nothing kept (bench.py runs thousands of chains per call this way)
+    got = []
+    assert pipe3.generate([5, 6, 7], base_seed=11, sink=got.append) == [] and len(got) == 3
+    for m, ref in zip(got, meshes):
+        assert same(m.vertices, ref.vertices) and same(m.faces, ref.faces)
 
 
 def test_occupancy_pipeline_bf16_batched_decode_and_side_stream(golden):
