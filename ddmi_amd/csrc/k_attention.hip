@@ -1660,12 +1660,17 @@ static int launch_attention_res(const AttnArgs& a, hipStream_t s) {
 }
 
 static int attention_stream_qf(int d) { return d <= 64 ? 4 : d == 128 ? 2 : 1; }
-static bool attention_stream_ok(const AttnArgs& a, int N) {
+// the (head dim, token count) pairs the streaming kernel serves, switches included - ONE predicate for the launcher below and for the
+// graph builders that choose the flash form only where this kernel will run (models.hip build_vae_attn)
+bool attention_stream_shape_ok(int d, int N) {
   static const bool off = getenv("DDMI_ATTN_STREAM") && atoi(getenv("DDMI_ATTN_STREAM")) == 0;   // diagnostics: the tiled kernels
   static const bool big_off = getenv("DDMI_ATTN_STREAM_BIG") && atoi(getenv("DDMI_ATTN_STREAM_BIG")) == 0;   // ... for d = 256 / 512 only
-  if (off || !a.q_prescaled || a.lse || !a.vec_ok || (a.d != 32 && a.d != 64 && a.d != 128 && a.d != 256 && a.d != 512)) return false;
-  if (a.d >= 256 && big_off) return false;
-  if (N < 2048 || N % (128 * attention_stream_qf(a.d)) != 0) return false;
+  if (off || (d != 32 && d != 64 && d != 128 && d != 256 && d != 512)) return false;
+  if (d >= 256 && big_off) return false;
+  return N >= 2048 && N % (128 * attention_stream_qf(d)) == 0;
+}
+static bool attention_stream_ok(const AttnArgs& a, int N) {
+  if (!a.q_prescaled || a.lse || !a.vec_ok || !attention_stream_shape_ok(a.d, N)) return false;
   for (int s = 0; s < 3; ++s)
     if (a.seg_len[s] % 64 != 0 || (int64_t)a.seg_len[s] * a.ld_qkv * 2 > 0x7FFFFFFFll) return false;
   return a.ld_qkv % 8 == 0 && a.hs_qkv % 8 == 0 && a.q_off % 8 == 0 && a.k_off % 8 == 0 && a.v_off % 8 == 0;
@@ -1736,7 +1741,7 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   PROF_SCOPE(pname, 4.0 * a.B * a.heads * (double)N * N * a.d, 4.0 * a.B * a.heads * N * a.d * dt_size(dt), s);
   static const int use_v2 = getenv("DDMI_ATTN_V1") ? 0 : 1;  // diagnostics: DDMI_ATTN_V1=1 pins the generic kernel
   if (dt == DT_BF16 && use_v2 && attention_stream_ok(a, N)) {
-    if (a.d == 32) return launch_attention_stream<32, 4, 64, 3>(a, s);   // (N > 1024: below that the resident kernel, checked first)
+    if (a.d == 32) return launch_attention_stream<32, 4, 64, 3>(a, s);   // (N >= 2048 only: the resident kernel below serves d = 32 up to 1024 tokens)
     if (a.d == 64) return launch_attention_stream<64, 4, 64, 3>(a, s);
     if (a.d == 128) return launch_attention_stream<128, 2, 64, 3>(a, s);
     if (a.d == 256) return launch_attention_stream<256, 1, 32, 3>(a, s);

@@ -158,6 +158,8 @@ struct AttnArgs {
                        // (written by attention_v2_kernel only: launch_attention refuses it on the other paths)
 };
 int launch_attention(const AttnArgs& a, int dt, hipStream_t s);
+// whether the bf16 streaming kernel (k_attention.hip attention_stream_kernel) serves head dim d at N tokens, diagnostics switches included
+bool attention_stream_shape_ok(int d, int N);
 int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse = nullptr);
 // k_attn_bwd.hip: one-pass backward from the forward's log-sum-exp (bf16, d = 32, T a multiple of 64)
 int launch_attention_legacy_backward_lse(const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,

@@ -489,7 +489,7 @@ static int build_vae_resblock(Net& n, const std::string& pre, int x, int cout, i
 static int build_vae_attn(Net& n, const std::string& pre, int x, int* out) {
   const TensorDesc t = n.tensors[x];
   // ONE fused q | k | v projection and the STREAMING attention kernel with a single head of C channels (k_attention.hip: d = 64 .. 512,
-  // >= 2048 tokens, a multiple of 128) instead of GEMM -> softmax -> transpose -> GEMM over a materialised [T][T] score matrix (33.5 MB
+  // >= 2048 tokens, whole 128 QF-query tiles: attention_stream_shape_ok) instead of GEMM -> softmax -> transpose -> GEMM over a materialised [T][T] score matrix (33.5 MB
   // per sample at the AFHQ decoder's 4096 tokens: 17 GB of arena and 67.6 GB through `softmax_rows` per launch at B = 512).  Round-3
   // verdict item 9.  Measured twice in round 4: on the generic kernel (S recomputed per 256-channel value slice, d = 512 QK^T from LDS
   // at a fifth of the MFMA rate) the decoder took 683 ms per 512 latents against 432; on the streaming kernel's d = 512 instantiation the
@@ -497,7 +497,7 @@ static int build_vae_attn(Net& n, const std::string& pre, int x, int* out) {
   // GEMMs, =1 takes the attention kernels for every shape.
   const char* fe = getenv("DDMI_VAE_ATTN_FLASH");
   const int T0 = t.H * t.W;
-  const bool streams = (t.C == 64 || t.C == 128 || t.C == 256 || t.C == 512) && T0 >= 2048 && T0 % 128 == 0;
+  const bool streams = t.C >= 64 && attention_stream_shape_ok(t.C, T0);   // the launcher's own predicate: the flash form only where that kernel runs
   const bool flash = fe ? atoi(fe) == 1 : streams;
   if (flash && n.dt == DT_BF16 && !n.x3 && t.C <= 512 && t.C % 8 == 0) {
     AttnW w;

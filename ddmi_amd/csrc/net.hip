@@ -550,16 +550,22 @@ int Net::plan() {
       }
       std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups, a.x2 ? a.C2 + a.C3 : 0};   // last: folded skip channels
       auto it = cache.find(key);
+      // a (cfg 0, 0 us) entry is the PLACEHOLDER an older strict run left in a plan file, not a measurement: treated as absent
+      if (it != cache.end() && it->second.cfg == 0 && it->second.us == 0.f) { cache.erase(it); own.erase(key); it = cache.end(); }
       if (it == cache.end()) {
         ConvPlan p;
         // DDMI_TUNE_STRICT=1: a shape the plan files do not hold takes the heuristic plan instead of a timing-based pick, so the
         // tile / split-K (and with them the bf16 rounding order) of every convolution is the same on every box and in every run -
-        // what the parity tests run under (tests/conftest.py)
+        // what the parity tests run under (tests/conftest.py).  That plan never reaches `used`: through it it would land in a
+        // read-write DDMI_TUNE_FILE (and in the plan text broadcast to other ranks), where a later non-strict run would take it for
+        // a tuned shape and never autotune it
         static const bool strict = getenv("DDMI_TUNE_STRICT") && atoi(getenv("DDMI_TUNE_STRICT")) != 0;
-        if (!strict) {
-          rc = conv_autotune(a, cdt, tws, tws_bytes, &p);
-          if (rc != DDMI_OK) break;
+        if (strict) {
+          o.tuned = ConvPlan{};
+          continue;
         }
+        rc = conv_autotune(a, cdt, tws, tws_bytes, &p);
+        if (rc != DDMI_OK) break;
         it = cache.emplace(key, p).first;
       }
       used[key] = it->second;

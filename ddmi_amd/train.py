@@ -659,6 +659,7 @@ class OverlappedGradReducer:
         self.next = 0
         self.works = []
         self.collectives = 0
+        self.late_written = False    # set by before_late_writes(): no bucket goes out after it (see range_done)
 
     def _active(self):
         import torch.distributed as dist
@@ -676,7 +677,10 @@ class OverlappedGradReducer:
             return
         self.next = idx + 1
         self.done_lo = self.ranges[idx][0]
-        if self._active() and self.sent_lo - self.done_lo >= self.bucket:
+        # after before_late_writes() the late views hold FINAL values: a bucket issued now would reduce them, and finish() - which
+        # redoes every late view of an early bucket - would sum them over the ranks a second time.  From then on range_done() only
+        # records progress; finish() sends the rest in one piece (whose late views it does not redo).
+        if self._active() and not self.late_written and self.sent_lo - self.done_lo >= self.bucket:
             self._issue(self.done_lo, self.sent_lo)
             self.sent_lo = self.done_lo
 
@@ -687,6 +691,14 @@ class OverlappedGradReducer:
         for w in self.works:
             w.wait()
         self.works = []
+        self.late_written = True
+
+    def abort(self):
+        """The backward raised: wait for what is in flight (the collectives run in place on the slab) and issue nothing more."""
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.late_written = True
 
     def finish(self):
         """After the backward: whatever is left of the slab (its head - `time_embed`, the first block - and anything below a bucket), then
@@ -845,6 +857,9 @@ class LDMTrainStep:
             n_out = len(self.model.output_blocks)
             order = (["mixing_logit"] if "mixing_logit" in spans else []) + ["out"] + [f"output_blocks.{j}" for j in reversed(range(n_out))] + \
                 ["middle_block"] + [f"input_blocks.{i}" for i in reversed(range(1, n_in))]
+            # a block without parameters (e.g. a Downsample with conv_resample=False) has no span of its own: it completes nothing,
+            # its neighbour's range_done() covers the slab up to there
+            order = [k for k in order if k in spans and spans[k][1] > spans[k][0]]
             self._reduce_plan = (order, [spans[k] for k in order], late)
         return self._reduce_plan
 
@@ -1067,9 +1082,18 @@ class LDMTrainStep:
 
     def train_step(self, z0, t=None, noise=None, world_size: int = 1):
         """The body of the reference's loop for one batch (tools/ldm/image.py:158-175)."""
+        if self.flat is None:         # the reducer views the flat gradient slab: lay it out before the hooks are installed
+            self.finalize()
         self._begin_overlapped_reduce(world_size)
         try:
             loss = self.loss_and_backward(z0, t, noise)
+        except BaseException:
+            # a backward that raised leaves buckets in flight over a half-written slab: wait them out and forget the reducer, so that
+            # a later optimizer_step() cannot finish() a partial reduction (it falls back to the blocking pass over what is there)
+            if self._reducer is not None:
+                self._reducer.abort()
+                self._reducer = None
+            raise
         finally:
             self._end_overlapped_reduce()
         if self.micro % self.accum == 0:

@@ -74,9 +74,30 @@ def bf16_metrics(a, b, axis=1):
     return {"linf": rel_err(a, b), "rel_l2": rel_l2(a, b), "min_channel_cos": channel_cosine_min(a, b, axis)}
 
 
+# Per-label limits (round-4 advisor): the global caps above let a 40 % precision regression of one network through (worst label
+# 0.0143 against 2.0e-2).  tests/golden/bf16_metric_baselines.json holds the worst (linf, rel_l2) every label measured in one full
+# plan-deterministic `pytest -m gpu` run (tools/bf16_metrics_summary.py --baselines <raw log>); a label that is in it must also stay
+# within BASELINE_SLACK x its own baseline - the runs are deterministic (pinned plans), the slack covers a re-ordered rounding chain
+# after a kernel change, not a lost bit (x sqrt(2)).
+BASELINE_SLACK = 1.2
+_BASELINES = None
+
+
+def bf16_baseline(what):
+    global _BASELINES
+    if _BASELINES is None:
+        p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_metric_baselines.json")
+        _BASELINES = json.load(open(p)) if os.path.exists(p) else {}
+    return _BASELINES.get(what)
+
+
 def assert_bf16_close(a, b, what="", linf=None, l2=None, cos=None, axis=1):
     """bf16 acceptance of a network output: L-infinity (of range) AND relative L2 AND the worst per-channel cosine."""
     m = bf16_metrics(a, b, axis)
+    base = bf16_baseline(what) if what and not os.environ.get("DDMI_NO_BF16_BASELINES") else None
+    if base is not None and linf is None and l2 is None:
+        linf = min(TOL_BF16, BASELINE_SLACK * base["linf"] + 1e-4)
+        l2 = min(TOL_BF16_L2, BASELINE_SLACK * base["rel_l2"] + 1e-4)
     if os.environ.get("DDMI_METRICS_LOG"):   # the numbers behind the thresholds, kept when a run asks for them
         with open(os.environ["DDMI_METRICS_LOG"], "a") as f:
             f.write(json.dumps({"what": what, **m}) + "\n")

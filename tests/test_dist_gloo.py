@@ -98,7 +98,7 @@ def test_config_loader_reads_reference_schema():
     assert DDPM(model=None, **b.ddpmconfig).is_ddim_sampling
 
 
-def _overlap_worker(rank, world, port, out_dir):
+def _overlap_worker(rank, world, port, out_dir, hooks_after_late=0):
     """A fake backward on two gloo ranks: the slab's ranges complete from its end, buckets go out while later ranges are still
     'computed', the late views are written last - against the blocking all-reduce of the same gradients."""
     sys.path.insert(0, ROOT)
@@ -123,13 +123,20 @@ def _overlap_worker(rank, world, port, out_dir):
             a2, b2 = max(a, lo), min(b, hi)
             if a2 < b2:
                 slab[a2:b2] = 0.0
-    for i, (lo, hi) in enumerate(ranges):
+    n_before = len(ranges) - hooks_after_late
+    for i, (lo, hi) in enumerate(ranges[:n_before]):
         write(lo, hi)
         red.range_done(i)
+    for lo, hi in ranges[n_before:]:
+        write(lo, hi)
     write(0, 100)                                               # the head (input_blocks.0, time_embed): no hook, left to finish()
     red.before_late_writes()
     for a, b in late:                                           # EmbProjFn.backward: the late views, accumulated into the slab
         slab[a:b] += local[a:b]
+    # hooks that fire AFTER the late writes (nothing but autograd's scheduling keeps a block-input hook in front of EmbProjFn.backward):
+    # a bucket issued now would carry final late values that finish() then reduces a second time - range_done() must only record
+    for i in range(n_before, len(ranges)):
+        red.range_done(i)
     red.finish()
     torch.save({"overlapped": slab, "blocking": blocking, "collectives": red.collectives}, os.path.join(out_dir, f"ov{rank}.pt"))
     D.barrier()
@@ -145,6 +152,16 @@ def test_overlapped_gradient_allreduce_equals_the_blocking_one(tmp_path):
         rec = torch.load(os.path.join(tmp_path, f"ov{rank}.pt"))
         assert torch.equal(rec["overlapped"], rec["blocking"]), rank
         assert rec["collectives"] >= 3          # buckets during the backward + the head + the gathered late views
+
+
+def test_overlapped_allreduce_with_hooks_firing_after_the_late_writes(tmp_path):
+    """Round-4 advisor item: a range_done() after before_late_writes() must not send a bucket (its late views are final by then and
+    finish() would sum them over the ranks twice).  Two of the five block hooks fire late here; the slab still equals the blocking pass."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path), 2), nprocs=world, join=True)
+    for rank in range(world):
+        rec = torch.load(os.path.join(tmp_path, f"ov{rank}.pt"))
+        assert torch.equal(rec["overlapped"], rec["blocking"]), rank
 
 
 def test_reduce_plan_ranges_follow_the_slab_layout():

@@ -246,3 +246,22 @@ def test_bench_profile_lookups_and_bounded_cpu_samples():
     assert n == 2 and calls == [1, 2] and 0.04 < mean < 0.2
     mean, n = bench.timed_evals(lambda a: time.sleep(0.02), [(1,)], budget_s=0.0)
     assert n == 1
+
+
+def test_op_package_imports_resolve_without_a_gpu():
+    """models/d2c_vae/op/__init__.py:1-2 imports `FusedLeakyReLU, fused_leaky_relu` and `upfirdn2d`; both of the reference's modules
+    JIT-build CUDA at import (op/fused_act.py:10-16, op/upfirdn2d.py:9-15).  INTEGRATION.md §2 swaps them for these two modules: the
+    imports must succeed on a box with no GPU and no nvcc, and the operator that is NOT on the generation path must fail loudly when
+    called (an import-only stand-in, not a silent identity)."""
+    import inspect
+    from ddmi_amd.fused_act import FusedLeakyReLU, fused, fused_leaky_relu  # noqa: F401  (the names op/__init__.py:1 imports)
+    from ddmi_amd.upfirdn2d import upfirdn2d, upfirdn2d_native, upfirdn2d_op  # (op/__init__.py:2, op/upfirdn2d.py:9)
+    assert list(inspect.signature(upfirdn2d).parameters) == ["input", "kernel", "up", "down", "pad"]   # op/upfirdn2d.py:144
+    assert list(inspect.signature(upfirdn2d_native).parameters) == ["input", "kernel", "up_x", "up_y", "down_x", "down_y", "pad_x0",
+                                                                    "pad_x1", "pad_y0", "pad_y1"]
+    assert FusedLeakyReLU(8).bias.shape == (8,)       # constructible without touching the library
+    x, k = torch.zeros(1, 1, 4, 4), torch.ones(2, 2)
+    for call in (lambda: upfirdn2d(x, k, up=2, pad=(1, 0)), lambda: upfirdn2d_native(x, k, 1, 1, 1, 1, 0, 0, 0, 0),
+                 lambda: upfirdn2d_op.upfirdn2d(x, k, 1, 1, 1, 1, 0, 0, 0, 0)):
+        with pytest.raises(NotImplementedError, match="generation path"):
+            call()

@@ -7,6 +7,14 @@ import sys
 LIMITS = {"linf": 0.04, "rel_l2": 0.02, "min_channel_cos": 0.999}
 
 if __name__ == "__main__":
+    if sys.argv[1] == "--baselines":   # -> tests/golden/bf16_metric_baselines.json: {label: {linf, rel_l2}} (worst per label), tests/helpers.py
+        worst = {}
+        for r in (json.loads(line) for line in open(sys.argv[2]) if line.strip()):
+            w = worst.setdefault(r["what"], {"linf": 0.0, "rel_l2": 0.0})
+            w["linf"] = round(max(w["linf"], r["linf"]), 6)
+            w["rel_l2"] = round(max(w["rel_l2"], r["rel_l2"]), 6)
+        print(json.dumps(worst, indent=0, sort_keys=True))
+        sys.exit(0)
     rows = [json.loads(line) for line in open(sys.argv[1]) if line.strip()]
     head = sys.argv[2] if len(sys.argv) > 2 else "unknown"
     worst = {}
