@@ -127,8 +127,13 @@ SYMBOLS = {
     "ddmi_op_conv2d_skip": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "ddmi_bench_conv": (_I, [_I] * 13 + [C.POINTER(C.c_double), C.POINTER(_I)]),
     "ddmi_debug_conv_config": (_I, [_I]),
+    "ddmi_debug_halo_half": (_I, [_I]),
     "ddmi_op_attention_block": (_I, [_VP] * 8 + [_I] * 6 + [C.POINTER(_I)]),
     "ddmi_debug_attn_fused": (_I, [_I]),
+    "ddmi_debug_gn_fuse": (_I, [_I]),
+    "ddmi_op_conv1x1_cat": (_I, [_VP] * 5 + [_I] * 7 + [C.POINTER(_I)]),
+    "ddmi_op_conv_gn": (_I, [_VP] * 7 + [_I] * 5 + [C.c_float] + [_I] * 3 + [C.POINTER(_I)]),
+    "ddmi_unet_async_status": (_I, [_VP, C.POINTER(_I)]),
     "ddmi_bench_peak_mfma": (_I, [C.c_double, C.POINTER(C.c_double)]),
     "ddmi_bench_peak_copy": (_I, [C.c_double, C.POINTER(C.c_double)]),
     "ddmi_bench_attention_block": (_I, [_I] * 5 + [C.POINTER(C.c_double), C.POINTER(_I)]),

@@ -95,6 +95,11 @@ int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps
   DDMI_REQUIRE(h, "null handle");
   return unet_forward(h->u, x, t, eps_out, B, (hipStream_t)stream);
 }
+int ddmi_unet_async_status(ddmi_unet* h, int* fused_gn_launches) {
+  DDMI_REQUIRE(h, "null handle");
+  if (fused_gn_launches) *fused_gn_launches = h->u.net.fgn_launches;
+  return h->u.net.async_status();
+}
 int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled) {
   DDMI_REQUIRE(h, "null handle");
   h->u.uniform_t = enabled != 0;
@@ -631,6 +636,108 @@ int ddmi_bench_peak_mfma(double seconds_target, double* tflops) {
 int ddmi_bench_peak_copy(double gib, double* tb_per_s) {
   DDMI_REQUIRE(tb_per_s && gib >= 0.25 && gib <= 32, "bench_peak_copy: bad arguments");
   return bench_peak_copy(gib, tb_per_s);
+}
+
+int ddmi_debug_halo_half(int mode) {
+  conv_halo_half_override(mode);
+  return DDMI_OK;
+}
+
+int ddmi_debug_gn_fuse(int mode) {
+  net_gn_fuse_override(mode);
+  return DDMI_OK;
+}
+
+// conv3x3 (+ bias + per-sample embedding row) -> GroupNorm32 [+ SiLU] as the ResBlock builds the pair (openaimodel.py:261-270), through the
+// network executor: NCHW in -> OP_CONV -> OP_GN -> NCHW out.  `iters` runs of the same net (the fused form's cross-workgroup hand-off under
+// repetition); *fused_used = fused launches of the last run
+int ddmi_op_conv_gn(const float* x, const float* w, const float* bias, const float* emb, const float* gamma, const float* beta, float* y,
+                    int B, int Cin, int H, int W, int Cout, float eps, int silu, int numerics, int iters, int* fused_used) {
+  DDMI_REQUIRE(x && w && bias && gamma && beta && y && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && iters > 0, "op_conv_gn: bad arguments");
+  Net n;
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(numerics, &n.dt, &x3));
+  n.x3 = x3;
+  n.max_batch = B;
+  const int64_t sw[4] = {Cout, Cin, 3, 3}, s1[1] = {Cout};
+  DDMI_TRY(n.add_host("c.weight", w, sw, 4));
+  DDMI_TRY(n.add_host("c.bias", bias, s1, 1));
+  DDMI_TRY(n.add_host("g.weight", gamma, s1, 1));
+  DDMI_TRY(n.add_host("g.bias", beta, s1, 1));
+  Op in;
+  in.kind = OP_NCHW_IN;
+  in.ext = 0;
+  in.out = n.new_tensor(Cin, H, W);
+  n.ops.push_back(in);
+  int ci = -1, gi = -1;
+  DDMI_TRY(n.make_conv("c.weight", "c.bias", &ci));
+  DDMI_TRY(n.make_gn("g.", &gi));
+  const int h = n.op_conv(in.out, ci, 1, 0, -1, emb ? 0 : -1);
+  const int o = n.op_gn(h, gi, silu, eps);
+  Op ex;
+  ex.kind = OP_EXPORT;
+  ex.in = o;
+  ex.ext = 1;
+  ex.out_nchw = 1;
+  n.ops.push_back(ex);
+  DDMI_TRY(n.plan());
+  void* ext[2] = {(void*)x, (void*)y};
+  for (int i = 0; i < iters; ++i) DDMI_TRY(n.run(B, ext, emb, Cout, 0));
+  if (fused_used) *fused_used = n.fgn_launches;
+  return n.async_status();
+}
+
+// the ResBlock's skip_connection on a channel-concatenated input (openaimodel.py:787, 272-275) through the network executor:
+// y = conv1x1([x1 | x2]) + bias, as ONE dual-source launch where the shape allows (*cat_used), else two accumulating launches
+int ddmi_op_conv1x1_cat(const float* x1, const float* x2, const float* w, const float* bias, float* y, int B, int C1, int C2, int H, int W,
+                        int Cout, int numerics, int* cat_used) {
+  DDMI_REQUIRE(x1 && x2 && w && bias && y && B > 0 && C1 > 0 && C2 > 0 && Cout > 0 && H > 0 && W > 0, "op_conv1x1_cat: bad arguments");
+  Net n;
+  bool x3 = false;
+  DDMI_TRY(numerics_to_dt(numerics, &n.dt, &x3));
+  n.x3 = x3;
+  n.max_batch = B;
+  const int64_t sw[2] = {Cout, C1 + C2}, s1[1] = {Cout};
+  DDMI_TRY(n.add_host("s.weight", w, sw, 2));
+  DDMI_TRY(n.add_host("s.bias", bias, s1, 1));
+  int t[2];
+  for (int i = 0; i < 2; ++i) {
+    Op in;
+    in.kind = OP_NCHW_IN;
+    in.ext = i;
+    in.out = t[i] = n.new_tensor(i ? C2 : C1, H, W);
+    n.ops.push_back(in);
+  }
+  int cfull = -1, sk = -1;
+  DDMI_TRY(n.make_conv("s.weight", "s.bias", &cfull));
+  const bool cat = n.cat_conv_ok(t[0], t[1], cfull);
+  if (cat) {
+    sk = n.op_conv_cat(t[0], t[1], cfull);
+  } else {   // the column blocks of the weight as two convolutions, the second accumulating (make_unet_resblock's split)
+    const HostTensor* wt = n.find("s.weight");
+    std::vector<float> wa((size_t)Cout * C1), wb((size_t)Cout * C2), bv(bias, bias + Cout);
+    for (int o = 0; o < Cout; ++o) {
+      std::copy(wt->data.begin() + (size_t)o * (C1 + C2), wt->data.begin() + (size_t)o * (C1 + C2) + C1, wa.begin() + (size_t)o * C1);
+      std::copy(wt->data.begin() + (size_t)o * (C1 + C2) + C1, wt->data.begin() + (size_t)(o + 1) * (C1 + C2), wb.begin() + (size_t)o * C2);
+    }
+    int ca = -1, cb = -1;
+    DDMI_TRY(n.make_conv_host(wa, Cout, C1, 1, &bv, &ca));
+    DDMI_TRY(n.make_conv_host(wb, Cout, C2, 1, nullptr, &cb));
+    sk = n.op_conv(t[0], ca, 1, 0, -1, -1);
+    sk = n.op_conv(t[1], cb, 1, 0, sk, -1);
+  }
+  if (cat_used) *cat_used = cat ? 1 : 0;
+  Op ex;
+  ex.kind = OP_EXPORT;
+  ex.in = sk;
+  ex.ext = 2;
+  ex.out_nchw = 1;
+  n.ops.push_back(ex);
+  DDMI_TRY(n.plan());
+  void* ext[3] = {(void*)x1, (void*)x2, (void*)y};
+  DDMI_TRY(n.run(B, ext, nullptr, 0, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
 }
 
 int ddmi_debug_attn_fused(int mode) {

@@ -63,6 +63,17 @@ struct ConvK {
   // bf16x3 numerics: the bf16 kernels finish in fp32 themselves - fp32 NHWC output and fp32 residual (general epilogue)
   float* y32;
   const float* res32;
+  // 1x1 convolution over the channel concatenation [x | xcat] read in place (persistent 1x1 kernel, CAT instantiation): x has C1
+  // channels per pixel, xcat Cin - C1; w is [Cout][Cin]
+  const void* xcat;
+  int C1;
+  // producer-side GroupNorm (halo kernel, FGN instantiation; see conv_epilogue_fgn): y = [SiLU](GroupNorm32(conv + bias + emb))
+  const float* gn_gamma;
+  const float* gn_beta;
+  float gn_eps;
+  int gn_silu, gn_cpg, gn_tps;              // channels per group, 256-row tiles per sample
+  float* gn_part;                           // [B * tps][32 groups] 16-byte granules {sum, sumsq, tag, tag}
+  unsigned* gn_sync;                        // [0] launch epoch (tag = epoch), [1] error flag (a poll timed out)
 };
 
 template <typename T> struct Tile;
@@ -332,6 +343,16 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)rp[i & 1][p][e];
       }
+#ifdef GN_ABL   // TIMING-ONLY build (tools/build_variant.sh ... -DGN_ABL): the VALU work of a producer-side GroupNorm + SiLU with made-up
+      // scale / shift on the convolutions that carry a time embedding (the out_layers producers); results are wrong on purpose
+      if ((a.dbg & 32) && a.emb) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float q = fmaf(v[e], cb[2 * p][e & 3], cb[2 * p + 1][e & 3]);
+          v[e] = q * __frcp_rn(1.0f + __expf(-q));
+        }
+      }
+#endif
       bf16x8 t;
 #pragma unroll
       for (int e = 0; e < 8; ++e) t[e] = (bf16_t)(v[e] * a.out_scale);
@@ -353,6 +374,15 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)ro[i & 1][e];
       }
+#ifdef GN_ABL
+      if ((a.dbg & 32) && a.emb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = fmaf(v[e], cb[FN - 1][e], cb[0][e]);
+          v[e] = q * __frcp_rn(1.0f + __expf(-q));
+        }
+      }
+#endif
       bf16x4 t;
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] = (bf16_t)(v[e] * a.out_scale);
@@ -413,6 +443,236 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
     }
   }
 }
+
+// =====================================================================================================
+// Producer-side GroupNorm (round 5): y = [SiLU](GroupNorm32(acc + bias + emb)) leaves the convolution's epilogue as bf16 - the raw
+// tensor is never stored, the gn_apply pass over it (a read + a write of the tensor at the HBM roof: 9.6 % of a UNet step in
+// round 4) and its launch are gone.  Serves the ResBlock's `out_layers` norm (openaimodel.py:207-215, 261-270: h = in_layers(x) +
+// emb_out; out_layers = GroupNorm32 -> SiLU -> conv): nothing but that norm reads h.
+//
+// A GroupNorm group = cpg consecutive channels x ALL pixels of a sample.  A 256 x BN tile holds BN / cpg whole groups of 256 pixels;
+// a sample is tps = H W / 256 tiles.  Per tile: per-channel (sum, sumsq) of the fp32 values (DPP row reduction over the 16 rows of a
+// fragment, as the chstat path) -> LDS -> per-group tile partials.  tps = 1 (16x16): done, no traffic at all.  tps > 1: the partial
+// goes out as ONE 16-byte granule {sum, sumsq, tag, tag} per (tile, group) through a write-through (`sc1`) store; every tile of the
+// sample polls the sample's tps x groups granules with `sc1` loads until their tag is this launch's epoch, and reduces them in
+// tile order (fp64; every tile computes the same mean / rstd bit for bit: deterministic).  No counter, no atomic, no fence: the
+// tag travels inside the granule's own 16 bytes (MI355X_MICROARCH.md, hand-offs: data-tagged granules, one `sc1` store each).  The
+// epoch is a device word that a one-thread kernel bumps before every such launch (hipGraph-replayable; a kernel argument would
+// be frozen into a captured graph).
+// Progress: the tiles that wait for each other are tps consecutive m-tiles of one n-tile.  Workgroups are dispatched in
+// blockIdx order (round-robin over the XCDs, in order inside each), conv_tile_of_block hands an XCD a contiguous range of tiles,
+// and tps * tiles_n <= 32 < the CUs of an XCD: whenever the oldest waiting tile's partners are not all resident, a CU is free
+// and the dispatcher brings the next one in.  HIP does not promise that order, so the poll is BOUNDED: on a timeout the workgroup
+// sets gn_sync[1] and finishes with what it has - the host checks the flag at its next synchronisation (Net::async_status) and
+// the caller falls back to the separate pass (DDMI_GN_FUSE=0).
+__device__ __forceinline__ void store_granule_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 load_granule_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int FM, int FN, int BN, int WM>
+__device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[FM][FN], unsigned char* lds, int m0, int n0, int wm,
+                                                  int wn, int lane, int tid, int hw) {
+  using T = bf16_t;
+  constexpr int TM = FM * 16, TN = FN * 16, NPAIR = FN / 2;
+  constexpr bool ODD = (FN & 1) != 0;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m_base = m0 + wm * TM, n_base = n0 + wn * TN;
+  // scratch in the halo buffers (nobody reads or fills them after the stage loop's last barrier)
+  float* const cs = reinterpret_cast<float*>(lds);     // [WM][BN][2]   per (wave row, channel): sum, sumsq over the wave's TM rows
+  float* const gp = cs + WM * BN * 2;                   // [16][32][2]   the sample's tile partials per group
+  float* const mr = gp + 16 * 32 * 2;                   // [32][2]       mean, rstd per group of this n-tile
+  float* const ss = mr + 64;                            // [BN][2]       scale, shift per channel
+  const int cpg = a.gn_cpg, tps = a.gn_tps, NG = BN / cpg;
+  const int b = m0 / hw, t_own = (m0 - b * hw) >> 8;    // sample, tile inside it (BM = 256)
+  const int n_pair = wn * TN + 8 * lg;                  // tile-local channel of pair p: + 32 p
+  const int n_odd = wn * TN + frag_chan<FN, true>(FN - 1, lg);
+
+  // ---- 1. v = acc + bias + emb (fp32, in place)
+  {
+    f32x4 cb[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) cb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        cb[2 * p] = *reinterpret_cast<const f32x4*>(a.bias + n0 + n_pair + 32 * p);
+        cb[2 * p + 1] = *reinterpret_cast<const f32x4*>(a.bias + n0 + n_pair + 32 * p + 4);
+      }
+      if constexpr (ODD) cb[FN - 1] = *reinterpret_cast<const f32x4*>(a.bias + n0 + n_odd);
+    }
+    if (a.emb) {
+      int be = b;
+      if (a.emb_mod) {
+        be -= be >= a.emb_mod ? a.emb_mod : 0;
+        be -= be >= a.emb_mod ? a.emb_mod : 0;
+      }
+      const float* pe = a.emb + (int64_t)be * a.emb_stride + n0;
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        cb[2 * p] += *reinterpret_cast<const f32x4*>(pe + n_pair + 32 * p);
+        cb[2 * p + 1] += *reinterpret_cast<const f32x4*>(pe + n_pair + 32 * p + 4);
+      }
+      if constexpr (ODD) cb[FN - 1] += *reinterpret_cast<const f32x4*>(pe + n_odd);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] += cb[j];
+  }
+  // ---- 2. per-channel sums over the wave's TM rows -> LDS
+  {
+    auto red16 = [](float v) {   // sum over the 16 lanes of a DPP row (= the 16 pixel rows of a fragment)
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+      return v;
+    };
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const float q = acc[i][j][e];
+          s1 += q;
+          s2 = fmaf(q, q, s2);
+        }
+        o[2 * e] = red16(s1);
+        o[2 * e + 1] = red16(s2);
+      }
+      if (lr == 0) {
+        float* d = cs + ((wm * BN) + wn * TN + frag_chan<FN, true>(j, lg)) * 2;
+        *reinterpret_cast<f32x4*>(d) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. tile partial per group; tps == 1: the statistics are complete
+  const unsigned tag = tps > 1 ? a.gn_sync[0] : 0u;
+  const double cnt = (double)hw * cpg;
+  if (tid < NG) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < WM; ++w)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+        s1 += cs[(w * BN + c) * 2];
+        s2 += cs[(w * BN + c) * 2 + 1];
+      }
+    if (tps == 1) {
+      const double m = (double)s1 / cnt;
+      double var = (double)s2 / cnt - m * m;
+      if (var < 0) var = 0;
+      mr[tid * 2] = (float)m;
+      mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+    } else {
+      const int gg = (n0 / BN) * NG + tid;   // group index in the sample
+      store_granule_sc1(a.gn_part + ((int64_t)(b * tps + t_own) * 32 + gg) * 4, f32x4{s1, s2, __uint_as_float(tag), __uint_as_float(tag)});
+    }
+  }
+  if (tps > 1) {
+    // ---- 4. the sample's tps x NG granules: one lane each, polled until they carry this launch's tag
+    const int idx = tid, want = tps * NG;
+    const int t = idx / NG, g = idx - t * NG;
+    const float* src = a.gn_part + ((int64_t)(b * tps + (idx < want ? t : 0)) * 32 + (n0 / BN) * NG + (idx < want ? g : 0)) * 4;
+    bool done = idx >= want;
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < (1 << 21); ++it) {
+      if (!done) {
+        v = load_granule_sc1(src);
+        done = __float_as_uint(v[2]) == tag && __float_as_uint(v[3]) == tag;
+      }
+      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!done) atomicOr(a.gn_sync + 1, 1u);   // a partner tile never arrived (dispatch order not as assumed): flagged, not hung
+    if (idx < want) {
+      gp[(t * 32 + g) * 2] = v[0];
+      gp[(t * 32 + g) * 2 + 1] = v[1];
+    }
+    __syncthreads();
+    if (tid < NG) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int tt = 0; tt < tps; ++tt) {   // tile order: every tile of the sample gets the same bits
+        s1 += (double)gp[(tt * 32 + tid) * 2];
+        s2 += (double)gp[(tt * 32 + tid) * 2 + 1];
+      }
+      const double m = s1 / cnt;
+      double var = s2 / cnt - m * m;
+      if (var < 0) var = 0;
+      mr[tid * 2] = (float)m;
+      mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+    }
+  }
+  __syncthreads();
+  // ---- 5. per-channel scale / shift of this n-tile
+  if (tid < BN) {
+    const int g = tid / cpg;
+    const float sc = mr[g * 2 + 1] * a.gn_gamma[n0 + tid];
+    ss[tid * 2] = sc;
+    ss[tid * 2 + 1] = a.gn_beta[n0 + tid] - mr[g * 2] * sc;
+  }
+  __syncthreads();
+  // ---- 6. normalise, SiLU, round once, store
+  T* __restrict__ yg = (T*)a.y;
+  const bool silu = a.gn_silu != 0;
+  auto act = [&](float x, float sc, float sh) {
+    float q = fmaf(x, sc, sh);
+    if (silu) q = q * __frcp_rn(1.0f + __expf(-q));
+    return q;
+  };
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) {
+    float sc[8], sh[8];
+    {
+      const f32x4* q = reinterpret_cast<const f32x4*>(ss + (n_pair + 32 * p) * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 w = q[u];
+        sc[2 * u] = w[0]; sh[2 * u] = w[1]; sc[2 * u + 1] = w[2]; sh[2 * u + 1] = w[3];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m_base + i * 16 + lr;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16_t)act(acc[i][2 * p][e], sc[e], sh[e]);
+        o[4 + e] = (bf16_t)act(acc[i][2 * p + 1][e], sc[4 + e], sh[4 + e]);
+      }
+      if (m < a.M) *reinterpret_cast<bf16x8*>(yg + (int64_t)m * a.Cout + n0 + n_pair + 32 * p) = o;
+    }
+  }
+  if constexpr (ODD) {
+    float sc[4], sh[4];
+    {
+      const f32x4* q = reinterpret_cast<const f32x4*>(ss + n_odd * 2);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 w = q[u];
+        sc[2 * u] = w[0]; sh[2 * u] = w[1]; sc[2 * u + 1] = w[2]; sh[2 * u + 1] = w[3];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m_base + i * 16 + lr;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)act(acc[i][FN - 1][e], sc[e], sh[e]);
+      if (m < a.M) *reinterpret_cast<bf16x4*>(yg + (int64_t)m * a.Cout + n0 + n_odd) = o;
+    }
+  }
+}
+// one thread: the launch epoch the granules of the next FGN convolution are tagged with
+__global__ void conv_fgn_epoch_kernel(unsigned* sync) { sync[0] += 1u; }
 
 template <typename T, int FM, int FN, bool PAIRED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
@@ -945,8 +1205,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_pipe_kernel(ConvK a) {
 // weights (L2): behind barrier g go B(g + 2) and then A(g + 3), and the wait before barrier g + 1 is `vmcnt(A_PER)`: everything but
 // the four youngest instructions, i.e. A(g + 3) stays in flight across the barrier (every wave issues exactly A_PER activation
 // pieces per stage, so the immediate is wave-independent whatever its share of the weight rows).
-template <int BN, int WM, int WN, bool STATS, int NA>
+// CAT instantiation (round 5): the A operand is the channel concatenation [x | xcat] of two NHWC tensors read in place - the ResBlock's
+// skip_connection on th.cat([h, hs.pop()], 1) (openaimodel.py:787, 272-275) in ONE launch.  It ran as two accumulating 1x1 launches
+// (conv(x1, W[:, :C1]) then conv(x2, W[:, C1:]) + the first result as residual): the intermediate was written and read back - a third
+// of the traffic of a pair that is HBM-bound at 64x64.  Here the 64-channel K blocks of x are followed by those of xcat (a ragged last
+// block of x is zero-filled like any channel tail; its weight columns stop at C1), the per-block source is wave-uniform scalar state.
+template <int BN, int WM, int WN, bool STATS, int NA, bool CAT = false>
 __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
+  static_assert(!(CAT && STATS), "the dual-source 1x1 convolution delivers no channel statistics");
   using T = bf16_t;
   constexpr int BM = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -961,7 +1227,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int K = a.Cin, NS = (K + 63) >> 6;
+  const int K = a.Cin;
+  const int NS1 = CAT ? (a.C1 + 63) >> 6 : 0;                          // 64-channel blocks of the first source
+  const int NS = CAT ? NS1 + ((K - a.C1 + 63) >> 6) : (K + 63) >> 6;
   for (int i = tid; i < a.Cout; i += NW * 64) bias_lds[i] = a.bias ? a.bias[i] : 0.f;   // visible after the first barrier below
   const int tiles_n = a.tiles_n, tiles_m = (a.M + BM - 1) / BM, T_all = tiles_m * tiles_n;
   // Tile order.  Workgroups are dealt to the 8 XCDs round-robin (w % 8); XCD x owns the contiguous eighth [r0, r1) of the tile list
@@ -1000,6 +1268,22 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
     const int m0 = tm * BM;
     // the activation descriptor is rebased at the tile's first row (tensors may exceed 2 GiB); rows past M fall outside its
     // extent and read as zeros
+    if constexpr (CAT) {   // block lka of [x | xcat]: source, its row pitch and the block inside it are scalars
+      const bool second = lka >= NS1;
+      const int Cs = second ? K - a.C1 : a.C1, kb = second ? lka - NS1 : lka;
+      const T* src = (const T*)(second ? a.xcat : a.x) + (int64_t)m0 * Cs;
+      const uint64_t rem = (uint64_t)(a.M - m0) * Cs * SZ;
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)rem, 0x00020000);
+      const int cok = kb * 64 + coff < Cs;
+      const int lane_off = (row0 * Cs + coff) * SZ + kb * 128;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const unsigned voff = cok ? (unsigned)(lane_off + i * (8 * NW) * Cs * SZ) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * A_BYTES + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+      }
+      if (++lka == NS) { lka = 0; lta += Sx; }
+      return;
+    }
     const uint64_t rem = (uint64_t)(a.M - m0) * K * SZ;
     auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.x + (int64_t)m0 * K), 0, rem > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)rem,
                                                     0x00020000);
@@ -1016,8 +1300,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
     int tm, tn;
     tile_mn(ltb, &tm, &tn);
     const int n0 = tn * BN;
-    const int cok = lkb * 64 + coff < K;
-    const int kbyte = lkb * 128;
+    int cok = lkb * 64 + coff < K;
+    int kbyte = lkb * 128;
+    if constexpr (CAT) {   // weight columns of the block: [0, C1) for x, [C1, K) for xcat; a ragged last block of x stops at C1
+      const bool second = lkb >= NS1;
+      const int kb = second ? lkb - NS1 : lkb;
+      cok = kb * 64 + coff < (second ? K - a.C1 : a.C1);
+      kbyte = ((second ? a.C1 : 0) + kb * 64) * SZ;
+    }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int g = i * NW + wave;
@@ -1068,7 +1358,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
   int ct = t0, ckb = 0, sa = 0, sb = 0;   // compute cursor; LDS slots of the current stage
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
-    const bool c1 = ckb * 64 + 32 < K;
+    const bool c1 = CAT ? (ckb >= NS1 ? (ckb - NS1) * 64 + 32 < K - a.C1 : ckb * 64 + 32 < a.C1) : ckb * 64 + 32 < K;
     read_frags(sa, sb, 1, xb, wb);
     mma(xa, wa);
     // A(g + 2) - issued behind the previous barrier as the youngest A_PER instructions - may stay in flight (NA = 3)
@@ -1119,11 +1409,20 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
 #define HALO_MAX_ROWS 400  // 6 x 66 = 396 rows at W = 64, rounded up to whole 8-row DMA groups (the tail lanes write zeros)
 // KT = 2 instantiation: the parity form of upsample + 3x3 (four 2x2 convolutions on the source grid, blockIdx.y = parity):
 // a (TR+1) x (W+1) halo whose border side depends on the parity, four taps per channel block, the up4 scatter in the epilogue.
-template <int BN, int WM, int WN, bool SKIP, int KT = 3>
+// HALF instantiation (round 5): Cin = 64 k + 32 (the AFHQ UNet's 224 and 672) left the last 64-channel block half empty - nine
+// stages that paid their barrier, their weight-stage DMA issue and their fragment reads for half the MFMAs (12.5 % of the stages of a
+// 224-channel convolution).  Here the ragged block runs TWO TAPS per stage: chunk 0 = its 32 channels at tap 2j, chunk 1 = the same
+// 32 channels at tap 2j + 1 - the weight stage holds [tap 2j | tap 2j + 1] halves (a per-lane column offset on the DMA source), the A
+// fragments of chunk 1 come from the SAME halo chunk at the next tap's shift.  Five stages instead of nine, every MFMA useful but
+// the last stage's second half; the products and their accumulation order are unchanged, so results are bit-identical.  A separate
+// instantiation: the plain one keeps its registers and schedule.
+template <int BN, int WM, int WN, bool SKIP, int KT = 3, bool HALF = false, bool FGN = false>
 __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
+  static_assert(!FGN || (!SKIP && KT == 3), "halo kernel: the GroupNorm epilogue exists for plain 3x3 convolutions");
   using T = bf16_t;
   constexpr int BM = 256, NW = WM * WN, TAPS = KT * KT;
   static_assert(KT == 3 || (KT == 2 && !SKIP), "halo kernel: 3x3, or the 2x2 parity convolutions of an upsample");
+  static_assert(!HALF || (!SKIP && KT == 3), "halo kernel: the two-taps-per-stage tail exists for plain 3x3 convolutions");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   static_assert(TM % 16 == 0 && TN % 16 == 0 && (TN / 2) % 8 == 0 && NW % 2 == 0, "bad tile");
   constexpr int GB = BN / 8, B_PER = (GB + NW - 1) / NW;
@@ -1182,7 +1481,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       nsk = NCB2 + ((skip_arg(int(0), offsetof(ConvK, C3)) + 63) >> 6);
     }
   }
-  const int nblk = nmain + nsk, nstage = nmain * TAPS + nsk;
+  // HALF (launched without split-K only): the ragged block is the LAST block and runs in a loop of its own behind the stage loop,
+  // HT = (TAPS + 1) / 2 two-tap stages (the first version decided "half or not" inside the ONE stage loop: 5-9 % slower on every shape -
+  // the loop's scalar state spilled); the stage loop only knows that its last two refills fetch that block's first two stages
+  constexpr int HT = (TAPS + 1) / 2;
+  const int nblk = nmain + nsk, nstage = HALF ? (nmain - 1) * TAPS : nmain * TAPS + nsk;
   // block -> (64-channel block inside its source, the source's channel count); scalar
   auto blk_cbl = [&](int blk) {
     if (!SKIP || blk < nmain) return cb_begin + blk;
@@ -1260,6 +1563,24 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
     }
   };
 
+  // HALF: a two-tap weight stage of the ragged (last) block: [tap | tap + 1] halves of its <= 32 channels - lanes of the logical
+  // slots 4..7 read the next tap's columns (a per-lane column offset on the DMA source; everything else as load_b_stage)
+  auto load_b_half = [&](int tap, int bbuf) {
+    const int c0 = (NCB - 1) * 64, sel = coff >> 5;
+    const int cvalid = (c0 + (coff & 31) < a.Cin) & (tap + sel < TAPS);
+    const int col = (tap * a.Cin + c0 + sel * (a.Cin - 32)) * SZ;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int g = i * NW + wave;
+      if (g < GB) {
+        const int brow = lds_row_chan<TN>(b_row0 + i * 8 * NW);
+        int ok = cvalid & (b_row0 + i * 8 * NW < BN) & (n0 + brow < a.Cout);
+        unsigned voff = ok ? (unsigned)(b_base0 + brow * Ktot * SZ + col) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(BB + bbuf * B_BYTES + g * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
   const int lr = lane & 15, lg = lane >> 4;
   // A fragments: tile-local pixel m = wm*TM + 16 i + lr -> halo row of tap (0,0); 16 consecutive pixels share a row
   // fragment i sits 16 i pixels further: + 16 i halo rows and + 2 per image row crossed (scalar, W >= 16)
@@ -1274,14 +1595,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   // `shift` = kh*(W+2) + kw moves every A fragment to the tap's halo row; it stays a loop-carried scalar so the
   // per-fragment swizzle (5 VALU) is recomputed per stage instead of being hoisted into ~70 loop-invariant VGPRs
   // `plain` (a skip block's tile): row = tile-local pixel wm*TM + 16 i + lr, no border; lr is recovered from woff0 (no new register)
-  auto read_frags = [&](int hbuf, int bbuf, int shift, bool plain, int c, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
+  // c: 32-channel chunk of the weight stage; ca: chunk of the halo rows (= c but in the two-tap stages of HALF, which read chunk 0 twice)
+  auto read_frags = [&](int hbuf, int bbuf, int shift, bool plain, int c, int ca, bf16x8(&xf)[FM], bf16x8(&wf)[FN]) {
     const unsigned char* ph = HB + hbuf * H_BYTES;
     const int vb = (SKIP && plain) ? wm * TM - wn * TN + (woff0 >> 7) : hr00 + shift;
     const int rj = (SKIP && plain) ? 0 : KT - 1;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       int hr = vb + i * 16 + ((i * 16) / W) * rj;
-      xf[i] = *reinterpret_cast<const bf16x8*>(ph + ((hr * ROWB + ((lg ^ ((hr >> 1) & 7)) << 4)) ^ (c << 6)));
+      xf[i] = *reinterpret_cast<const bf16x8*>(ph + ((hr * ROWB + ((lg ^ ((hr >> 1) & 7)) << 4)) ^ (ca << 6)));
     }
     const unsigned char* pw = BB + bbuf * B_BYTES + (woff0 ^ (c << 6));
 #pragma unroll
@@ -1304,24 +1626,29 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   bf16x8 xa[FM], wa[FN], xb[FM], wb[FN];
 
   if (ts) ts[1] = wall_clock64();
-  if (nstage > 0) {   // (split 0 always has blocks of x, so stages 0 and 1 are taps 0 and 1 of block 0)
+  if (nstage > 0 || HALF) {   // (split 0 always has blocks of x, so stages 0 and 1 are taps 0 and 1 of block 0)
     for (int g = wave; g < GH; g += NW) load_halo_group(g, 0, 0);
-    load_b_stage(0, 0, 0, true);
-    load_b_stage(0, 1, 1, true);
+    if (HALF && nmain == 1) {   // the ragged block is the only one: its stages 0 and 1 are taps (0, 1) and (2, 3)
+      load_b_half(0, 0);
+      load_b_half(2, 1);
+    } else {
+      load_b_stage(0, 0, 0, true);
+      load_b_stage(0, 1, 1, true);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ts) ts[2] = wall_clock64();
-    read_frags(0, 0, 0, false, 0, xa, wa);
+    read_frags(0, 0, 0, false, 0, 0, xa, wa);
   }
   // one flat stage loop; (blk, tap, kw, shift, hbuf) are scalar state so nothing per-tap gets unrolled or hoisted
   int blk = 0, tap = 0, kw = 0, shift = 0, hbuf = 0;
 #pragma unroll 1
   for (int st = 0; st < nstage; ++st) {
     const int bbuf = st & 1;
-    const bool c1 = blk_cbl(blk) * 64 + 32 < blk_C(blk);
+    const bool c1 = HALF || blk_cbl(blk) * 64 + 32 < blk_C(blk);   // (HALF: every block of this loop is whole)
     const bool one_stage = SKIP && blk >= nmain;   // a skip block: centre tap only
     // [A] chunk 0 of this stage on set a, prefetch chunk 1 into set b
-    read_frags(hbuf, bbuf, shift, one_stage, 1, xb, wb);
+    read_frags(hbuf, bbuf, shift, one_stage, 1, 1, xb, wb);
     mma(xa, wa);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // next weight stage + halo pieces issued a stage ago have landed; BB[bbuf] is free
@@ -1334,7 +1661,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
         t2 -= TAPS; ++b2;
         if (SKIP && b2 >= nmain) { b2 += t2; t2 = 0; }
       }
-      load_b_stage(b2, t2, bbuf, b2 < nblk);
+      if (HALF && b2 + 1 == nblk) load_b_half(2 * t2, bbuf);   // entering the ragged block: its stage t2 = taps 2 t2, 2 t2 + 1
+      else load_b_stage(b2, t2, bbuf, b2 < nblk);
       // halo prefetch.  A nine-stage block fetches its successor's halo in eight pieces behind taps 0..7.  A one-stage block has
       // no such lead for ITS successor (the stage after the barrier already reads it), so one-stage blocks are fetched TWO blocks
       // ahead: whole, into the halo buffer this barrier has just released (the current block's chunk-1 reads are retired) - behind
@@ -1360,11 +1688,33 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       ++blk; hbuf ^= 1;
     }
     // [B] chunk 1 on set b, prefetch chunk 0 of the next stage into set a
-    if (st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, SKIP && blk >= nmain, 0, xa, wa);
+    if (HALF || st + 1 < nstage) read_frags(hbuf, bbuf ^ 1, shift, SKIP && blk >= nmain, 0, 0, xa, wa);   // (HALF: the tail's first chunk)
     if (c1) mma(xb, wb);
   }
+  if constexpr (HALF) {
+    // ---- the ragged block, two taps per stage (unrolled: taps, shifts and buffer parities are constants) --------------------------
+    // chunk 0 = its channels at tap 2 j (halo chunk 0, weight half 0), chunk 1 = the SAME halo chunk at tap 2 j + 1 (weight half 1)
+    const int par = nstage & 1;   // LDS weight buffer of its first stage
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+      const int t0 = 2 * j, t1 = 2 * j + 1;
+      const int bbuf = par ^ (j & 1);
+      const int sh1 = (t1 / KT) * HWd + (t1 % KT);
+      if (t1 < TAPS) read_frags(hbuf, bbuf, sh1, false, 1, 0, xb, wb);
+      mma(xa, wa);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t0 + 4 < TAPS) load_b_half(t0 + 4, bbuf);   // stage j + 2
+      if (j + 1 < HT) {
+        const int sh0 = ((t0 + 2) / KT) * HWd + ((t0 + 2) % KT);
+        read_frags(hbuf, bbuf ^ 1, sh0, false, 0, 0, xa, wa);
+      }
+      if (t1 < TAPS) mma(xb, wb);
+    }
+  }
   if (ts) ts[3] = wall_clock64();
-  conv_epilogue<T, FM, FN, true>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
+  if constexpr (FGN) conv_epilogue_fgn<FM, FN, BN, WM>(a, acc, HB, m0, n0, wm, wn, lane, tid, hw);
+  else conv_epilogue<T, FM, FN, true>(a, acc, m0 + wm * TM, n0 + wn * TN, lr, lg, hw);
   if (ts) {
     ts[4] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1691,6 +2041,8 @@ static const int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 struct TileCfg { int bm, bn, kps, id; };  // id < 0: fp32 kernel tile
 static int g_force_bm = 0, g_force_bn = 0;  // diagnostics (ddmi_bench_conv): bn == -1 -> bm is a ring config id
 void conv_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+static int g_halo_half = -1;   // ddmi_debug_halo_half: -1 = the DDMI_HALO_HALF environment decides (default on)
+void conv_halo_half_override(int mode) { g_halo_half = mode; }
 
 static TileCfg pick_tile(int M, int Cout, int dt, int cfg = 0) {
   if (dt == DT_BF16) {
@@ -1751,6 +2103,12 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   k.x2 = a.x2; k.x3 = a.C3 > 0 ? a.x3 : nullptr; k.w2 = a.w2; k.C2 = a.x2 ? a.C2 : 0; k.C3 = a.x2 && a.x3 ? a.C3 : 0;
   k.w2_bytes = (unsigned)((uint64_t)a.Cout * (k.C2 + k.C3) * dt_size(dt));
   k.y32 = a.y32; k.res32 = a.res32;
+  if (a.xcat) { k.xcat = a.xcat; k.C1 = a.Cin - a.Ccat; }
+  if (a.gn_gamma) {
+    k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta; k.gn_eps = a.gn_eps; k.gn_silu = a.gn_silu;
+    k.gn_cpg = a.Cout / 32; k.gn_tps = (a.Hout * a.Wout) / 256;
+    k.gn_part = a.gn_part; k.gn_sync = a.gn_sync;
+  }
   *out = k;
   return DDMI_OK;
 }
@@ -1908,6 +2266,7 @@ static int launch_pipe(ConvK k, int splitk, int batch, hipStream_t s) {
   return DDMI_OK;
 }
 
+bool conv_cat_ok(const ConvArgs& a, int dt);
 // shapes the persistent 1x1 kernel (configuration 24) serves; anything else asked of it runs on the pipe kernel (13)
 static bool gemm1x1_ok(const ConvArgs& a, int bn = 224) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.ups && a.splitk <= 1 && !a.force_ws && a.Cout % bn == 0 && a.y_nchw == nullptr &&
@@ -1915,6 +2274,12 @@ static bool gemm1x1_ok(const ConvArgs& a, int bn = 224) {
          (a.emb == nullptr || (a.Hout * a.Wout) % 64 == 0);   // (the fast epilogue's conditions; at least three stages per tile)
 }
 static const int kGemmFallback = 13;
+// a 1x1 convolution over [x | xcat]: bf16, no split-K, plain NHWC output, whole 224- or 128-wide channel tiles, 16-byte channel vectors
+bool conv_cat_ok(const ConvArgs& a, int dt) {
+  if (dt != DT_BF16 || !a.xcat || a.Ccat <= 0 || a.Ccat >= a.Cin || a.Ccat % 8 || (a.Cin - a.Ccat) % 8) return false;
+  if (a.splitk > 1 || a.chstat || a.x2 || a.emb || a.Cout > 2016 * 4) return false;
+  return gemm1x1_ok(a, 224) || gemm1x1_ok(a, 128);
+}
 template <int BN, int WM, int WN>
 static int launch_gemm1x1(ConvK k, hipStream_t s) {
   // three activation slots where the bias vector leaves room for them (Cout <= 2016), else two
@@ -1941,11 +2306,22 @@ static int launch_gemm1x1(ConvK k, hipStream_t s) {
     attr_set = true;
   }
   auto kern = kerns[(na3 ? 2 : 0) + (k.chstat ? 1 : 0)];
+  if (k.xcat) {   // [x | xcat] read in place
+    void (*kcat[2])(ConvK) = {conv_gemm1x1_kernel<BN, WM, WN, false, 2, true>, conv_gemm1x1_kernel<BN, WM, WN, false, 3, true>};
+    static bool cat_attr_set = false;
+    if (!cat_attr_set) {
+      for (auto kp : kcat) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      cat_attr_set = true;
+    }
+    DDMI_REQUIRE(!k.chstat, "gemm1x1: the dual-source form delivers no channel statistics");
+    kern = kcat[na3 ? 1 : 0];
+  }
   {
     double flops, bytes;
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_gemm1x1<bf16,256x" + std::to_string(BN) + ",persistent>";
-    PROF_SCOPE(conv_prof_name(name, k).c_str(), flops, bytes, s);
+    static const std::string name_cat = "conv_gemm1x1_cat<bf16,256x" + std::to_string(BN) + ",persistent>";
+    PROF_SCOPE(conv_prof_name(k.xcat ? name_cat : name, k).c_str(), flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
@@ -1977,20 +2353,36 @@ static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
   }
   auto kern = conv_halo_kernel<BN, WM, WN, false>;
   auto kern_skip = conv_halo_kernel<BN, WM, WN, true>;   // + the folded 1x1 skip connection
+  auto kern_half = conv_halo_kernel<BN, WM, WN, false, 3, true>;   // Cin = 64 k + (1..32): two taps per stage in the ragged block
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_skip), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_half), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  auto kern_fgn = conv_halo_kernel<BN, WM, WN, false, 3, false, true>;        // + the producer-side GroupNorm epilogue
+  auto kern_half_fgn = conv_halo_kernel<BN, WM, WN, false, 3, true, true>;
+  static bool attr_fgn_set = false;
+  if (!attr_fgn_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_fgn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_half_fgn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_fgn_set = true;
+  }
+  static const bool half_off = getenv("DDMI_HALO_HALF") && atoi(getenv("DDMI_HALO_HALF")) == 0;   // diagnostics: nine half-empty stages
+  const bool half = (g_halo_half < 0 ? !half_off : g_halo_half != 0) && !k.x2 && splitk == 1 && (k.Cin & 63) != 0 && (k.Cin & 63) <= 32;
   {
     double flops, bytes;
     conv_work(k, 1, 2, &flops, &bytes);
     static const std::string name = "conv_halo<bf16,256x" + std::to_string(BN) + ">";
     static const std::string name_skip = "conv_halo+skip<bf16,256x" + std::to_string(BN) + ">";
-    PROF_SCOPE(conv_prof_name(k.x2 ? name_skip : name, k).c_str(), flops, bytes, s);
-    k.ts = conv_ts_buffer((int)grid.x);
+    static const std::string name_fgn = "conv_halo+gn<bf16,256x" + std::to_string(BN) + ">";
+    if (k.gn_gamma && k.gn_tps > 1) hipLaunchKernelGGL(conv_fgn_epoch_kernel, dim3(1), dim3(1), 0, s, k.gn_sync);   // this launch's granule tag
+    PROF_SCOPE(conv_prof_name(k.x2 ? name_skip : k.gn_gamma ? name_fgn : name, k).c_str(), flops, bytes, s);
+    k.ts = k.gn_gamma ? nullptr : conv_ts_buffer((int)grid.x);
     if (k.x2) hipLaunchKernelGGL(kern_skip, grid, dim3(WM * WN * 64), lds, s, k);
+    else if (k.gn_gamma) hipLaunchKernelGGL(half ? kern_half_fgn : kern_fgn, grid, dim3(WM * WN * 64), lds, s, k);
+    else if (half) hipLaunchKernelGGL(kern_half, grid, dim3(WM * WN * 64), lds, s, k);
     else hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, k);
   }
   HIP_TRY(hipGetLastError());
@@ -2077,7 +2469,7 @@ static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave ti
 int conv_chstat_rows(const ConvArgs& a, int dt) {
   static const bool off = getenv("DDMI_GN_CHSTAT") && atoi(getenv("DDMI_GN_CHSTAT")) == 0;
   static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
-  if (off || dbg || dt != DT_BF16 || a.splitk > 1 || a.y_nchw || !a.y) return 0;
+  if (off || dbg || dt != DT_BF16 || a.splitk > 1 || a.y_nchw || !a.y || a.xcat) return 0;
   const int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
@@ -2091,8 +2483,33 @@ int conv_chstat_rows(const ConvArgs& a, int dt) {
   return TM;
 }
 
+// Producer-side GroupNorm: the launch must be a plain bf16 3x3 / stride 1 convolution on the halo kernel with no split-K, whole
+// BN-wide channel tiles that hold whole groups (BN % (Cout / 32) == 0), 256-row tiles inside one sample (H W % 256 == 0), at most
+// 16 tiles per sample and one polling lane per (tile, group) granule, granule runs that fill whole 128-byte lines.
+bool conv_fgn_ok(const ConvArgs& a, int dt) {
+  static const bool off = getenv("DDMI_GN_FUSE") && atoi(getenv("DDMI_GN_FUSE")) == 0;
+  static const int dbg = getenv("DDMI_CONV_DBG") ? atoi(getenv("DDMI_CONV_DBG")) : 0;
+  if (off || dbg || dt != DT_BF16 || !a.gn_gamma || !a.gn_beta || !a.gn_part || !a.gn_sync) return false;
+  if (a.splitk > 1 || a.force_ws || a.res || a.res32 || a.y32 || a.y_nchw || !a.y || a.x2 || a.ups || a.out_scale != 1.f) return false;
+  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1) || !halo_ok(a)) return false;
+  const int M = conv_rows(a), hw = a.Hout * a.Wout;
+  TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
+  if (t.kps != -2) return false;
+  const int BN = t.bn, cpg = a.Cout / 32, tps = hw / 256;
+  if (a.Cout % 32 || a.Cout % BN || BN % cpg || hw % 256 || tps > 16) return false;
+  const int NG = BN / cpg, tiles_n = a.Cout / BN;
+  if (tps > 1 && (tps * NG > 512 || NG % 8 != 0)) return false;
+  // progress (conv_epilogue_fgn): the tiles that wait for each other - tps m-tiles of one n-tile, tps * tiles_n consecutive ids in the
+  // m-major order the launch is pinned to - must all fit the 32 CUs of an XCD with room to spare.  (The D2C-VAE decoder's 512-channel
+  // convolutions at 64x64 - 16 x 4 = 64 - do not: every launch sat in its bounded poll until the timeout; found on the first bench run.)
+  if (tps > 1 && tps * tiles_n > 16) return false;
+  if (a.emb && a.emb_stride % 4) return false;
+  return true;
+}
+
 int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   DDMI_TRY(check_conv(a, dt));
+  DDMI_REQUIRE(!a.gn_gamma || conv_fgn_ok(a, dt), "conv: a fused GroupNorm asked of a launch that cannot provide it");
   int splitk = std::max(1, a.splitk);
   DDMI_REQUIRE((splitk == 1 && !a.force_ws) || a.splitk_ws, "conv: split-K needs a workspace");
   int M = conv_rows(a);
@@ -2100,6 +2517,10 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   if (t.kps == -3 && !gemm1x1_ok(a, t.bn)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
+  if (a.xcat) {   // the dual-source form exists on the persistent 1x1 kernel only
+    DDMI_REQUIRE(conv_cat_ok(a, dt), "conv: a channel-concatenated input needs a bf16 1x1 shape of the persistent kernel");
+    if (t.kps != -3 || a.Cout % t.bn) t = pick_tile(M, a.Cout, dt, (a.Cout % 224 == 0 ? 24 : 25) + 1);
+  }
   ConvK k;
   DDMI_TRY(make_k(a, dt, t.kps, splitk, &k));
   // order: 1 tap-major, 2 channel-major, +2 = paired-fragment instantiation of the pipe kernel; 0 = heuristic
@@ -2114,6 +2535,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
       tm = wgt > act ? 2 : 1;
     }
     k.tile_map = tm < 0 ? 0 : tm;
+    if (a.gn_gamma) k.tile_map = 1;   // producer-side GroupNorm: the tiles of a sample on consecutive ids of one XCD (conv_fgn_ok)
   }
   if (a.chstat) {
     DDMI_REQUIRE(conv_chstat_rows(a, dt) > 0, "conv: channel statistics asked of a launch that cannot provide them");
@@ -2171,6 +2593,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
     const RingCfg& rc = kRing[id];
     if (rc.kps == -2 && !halo_ok(a0)) continue;
     if (a0.x2 && rc.kps != -2) continue;   // a folded skip connection runs on the halo kernel only
+    if (a0.xcat && rc.kps != -3) continue;  // a channel-concatenated input on the persistent 1x1 kernel only
     if (rc.kps == -3) {
       static const bool no_gemm = getenv("DDMI_NO_GEMM1X1") != nullptr;   // diagnostics: A/B against the pipe / ring kernels
       if (no_gemm) continue;

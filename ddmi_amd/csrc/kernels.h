@@ -106,7 +106,26 @@ struct ConvArgs {
   const float* res32; // fp32 residual for y32 / y_nchw outputs
   int force_ws;       // write the raw fp32 accumulators to splitk_ws even when splitk == 1 (bias / emb / res / y untouched): the
                       // bf16x3 mode finishes them in fp32 with launch_splitk_finish(..., DT_F32)
+  // 1x1 convolution over the channel concatenation [x (Cin - Ccat channels) | xcat (Ccat channels)] of two NHWC tensors read in place
+  // (the ResBlock's skip_connection on th.cat([h, hs.pop()], 1)); w [Cout][Cin]; persistent 1x1 kernel only (conv_cat_ok)
+  const void* xcat;
+  int Ccat;
+  // producer-side GroupNorm (k_conv.hip conv_epilogue_fgn): when gn_gamma is set, y receives [SiLU](GroupNorm32(conv + bias + emb))
+  // instead of the raw result.  Only launches conv_fgn_ok() accepts; gn_part / gn_sync from ConvFgnScratch (one per network).
+  const float* gn_gamma;
+  const float* gn_beta;
+  float gn_eps;
+  int gn_silu;
+  float* gn_part;
+  unsigned* gn_sync;
 };
+// scratch of the producer-side GroupNorm: granules [max samples][16 tiles][32 groups][4 floats] + sync words {epoch, error flag}
+#define CONV_FGN_PART_FLOATS(samples) ((size_t)(samples) * 16 * 32 * 4)
+#define CONV_FGN_SYNC_WORDS 4
+// whether launch_conv(a) with a.gn_gamma set can run the fused epilogue (bf16 halo-kernel launch without split-K, whole channel tiles
+// holding whole groups, 256-row tiles inside one sample ...); the caller runs conv + gn_apply otherwise
+bool conv_fgn_ok(const ConvArgs& a, int dt);
+bool conv_cat_ok(const ConvArgs& a, int dt);
 // the 3x3 / stride 1 shapes the halo kernel (and with it the folded skip connection) serves
 bool conv_halo_shape_ok(int H, int W);
 // whether a bf16 network may fold the softmax scale into its qkv projection for head dim d (every bf16 attention kernel then takes the
@@ -126,6 +145,7 @@ int conv_chstat_rows(const ConvArgs& a, int dt);
 int launch_splitk_finish(const ConvArgs& a, int dt, hipStream_t s);
 int conv_pick_splitk(const ConvArgs& a, int dt);
 void conv_force_tile(int bm, int bn);  // diagnostics: 0,0 = automatic
+void conv_halo_half_override(int mode);  // diagnostics: halo kernel's two-taps-per-stage tail for Cin = 64 k + 32: 0 off, 1 on, -1 environment
 
 // batched plain GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * Bm[b][n][k]  (both K-contiguous), dtype dt in/out
 int launch_gemm_nt(const void* A, const void* Bm, void* C, int dt, int batch, int M, int N, int K, int64_t strideA,

@@ -73,8 +73,12 @@ int emit_resblock_cat(Net& n, const ResW& w, int x1, int x2, int* out) {
   const bool fold = w.cs_full >= 0 && n.can_fold_skip(x1, w.c2);   // skip_connection as extra K columns of conv2 (k_conv.hip)
   int sk = -1;
   if (!fold) {
-    sk = n.op_conv(x1, w.cs, 1, 0, -1, -1);
-    sk = n.op_conv(x2, w.cs2, 1, 0, sk, -1);
+    if (w.cs_full >= 0 && n.cat_conv_ok(x1, x2, w.cs_full)) {   // ONE launch over [x1 | x2] read in place (k_conv.hip, CAT)
+      sk = n.op_conv_cat(x1, x2, w.cs_full);
+    } else {
+      sk = n.op_conv(x1, w.cs, 1, 0, -1, -1);
+      sk = n.op_conv(x2, w.cs2, 1, 0, sk, -1);
+    }
   }
   int a = n.op_gn(x1, w.gn1, 1, w.eps, x2);
   int h = n.op_conv(a, w.c1, 1, 0, -1, w.emb_off, 1.f, w.emb_rep == 4);

@@ -10,6 +10,9 @@
 #include <vector>
 #include "kernels.h"
 
+// diagnostics: producer-side GroupNorm for networks planned and run afterwards: 0 off, 1 on, -1 = the DDMI_GN_FUSE environment (net.hip)
+void net_gn_fuse_override(int mode);
+
 struct HostTensor {
   std::vector<float> data;
   std::vector<int64_t> shape;
@@ -83,6 +86,10 @@ struct Op {
   // GroupNorm statistics out of the producer's epilogue (plan()): OP_CONV writes per-channel sums of its output into tensor
   // `stat_out`; OP_GN reads the ones of its input(s) instead of running the statistics pass when every producer delivered
   int stat_out = -1, stat_in = -1, stat_in2 = -1;
+  // producer-side GroupNorm (k_conv.hip conv_epilogue_fgn; plan(): attach_fused_groupnorm): OP_CONV whose output feeds ONE single-source
+  // OP_GN and nothing else carries that op's index in `fgn_gn`; when the launch qualifies (conv_fgn_ok, decided per run) it writes the
+  // normalised tensor - the GN op's `out` - itself and the GN op (`fgn_conv` = the producer's index) is skipped
+  int fgn_gn = -1, fgn_conv = -1;
   // OP_CONV with the ResBlock's 1x1 skip_connection folded into its K loop (bf16, halo-kernel shapes): the block input(s)
   // `skip_in` (| `skip_in2`: the second half of a channel-concatenated input), the un-split 1x1 weights `skip_conv`, and the
   // summed bias of both convolutions
@@ -144,6 +151,11 @@ struct Net {
   int op_gn(int in, int gn, int silu, float eps, int in2 = -1);  // in2 >= 0: GroupNorm of the channel concat [in | in2]
   // emb_px4: the rows at emb_off are repeated four times (make_unet_resblock emb_rep = 4), as the dense 2 x 2 form needs them
   int op_conv(int in, int conv, int stride, int ups, int res, int emb_off, float scale = 1.f, bool emb_px4 = false);
+  // 1x1 convolution over the channel concatenation [in | in2] read in place (k_conv.hip CAT instantiation of the persistent 1x1
+  // kernel); cat_conv_ok: this network / shape can run it (bf16, whole 224- / 128-wide channel tiles ...), else the caller emits the
+  // two accumulating launches.  DDMI_CONV_CAT=0 keeps those everywhere (A/B)
+  bool cat_conv_ok(int in, int in2, int conv) const;
+  int op_conv_cat(int in, int in2, int conv);
   bool px4_ok(int in) const;   // a 3x3 / stride 1 convolution on tensor `in` may take the dense 2 x 2 form (bf16, 2 x 2 image, one plane)
   // conv3x3(in) + conv1x1([skip_in | skip_in2]) in one launch; false when this network / shape cannot fold (caller emits the two ops)
   bool can_fold_skip(int in, int conv) const;
@@ -153,6 +165,12 @@ struct Net {
   int pack_px4_weights();  // dense 2 x 2 form of the marked convolutions (called by plan)
   void mark_x3_images();         // bf16x3: GroupNorm outputs consumed only by x3 convolutions are produced as x3 images (called by plan)
   void attach_channel_stats();  // pairs GroupNorm inputs with the convolutions that produce them (called by plan)
+  void attach_fused_groupnorm();  // marks (convolution, GroupNorm) pairs for the producer-side GroupNorm epilogue (called by plan)
+  float* fgn_part = nullptr;      // granule scratch of the producer-side GroupNorm (CONV_FGN_PART_FLOATS), shared by all such launches
+  unsigned* fgn_sync = nullptr;   // {launch epoch, error flag, -, -}
+  int fgn_launches = 0;           // fused launches of the last run() (diagnostics)
+  // 0 = fine; DDMI_ERR_STATE when a fused GroupNorm launch timed out waiting for a partner tile.  SYNCHRONISES the device.
+  int async_status();
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }
   size_t tbytes(int id, int B) const;

@@ -221,6 +221,25 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
   return o.out;
 }
 
+bool Net::cat_conv_ok(int in, int in2, int conv) const {
+  static const bool off = getenv("DDMI_CONV_CAT") && atoi(getenv("DDMI_CONV_CAT")) == 0;
+  if (off || dt != DT_BF16 || x3 || conv < 0) return false;
+  const TensorDesc &t1 = tensors[in], &t2 = tensors[in2];
+  const ConvW& c = convs[conv];
+  if (c.K != 1 || !c.w || c.Cin != t1.C + t2.C || t1.H != t2.H || t1.W != t2.W || t1.bmul != t2.bmul) return false;
+  ConvArgs a{};
+  a.x = (const void*)1; a.xcat = (const void*)1; a.y = (void*)1;   // shape check only
+  a.Cin = c.Cin; a.Ccat = t2.C; a.Cout = c.Cout; a.KH = a.KW = 1; a.stride = 1; a.Hin = a.Hout = t1.H; a.Win = a.Wout = t1.W; a.B = 1;
+  a.splitk = 1;
+  return conv_cat_ok(a, dt);
+}
+
+int Net::op_conv_cat(int in, int in2, int conv) {
+  const int out = op_conv(in, conv, 1, 0, -1, -1);
+  ops.back().in2 = in2;
+  return out;
+}
+
 bool Net::can_fold_skip(int in, int conv) const {
   // OFF by default: measured on one box (B = 512, same process order, round 3) the folded launch is SLOWER than conv2 + the separate
   // 1x1 launches (41.9 vs 30.1 ms of a 139 ms UNet step; 32.5 vs ~29.5 for the variant that staged the skip sources as halos):
@@ -273,6 +292,10 @@ static void fill_conv_args(const Net& n, const Op& o, int B, ConvArgs* a) {
   }
   a->out_scale = o.scale;
   a->splitk = 1;
+  if (o.kind == OP_CONV && o.in2 >= 0) {   // [in | in2] read in place (op_conv_cat)
+    a->xcat = n.tptr(o.in2);
+    a->Ccat = n.tensors[o.in2].C;
+  }
   if (o.skip_conv >= 0) {
     a->x2 = n.tptr(o.skip_in); a->C2 = n.tensors[o.skip_in].C;
     if (o.skip_in2 >= 0) { a->x3 = n.tptr(o.skip_in2); a->C3 = n.tensors[o.skip_in2].C; }
@@ -403,9 +426,62 @@ void Net::attach_channel_stats() {
   }
 }
 
+// Producer-side GroupNorm: a GroupNorm whose single input is written by ONE plain convolution and read by nothing else (the
+// ResBlock's out_layers norm on h = conv1 + emb, openaimodel.py:261-270) can leave that convolution's epilogue already normalised.
+// Only marked here; whether a launch qualifies is decided per run (conv_fgn_ok: bf16 halo-kernel launch, no split-K, whole groups
+// per channel tile ...), and run() keeps the separate pass otherwise.  DDMI_GN_FUSE=0 / ddmi_debug_gn_fuse(0) keep every pass.
+static int g_gn_fuse_override = -1;
+void net_gn_fuse_override(int mode) { g_gn_fuse_override = mode; }
+// 0 = never, 1 = where the launch would run on the halo kernel without split-K anyway, 2 = wherever the SHAPE allows (the launch is
+// moved to the halo kernel without split-K: the parity tests' small batches)
+static int gn_fuse_mode() {
+  if (g_gn_fuse_override >= 0) return g_gn_fuse_override;
+  static const int env = getenv("DDMI_GN_FUSE") ? atoi(getenv("DDMI_GN_FUSE")) : 1;
+  return env < 0 ? 1 : env;
+}
+static bool gn_fuse_enabled() { return gn_fuse_mode() != 0; }
+void Net::attach_fused_groupnorm() {
+  if (dt != DT_BF16 || x3 || !gn_fuse_enabled()) return;
+  std::vector<int> producer(tensors.size(), -1), readers(tensors.size(), 0);
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const Op& o = ops[i];
+    auto writes = [&](int t, bool plain_conv) {
+      if (t >= 0) producer[t] = (plain_conv && producer[t] == -1) ? (int)i : -2;
+    };
+    writes(o.out, o.kind == OP_CONV && !o.out_nchw && o.out_boff == 0 && o.in_boff == 0 && o.bmul == tensors[o.out].bmul && o.res < 0 &&
+                      o.skip_conv < 0 && !o.px4 && o.ups == 0 && o.stride == 1 && o.scale == 1.f && convs[o.conv].K == 3);
+    writes(o.out2, false); writes(o.tmp0, false); writes(o.tmp1, false); writes(o.tmp2, false);
+    for (int t : {o.in, o.in2, o.res, o.skip_in, o.skip_in2}) if (t >= 0) ++readers[t];
+  }
+  for (size_t i = 0; i < ops.size(); ++i) {
+    Op& g = ops[i];
+    if (g.kind != OP_GN || g.in2 >= 0 || g.frag_out || producer[g.in] < 0 || readers[g.in] != 1) continue;
+    Op& c = ops[producer[g.in]];
+    if (c.bmul != g.bmul || c.fgn_gn >= 0) continue;
+    const TensorDesc& t = tensors[g.in];
+    if ((t.H * t.W) % 256 != 0 || t.C % 32 != 0) continue;
+    c.fgn_gn = (int)i;
+    g.fgn_conv = producer[g.in];
+  }
+}
+
+int Net::async_status() {
+  if (!fgn_sync) return DDMI_OK;
+  unsigned w[CONV_FGN_SYNC_WORDS] = {0, 0, 0, 0};
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(w, fgn_sync, sizeof w, hipMemcpyDeviceToHost));
+  if (w[1]) {
+    HIP_TRY(hipMemset(fgn_sync + 1, 0, sizeof(unsigned)));
+    return ddmi_fail(DDMI_ERR_STATE, "a fused GroupNorm launch timed out waiting for a partner tile (workgroup dispatch order not as "
+                                     "assumed): results of that run are invalid; set DDMI_GN_FUSE=0");
+  }
+  return DDMI_OK;
+}
+
 int Net::plan() {
   DDMI_TRY(pack_up4_weights());
   DDMI_TRY(pack_px4_weights());
+  attach_fused_groupnorm();
   attach_channel_stats();
   mark_x3_images();
   const int nops = (int)ops.size();
@@ -421,6 +497,7 @@ int Net::plan() {
     touch(o.in, i, false); touch(o.in2, i, false); touch(o.res, i, false); touch(o.skip_in, i, false); touch(o.skip_in2, i, false);
     touch(o.out, i, true); touch(o.out2, i, true); touch(o.tmp0, i, true); touch(o.tmp1, i, true); touch(o.tmp2, i, true);
     touch(o.stat_out, i, true); touch(o.stat_in, i, false); touch(o.stat_in2, i, false);
+    if (o.fgn_gn >= 0) touch(ops[o.fgn_gn].out, i, true);   // a fused launch writes the GroupNorm's output itself
   }
   // first-fit allocator over op order
   struct Blk { size_t off, size; };
@@ -478,6 +555,17 @@ int Net::plan() {
     size_t bytes = GN_STATS_DOUBLES(max_batch * max_bmul) * sizeof(double);  // one scratch shared by every GN op (stream order)
     HIP_TRY(hipMalloc((void**)&gn_stats, bytes));
     dev_allocs.push_back(gn_stats);
+  }
+  bool any_fgn = false;
+  for (const Op& o : ops) any_fgn = any_fgn || o.fgn_gn >= 0;
+  if (any_fgn) {
+    const size_t pbytes = CONV_FGN_PART_FLOATS((size_t)max_batch * max_bmul) * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&fgn_part, pbytes));
+    dev_allocs.push_back(fgn_part);
+    HIP_TRY(hipMemset(fgn_part, 0, pbytes));   // tag 0 never matches an epoch (the first launch's is 1)
+    HIP_TRY(hipMalloc((void**)&fgn_sync, CONV_FGN_SYNC_WORDS * sizeof(unsigned)));
+    dev_allocs.push_back(fgn_sync);
+    HIP_TRY(hipMemset(fgn_sync, 0, CONV_FGN_SYNC_WORDS * sizeof(unsigned)));
   }
   // split-K slabs: worst case over batch sizes
   splitk_bytes = 0;
@@ -548,7 +636,8 @@ int Net::plan() {
         if (!convs[o.conv].w_x3) continue;   // stays on the fp32 kernel
         a = x3_launch_args(a, x3_in, convs[o.conv].w_x3, tws);   // tuned as the bf16 problem it runs as (slab output)
       }
-      std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups, a.x2 ? a.C2 + a.C3 : 0};   // last: folded skip channels
+      std::vector<int> key{a.B, a.Hin, a.Win, a.Cin, a.Cout, a.KH, a.stride, a.ups,
+                           a.x2 ? a.C2 + a.C3 : a.xcat ? 1000000 + a.Ccat : 0};   // last: folded skip channels / second source of a concatenated input
       auto it = cache.find(key);
       // a (cfg 0, 0 us) entry is the PLACEHOLDER an older strict run left in a plan file, not a measurement: treated as absent
       if (it != cache.end() && it->second.cfg == 0 && it->second.us == 0.f) { cache.erase(it); own.erase(key); it = cache.end(); }
@@ -635,7 +724,12 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
   DDMI_REQUIRE(B >= 1 && B <= max_batch, "batch exceeds max_batch given at create time");
   const int Bnet = B;
   std::vector<int> stat_rows(tensors.size(), 0);   // rows per block of the channel statistics a conv wrote for its output (0: none)
+  std::vector<char> emb_out(tensors.size(), 0);    // diagnostics (DDMI_GN_ABL): tensors written by a convolution that adds a time embedding
+  std::vector<char> fgn_done(ops.size(), 0);       // GroupNorm ops whose producer convolution wrote the normalised tensor itself this run
+  fgn_launches = 0;
+  size_t op_index = 0;
   for (const Op& o : ops) {
+    const size_t oi = op_index++;
     const int B = Bnet * o.bmul;  // samples this op runs on
     auto plane_ptr = [&](int id, int boff) -> void* {
       return (unsigned char*)tptr(id) + (size_t)boff * Bnet * tensors[id].elems * dt_size(dt);
@@ -647,6 +741,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         break;
       }
       case OP_GN: {
+        if (fgn_done[oi]) break;   // its producer's epilogue wrote the normalised tensor
         const TensorDesc& t = tensors[o.in];
         const GNW& g = gns[o.gn];
         // in2 >= 0: GroupNorm of the channel concatenation [in | in2] without materialising it
@@ -654,6 +749,11 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         const void* x2 = o.in2 >= 0 ? tptr(o.in2) : nullptr;
         DDMI_REQUIRE(g.C == C, "groupnorm channel mismatch");
         double* st = gn_stats;
+        {  // TIMING-ONLY (DDMI_GN_ABL=1, with a -DGN_ABL build of k_conv.hip and DDMI_CONV_DBG=32): the out_layers GroupNorm passes are
+           // skipped, their consumers read stale memory - prices the producer-side GroupNorm before it is built
+          static const bool abl = getenv("DDMI_GN_ABL") && atoi(getenv("DDMI_GN_ABL")) == 1;
+          if (abl && o.in2 < 0 && emb_out[o.in]) break;
+        }
         static const bool fused_finish = !(getenv("DDMI_GN_FINISH_PASS") && atoi(getenv("DDMI_GN_FINISH_PASS")) == 1);   // diagnostics: the round-2 finish launch
         if (fused_finish && o.stat_in >= 0 && stat_rows[o.in] > 0 && (o.in2 < 0 || (o.stat_in2 >= 0 && stat_rows[o.in2] > 0))) {
           DDMI_TRY(launch_gn_apply_chstat(tptr(o.in), tptr(o.out), (const float*)tptr(o.stat_in), stat_rows[o.in],
@@ -673,12 +773,13 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
       case OP_CONV: {
         ConvArgs a;
         fill_conv_args(*this, o, B, &a);
-        DDMI_REQUIRE(tensors[o.in].C == convs[o.conv].Cin, "conv input channel mismatch");
+        DDMI_REQUIRE(tensors[o.in].C + (o.in2 >= 0 ? tensors[o.in2].C : 0) == convs[o.conv].Cin, "conv input channel mismatch");
         a.x = plane_ptr(o.in, o.in_boff);
         if (o.out_nchw) a.y_nchw = (float*)ext[o.ext];
         else a.y = plane_ptr(o.out, o.out_boff);
         if (o.res >= 0) a.res = tptr(o.res);
         if (o.emb_off >= 0) {
+          emb_out[o.out] = 1;
           DDMI_REQUIRE(emb != nullptr, "conv needs the time embedding");
           a.emb = emb + o.emb_off;
           a.emb_stride = emb_stride;
@@ -690,6 +791,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           a.cfg = o.tuned.cfg;  // keep the tuned tile, re-derive the split for this batch size
           a.splitk = conv_pick_splitk(a, dt);
         }
+        if (a.xcat) a.splitk = 1;   // the dual-source 1x1 form has no split-K (persistent kernel)
         a.splitk_ws = splitk_ws;
         if (a.splitk > 1)
           DDMI_REQUIRE((size_t)a.splitk * a.B * a.Hout * a.Wout * a.Cout * sizeof(float) <= splitk_bytes, "split-K workspace too small");
@@ -713,6 +815,24 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           a.splitk = b.splitk;
           DDMI_TRY(launch_splitk_finish(a, DT_F32, s));
           break;
+        }
+        if (o.fgn_gn >= 0 && fgn_part && gn_fuse_enabled()) {   // producer-side GroupNorm where this launch qualifies
+          const Op& gop = ops[o.fgn_gn];
+          const GNW& g = gns[gop.gn];
+          ConvArgs f = a;
+          f.gn_gamma = g.gamma; f.gn_beta = g.beta; f.gn_eps = gop.eps; f.gn_silu = gop.silu;
+          f.gn_part = fgn_part; f.gn_sync = fgn_sync;
+          f.y = tptr(gop.out);
+          if (f.cfg == 0 || gn_fuse_mode() == 2) {   // no tuned tile for this shape (or forced): the halo kernel is the 3x3 kernel of choice
+            f.cfg = (a.Cout % 224 == 0 ? 19 : 20) + 1;
+            f.splitk = gn_fuse_mode() == 2 ? 1 : conv_pick_splitk(f, dt);
+          }
+          if (g.C == a.Cout && conv_fgn_ok(f, dt)) {
+            DDMI_TRY(launch_conv(f, dt, s));
+            fgn_done[o.fgn_gn] = 1;
+            ++fgn_launches;
+            break;
+          }
         }
         if (o.stat_out >= 0) {
           const int rows = conv_chstat_rows(a, dt);

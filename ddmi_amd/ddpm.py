@@ -285,6 +285,13 @@ class DDPM:
     def sample(self, shape, cond=None, return_intermediates=False, noise=None, enable_mask=False, **kw):
         """ddpm.py:371-381: DDIM when sampling_timesteps < timesteps, ancestral loop otherwise."""
         if self.is_ddim_sampling:
-            return self.ddim_sample(shape, cond, noise=noise, enable_mask=enable_mask, **kw)
-        return self.p_sample_loop(shape, cond, return_intermediates=return_intermediates, noise=noise,
-                                  enable_mask=enable_mask, **kw)
+            out = self.ddim_sample(shape, cond, noise=noise, enable_mask=enable_mask, **kw)
+        else:
+            out = self.p_sample_loop(shape, cond, return_intermediates=return_intermediates, noise=noise,
+                                     enable_mask=enable_mask, **kw)
+        # deferred errors of the asynchronous UNet forwards (a fused GroupNorm launch that timed out waiting for a partner tile is
+        # flagged, not hung: unet.UNetModel.async_status) - checked once per chain batch; synchronises
+        status = getattr(self.model, "async_status", None)
+        if status is not None:
+            self.fused_gn_launches = status()
+        return out

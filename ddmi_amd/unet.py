@@ -194,6 +194,15 @@ class UNetModel:
         _lib.check(_lib.lib().ddmi_unet_memory(self._handle, C.byref(out)))
         return {"weights": int(out[0]), "arena": int(out[1]), "splitk": int(out[2])}
 
+    def async_status(self):
+        """Deferred errors of the asynchronous forwards (ddmi_unet_async_status; SYNCHRONISES the device): raises when a fused GroupNorm
+        launch of a bf16 network timed out waiting for a partner tile; returns how many convolutions of the last forward carried their
+        GroupNorm in the epilogue.  The sampling loops call it once per chain, at the point where they synchronise anyway."""
+        n = C.c_int(0)
+        if self._handle is not None:
+            _lib.check(_lib.lib().ddmi_unet_async_status(self._handle, C.byref(n)))
+        return int(n.value)
+
     # ---- forward ----------------------------------------------------------------------------------------
     def set_uniform_t(self, enabled: bool):
         """Sampling loops feed the same timestep to every chain of the batch; tell the library so."""

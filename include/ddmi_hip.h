@@ -79,6 +79,12 @@ int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled);
  * calls with the same buffers are one hipGraphLaunch.  Worth it when the forward is launch-bound (batch <~ 16: ~900
  * kernels of a few microseconds); at large batch it changes nothing.  The stream must not be the legacy null stream. */
 int ddmi_unet_set_graph(ddmi_unet* h, int enabled);
+/* Deferred errors of the asynchronous forwards (SYNCHRONISES the device): the producer-side GroupNorm of the bf16 networks (k_conv.hip
+ * conv_epilogue_fgn: the ResBlock's out_layers norm leaves conv1's epilogue normalised; tiles of a sample exchange their partial
+ * statistics in memory) bounds its wait for a partner tile and flags a timeout instead of hanging - DDMI_ERR_STATE then, the results
+ * of that run are invalid (DDMI_GN_FUSE=0 / ddmi_debug_gn_fuse(0) keep the separate pass).  *fused_gn_launches (may be null): how
+ * many convolutions of the last forward ran the fused epilogue. */
+int ddmi_unet_async_status(ddmi_unet* h, int* fused_gn_launches);
 int ddmi_unet_destroy(ddmi_unet* h);
 /* bytes held by the handle: [0] packed weights, [1] activation arena, [2] split-K slabs */
 int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]);
@@ -319,6 +325,10 @@ int ddmi_bench_conv(int B, int Cin, int H, int W, int Cout, int k, int stride, i
  * ddmi_op_conv2d calls of this process, so each variant can be parity-tested on its own; cfg_id < 0 restores the
  * library's choice.  A variant that does not apply to a shape (the halo kernel outside 3x3/stride 1) falls back. */
 int ddmi_debug_conv_config(int cfg_id);
+/* diagnostics: the halo kernel's two-taps-per-stage tail for a ragged last channel block (Cin = 64 k + 1..32, no split-K; k_conv.hip
+ * HALF instantiation; same products in the same order, so results are bit-identical to the plain form): 0 = off, 1 = on,
+ * -1 = the DDMI_HALO_HALF environment (default on). */
+int ddmi_debug_halo_half(int mode);
 /* GroupNorm(32 groups, eps) [+ SiLU] over [B,C,HW] */
 int ddmi_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, float eps,
                       int silu, int numerics);
@@ -349,6 +359,21 @@ int ddmi_op_attention_block(const float* x, const float* gamma, const float* bet
                             const float* wproj, const float* bproj, float* y, int B, int C, int H, int W, int head_channels,
                             int numerics, int* fused_used);
 int ddmi_debug_attn_fused(int mode);
+/* conv3x3 + bias (+ emb [B, Cout] per-sample addend, may be null) -> GroupNorm(32 groups, eps) [+ SiLU] as the LDM ResBlock runs the
+ * pair h = in_layers(x) + emb_out; out_layers[0:2](h) (openaimodel.py:261-270): x [B,Cin,H,W], w [Cout,Cin,3,3] -> y [B,Cout,H,W].  In bf16
+ * mode, where the launch qualifies (k_conv.hip conv_fgn_ok), the GroupNorm is the convolution's epilogue and the raw tensor is never
+ * stored; *fused_used reports it.  `iters` repeats the run.  ddmi_debug_gn_fuse pins the choice for networks built AND run afterwards:
+ * 0 = separate pass, 1 = fused where the launch runs on the halo kernel without split-K anyway, 2 = fused wherever the shape allows
+ * (the launch is moved to the halo kernel without split-K: small test batches), -1 = the DDMI_GN_FUSE environment (default 1). */
+int ddmi_op_conv_gn(const float* x, const float* w, const float* bias, const float* emb, const float* gamma, const float* beta, float* y,
+                    int B, int Cin, int H, int W, int Cout, float eps, int silu, int numerics, int iters, int* fused_used);
+int ddmi_debug_gn_fuse(int mode);
+/* The ResBlock's skip_connection on a channel-concatenated input (openaimodel.py:787 `th.cat([h, hs.pop()], dim=1)`, :272-275): y =
+ * conv1x1([x1 | x2]) + bias with x1 [B,C1,H,W], x2 [B,C2,H,W], w [Cout, C1 + C2] -> y [B,Cout,H,W].  In bf16 mode, for Cout a multiple
+ * of 224 or 128, it is ONE launch that reads both tensors in place (k_conv.hip, CAT instantiation of the persistent 1x1 kernel;
+ * *cat_used = 1), else two accumulating launches over the column blocks of w.  DDMI_CONV_CAT=0 in the environment keeps the two. */
+int ddmi_op_conv1x1_cat(const float* x1, const float* x2, const float* w, const float* bias, float* y, int B, int C1, int C2, int H, int W,
+                        int Cout, int numerics, int* cat_used);
 /* average device time (us) of one bf16 AttentionBlock with num_head_channels 32 on device-resident pseudo-random data */
 int ddmi_bench_attention_block(int B, int C, int H, int W, int iters, double* us_out, int* fused_used);
 /* On-box peak microbenchmarks: what this GPU sustains, beside the nominal 2.5 PFLOP/s / 8 TB/s the rooflines are
