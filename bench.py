@@ -124,12 +124,14 @@ def _profile_entry(glob_pat, live_name):
     if not files or not live_name:
         return None
     m = re.match(r"conv_ring<bf16,(\d+)x(\d+),k(\d+)x(\d+)(,ilv)?>", live_name)
-    m2 = re.match(r"conv_(pipe|halo|halo\+skip)<bf16,(\d+)x(\d+)>", live_name)
+    m2 = re.match(r"conv_(pipe|halo|halo\+skip|halo\+gn)<bf16,(\d+)x(\d+)(,tail2)?>", live_name)
     if m:
         bm, bn, kk, nst = (int(v) for v in m.groups()[:4])
         pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}, {'true' if m.group(5) else 'false'}>")
     elif m2 and m2.group(1).startswith("halo"):  # conv_halo_kernel<BN, WM, WN, SKIP>: BM is fixed at 256
-        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}(, 3)?>")   # (, 3: the 3x3 tap grid; 2 = conv_halo_up4)
+        # conv_halo_kernel<BN, WM, WN, SKIP, KT, HALF, FGN>: KT = 3 (2 = conv_halo_up4), HALF = the two-taps-per-stage tail, FGN = GroupNorm epilogue
+        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}, 3, "
+                         rf"{'true' if m2.group(4) else 'false'}, {'true' if 'gn' in m2.group(1) else 'false'}>")
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:
@@ -344,6 +346,9 @@ def run_afhq(args, rank, local_rank, world, dev):
         "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
         "last_step_phase_ms": {k: round(v, 2) for k, v in phase_ms.items()},
         "unet_memory_bytes": pipe.unet.memory(),
+        # convolutions of one UNet evaluation that carried their consumer GroupNorm in the epilogue (k_conv.hip conv_epilogue_fgn; the
+        # sampler checked the hand-off's timeout flag after every chain: DDPM.sample -> UNetModel.async_status)
+        "fused_groupnorm_launches_per_eval": getattr(pipe.ddpm, "fused_gn_launches", None),
     }
     if "attnblock_qkv_attn" in prof:   # the fused AttentionBlock launch (all three levels averaged, as profiled in the timed region)
         line["attnblock_roofline"] = roofline_of(prof, lambda p: "attnblock_qkv_attn")

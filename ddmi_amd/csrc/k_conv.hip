@@ -556,6 +556,9 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
     }
   }
   __syncthreads();
+  // (the affine parameters of step 5, fetched here so that their latency lies under the hand-off)
+  float gam = 0.f, bet = 0.f;
+  if (tid < BN) { gam = a.gn_gamma[n0 + tid]; bet = a.gn_beta[n0 + tid]; }
   // ---- 3. tile partial per group; tps == 1: the statistics are complete
   const unsigned tag = tps > 1 ? a.gn_sync[0] : 0u;
   const double cnt = (double)hw * cpg;
@@ -615,9 +618,9 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
   // ---- 5. per-channel scale / shift of this n-tile
   if (tid < BN) {
     const int g = tid / cpg;
-    const float sc = mr[g * 2 + 1] * a.gn_gamma[n0 + tid];
+    const float sc = mr[g * 2 + 1] * gam;
     ss[tid * 2] = sc;
-    ss[tid * 2 + 1] = a.gn_beta[n0 + tid] - mr[g * 2] * sc;
+    ss[tid * 2 + 1] = bet - mr[g * 2] * sc;
   }
   __syncthreads();
   // ---- 6. normalise, SiLU, round once, store
@@ -678,7 +681,7 @@ template <typename T, int FM, int FN, bool PAIRED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr,
                                               int lg, int hw) {
   if (a.dbg & 8) return;
-  if constexpr (PAIRED && sizeof(T) == 2 && (FM == 2 || FM == 4)) {
+  if constexpr (PAIRED && sizeof(T) == 2 && (FM == 2 || FM == 4 || FM == 8)) {
     // wave-uniform test (m_base, n_base and the kernel arguments are): FM * 16 is 32 or 64, a power of two
     if (!(a.dbg & 16) && a.ws == nullptr && a.y_nchw == nullptr && a.y32 == nullptr && n_base + FN * 16 <= a.Cout &&
         (a.emb == nullptr || (hw & (FM * 16 - 1)) == 0)) {
@@ -1427,7 +1430,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
   static_assert(TM % 16 == 0 && TN % 16 == 0 && (TN / 2) % 8 == 0 && NW % 2 == 0, "bad tile");
   constexpr int GB = BN / 8, B_PER = (GB + NW - 1) / NW;
   constexpr int ROWB = 128, SZ = 2;
-  constexpr int H_BYTES = HALO_MAX_ROWS * ROWB, B_BYTES = BN * ROWB;
+  // halo buffer rows: 400 serve every W (6 x 66 at W = 64, 4 x 100 at 8 x 8); the 256-wide tile's two 32 KB weight stages leave room for
+  // 344 (10 x 34 at W = 32, 18 x 18 at W = 16: the launcher keeps it off the other shapes)
+  constexpr int HROWS = BN > 224 ? 344 : HALO_MAX_ROWS;
+  constexpr int H_BYTES = HROWS * ROWB, B_BYTES = BN * ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const HB = smem;                 // [2][H_BYTES]
   unsigned char* const BB = smem + 2 * H_BYTES;   // [2][B_BYTES]
@@ -1669,7 +1675,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_halo_kernel(ConvK a) {
       // the last barrier of the last nine-stage block and behind the barrier of every one-stage block.
       if (!one_stage && tap < TAPS - 1) {
         // (2x2: three stages carry the next halo, so a stage issues up to PPS groups per wave)
-        constexpr int PPS = KT == 3 ? 1 : (HALO_MAX_ROWS / 8 + NW * (TAPS - 1) - 1) / (NW * (TAPS - 1));
+        constexpr int PPS = KT == 3 ? 1 : (HROWS / 8 + NW * (TAPS - 1) - 1) / (NW * (TAPS - 1));
 #pragma unroll 1
         for (int pp = 0; pp < PPS; ++pp) {
           const int q = (tap * PPS + pp) * NW + wave;
@@ -2011,6 +2017,7 @@ static const RingCfg kRing[] = {
     {256, 224, 1},   // 23: ring <256,224,4,2,1,5> interleaved, one stage deeper (158 KB)
     {256, 224, -3},  // 24: gemm1x1<224,4,2> PERSISTENT 1x1 kernel, 8 waves, per-wave 64x112, 120 KB  (kps -3; other shapes fall back to 13)
     {256, 128, -3},  // 25: gemm1x1<128,4,2> the same for channel counts that are multiples of 128 (tri-plane UNet, decoders), per-wave 64x64
+    {256, 256, -2},  // 26: halo<256,2,4> 8 waves, per-wave 128x64, 150 KB: the 256-wide tile for the model_channels = 256 networks (W = 16 / 32)
 };
 bool conv_halo_shape_ok(int H, int W) {
   if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
@@ -2019,6 +2026,8 @@ bool conv_halo_shape_ok(int H, int W) {
   if (hw != 64 && hw != 128) return false;              // whole samples per tile, 64 pixels per wave inside one sample
   return (256 / hw) * (H + 2) * (W + 2) <= HALO_MAX_ROWS;
 }
+// the 256-wide halo tile (configuration 26) keeps 344 halo rows: whole image rows of one sample at W = 16 / 32
+static bool halo256_shape_ok(int H, int W) { return (W == 16 || W == 32) && (H * W) % 256 == 0; }
 static bool halo_ok(const ConvArgs& a) {
   // the parity form of upsample + 3x3: 2x2 taps on the source grid (the KT = 2 instantiation)
   if (a.ups == 3) return a.KH == 2 && a.KW == 2 && a.pad == 1 && !a.x2 && conv_halo_shape_ok(a.Hin, a.Win);
@@ -2330,9 +2339,10 @@ static int launch_gemm1x1(ConvK k, hipStream_t s) {
 
 template <int BN, int WM, int WN>
 static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
-  constexpr int lds = 2 * HALO_MAX_ROWS * 128 + 2 * BN * 128;
+  constexpr int lds = 2 * (BN > 224 ? 344 : HALO_MAX_ROWS) * 128 + 2 * BN * 128;
   static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
   DDMI_REQUIRE(batch == 1 || (k.up4 && batch == 4 && splitk == 1), "halo kernel: no batched-GEMM mode");
+  DDMI_REQUIRE(BN <= 224 || halo256_shape_ok(k.Hin, k.Win), "halo kernel: the 256-wide tile serves W = 16 / 32 with whole 256-pixel tiles per sample");
   k.tiles_n = cdiv(k.Cout, BN);
   dim3 grid(cdiv(k.M, 256) * k.tiles_n, batch, splitk);
   if (k.up4) {   // four 2x2 parity convolutions on the source grid
@@ -2377,9 +2387,12 @@ static int launch_halo(ConvK k, int splitk, int batch, hipStream_t s) {
     static const std::string name = "conv_halo<bf16,256x" + std::to_string(BN) + ">";
     static const std::string name_skip = "conv_halo+skip<bf16,256x" + std::to_string(BN) + ">";
     static const std::string name_fgn = "conv_halo+gn<bf16,256x" + std::to_string(BN) + ">";
+    // (one profiler scope per INSTANTIATION, so that a scope's average launch is one rocprofv3 kernel's: tail2 = the two-taps-per-stage tail)
+    static const std::string name_half = "conv_halo<bf16,256x" + std::to_string(BN) + ",tail2>";
+    static const std::string name_half_fgn = "conv_halo+gn<bf16,256x" + std::to_string(BN) + ",tail2>";
     if (k.gn_gamma && k.gn_tps > 1) hipLaunchKernelGGL(conv_fgn_epoch_kernel, dim3(1), dim3(1), 0, s, k.gn_sync);   // this launch's granule tag
-    PROF_SCOPE(conv_prof_name(k.x2 ? name_skip : k.gn_gamma ? name_fgn : name, k).c_str(), flops, bytes, s);
-    k.ts = k.gn_gamma ? nullptr : conv_ts_buffer((int)grid.x);
+    PROF_SCOPE(conv_prof_name(k.x2 ? name_skip : k.gn_gamma ? (half ? name_half_fgn : name_fgn) : half ? name_half : name, k).c_str(), flops, bytes, s);
+    k.ts = conv_ts_buffer((int)grid.x);
     if (k.x2) hipLaunchKernelGGL(kern_skip, grid, dim3(WM * WN * 64), lds, s, k);
     else if (k.gn_gamma) hipLaunchKernelGGL(half ? kern_half_fgn : kern_fgn, grid, dim3(WM * WN * 64), lds, s, k);
     else if (half) hipLaunchKernelGGL(kern_half, grid, dim3(WM * WN * 64), lds, s, k);
@@ -2420,6 +2433,7 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 23: return launch_ring<256, 224, 4, 2, 1, 5, true>(k, splitk, batch, s);
       case 24: return launch_gemm1x1<224, 4, 2>(k, s);
       case 25: return launch_gemm1x1<128, 4, 2>(k, s);
+      case 26: return launch_halo<256, 2, 4>(k, splitk, batch, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -2461,7 +2475,7 @@ static int check_conv(const ConvArgs& a, int dt) {
 // wave tile (rows, channels) of the bf16 configurations kRing[id]
 static const int kRingWave[][2] = {{32, 112}, {32, 112}, {32, 112}, {32, 112}, {64, 64}, {32, 64}, {32, 64}, {32, 32}, {64, 64}, {64, 112}, {64, 112},
                                    {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64},
-                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}};
+                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {128, 64}};
 static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave tile per ring configuration");
 
 // Rows per statistics block (the wave tile height) when a launch of `a` with a.chstat set would fill the WHOLE
@@ -2473,6 +2487,7 @@ int conv_chstat_rows(const ConvArgs& a, int dt) {
   const int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
+  if (t.kps == -2 && t.bn == 256 && (a.ups == 3 || a.x2 || !halo256_shape_ok(a.Hin, a.Win))) t = pick_tile(M, a.Cout, dt, 20 + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   if (t.kps == -3 && !gemm1x1_ok(a, t.bn)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
   if (t.id < 0) return 0;
@@ -2495,6 +2510,7 @@ bool conv_fgn_ok(const ConvArgs& a, int dt) {
   const int M = conv_rows(a), hw = a.Hout * a.Wout;
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps != -2) return false;
+  if (t.bn == 256 && !halo256_shape_ok(a.Hin, a.Win)) t = pick_tile(M, a.Cout, dt, 20 + 1);
   const int BN = t.bn, cpg = a.Cout / 32, tps = hw / 256;
   if (a.Cout % 32 || a.Cout % BN || BN % cpg || hw % 256 || tps > 16) return false;
   const int NG = BN / cpg, tiles_n = a.Cout / BN;
@@ -2515,6 +2531,7 @@ int launch_conv(const ConvArgs& a, int dt, hipStream_t s) {
   int M = conv_rows(a);
   TileCfg t = pick_tile(M, a.Cout, dt, a.cfg);
   if (t.kps == -2 && !halo_ok(a)) t = pick_tile(M, a.Cout, dt, kHaloFallback + 1);
+  if (t.kps == -2 && t.bn == 256 && (a.ups == 3 || a.x2 || !halo256_shape_ok(a.Hin, a.Win))) t = pick_tile(M, a.Cout, dt, 20 + 1);
   if (a.x2 && t.kps != -2) t = pick_tile(M, a.Cout, dt, skip_fold_cfg(a) + 1);
   if (t.kps == -3 && !gemm1x1_ok(a, t.bn)) t = pick_tile(M, a.Cout, dt, kGemmFallback + 1);
   if (a.xcat) {   // the dual-source form exists on the persistent 1x1 kernel only
@@ -2592,6 +2609,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
   for (int id = 0; id < kNumRing; ++id) {
     const RingCfg& rc = kRing[id];
     if (rc.kps == -2 && !halo_ok(a0)) continue;
+    if (rc.kps == -2 && rc.bn == 256 && (a0.ups == 3 || a0.x2 || !halo256_shape_ok(a0.Hin, a0.Win))) continue;
     if (a0.x2 && rc.kps != -2) continue;   // a folded skip connection runs on the halo kernel only
     if (a0.xcat && rc.kps != -3) continue;  // a channel-concatenated input on the persistent 1x1 kernel only
     if (rc.kps == -3) {

@@ -97,7 +97,7 @@ def _conv_gn_ref(x, w, b, emb, gamma, beta, eps, silu):
 # without the embedding addend / SiLU; 1344 channels (42 per group: no whole groups per 224-wide tile) and 8x8 must fall back
 FGN_CASES = [(2, 224, 64, 64, 224, True, 1), (8, 64, 64, 64, 224, False, 1), (3, 448, 32, 32, 448, True, 1), (16, 224, 32, 32, 448, True, 0),
              (5, 896, 16, 16, 896, True, 1), (9, 448, 16, 16, 896, False, 1),
-             (2, 64, 32, 32, 256, True, 1), (3, 128, 16, 16, 512, True, 1)]   # 128-wide channel tiles (the model_channels = 256 networks)
+             (2, 64, 32, 32, 256, True, 1), (3, 128, 16, 16, 512, True, 1)]   # 128- / 256-wide channel tiles (the model_channels = 256 networks)
 
 
 @pytest.mark.parametrize("case", FGN_CASES)
@@ -191,3 +191,31 @@ def test_skip_connection_over_a_concatenated_input_in_one_launch(case):
         assert used.value == (expect_cat if numerics == "bf16" else 0), (case, numerics)
         assert rel_err(y.cpu(), ref) < tol, (case, numerics)
         assert float((y.cpu() - ref).abs().max()) < 2 * tol * float(ref.abs().max()), (case, numerics)
+
+
+# ---- the 256-wide halo tile (configuration 26: per-wave 128 x 64) for the model_channels = 256 networks ---------------------------------
+# (B, Cin, H, W, Cout): W = 32 / 16 whole-sample tiles, a non-square plane (video xt / yt: 16 x 32), a Cout tail (320 = 256 + 64), the
+# ragged Cin the two-tap tail takes, a batch whose last tile is the only one of its XCD range; 8 x 8 and W = 64 must fall back
+WIDE_CASES = [(2, 256, 32, 32, 256), (3, 128, 16, 16, 512), (2, 96, 16, 32, 1024), (1, 64, 32, 32, 320), (9, 32, 16, 16, 256)]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_halo_256_wide_tile(case):
+    B, Cin, H, W, Cout = case
+    tag = "wide%s" % (case,)
+    x = iw.normal(tag, "x", (B, Cin, H, W))
+    w = iw.normal(tag, "w", (Cout, Cin, 3, 3), 0.0, 1.0 / math.sqrt(Cin * 9))
+    b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=1)
+    got = conv_op(x, w, b, cfg=26)
+    assert rel_err(got, ref) < 1.5e-2, case
+    assert float((got - ref).abs().max()) < 0.03 * float(ref.abs().max()), case
+    # the same products in the same order as the 128-wide tile: bit-identical
+    assert torch.equal(got, conv_op(x, w, b, cfg=20)), case
+    for other in ((2, 64, 8, 8, 256), (1, 64, 64, 64, 256)):     # shapes it does not serve fall back to the 128-wide tile
+        Bo, Ci, Ho, Wo, Co = other
+        xo = iw.normal(tag, "xo%d" % Ho, (Bo, Ci, Ho, Wo))
+        wo = iw.normal(tag, "wo%d" % Ho, (Co, Ci, 3, 3), 0.0, 1.0 / math.sqrt(Ci * 9))
+        bo = iw.normal(tag, "bo%d" % Ho, (Co,), 0.0, 0.1)
+        ro = F.conv2d(torch.from_numpy(xo), torch.from_numpy(wo), torch.from_numpy(bo), padding=1)
+        assert rel_err(conv_op(xo, wo, bo, cfg=26), ro) < 1.5e-2, other

@@ -27,6 +27,12 @@ DEC_SHAPES = [("512->512 k3 @64", 512, 64, 512, 3, 1, 0, 10), ("256->256 k3 @128
               ("128->128 k3 @256", 128, 256, 128, 3, 1, 0, 5), ("512->512 k3 up @64->128", 512, 64, 512, 3, 1, 1, 1)]
 
 
+# the model_channels = 256 networks (configs 4 / 5): the 3x3 shapes the 256-wide halo tile (configuration 26) serves
+WIDE_SHAPES = [("256->256 k3 @32", 256, 32, 256, 3, 1, 0, 4), ("512->256 k3 @32", 512, 32, 256, 3, 1, 0, 2), ("768->256 k3 @32", 768, 32, 256, 3, 1, 0, 1),
+               ("256->256 k3 @16", 256, 16, 256, 3, 1, 0, 4), ("512->512 k3 @16", 512, 16, 512, 3, 1, 0, 6), ("1024->512 k3 @16", 1024, 16, 512, 3, 1, 0, 2),
+               ("1536->512 k3 @16", 1536, 16, 512, 3, 1, 0, 1)]
+
+
 def run(B, shape, numerics, bm=0, bn=0, splitk=0, iters=20):
     name, cin, hw, cout, k, stride, ups, cnt = shape
     ms = C.c_double()
@@ -43,6 +49,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, nargs="+", default=[4, 8])
     ap.add_argument("--numerics", default="bf16")
     ap.add_argument("--decoder", action="store_true")
+    ap.add_argument("--wide", action="store_true", help="the 3x3 shapes of the model_channels = 256 networks at W = 16 / 32")
     ap.add_argument("--only", default="", help="substring filter on shape names")
     ap.add_argument("--tiles", default="", help="comma list of BMxBN to force, e.g. 128x112,128x128")
     ap.add_argument("--cfgs", default="", help="comma list of bf16 ring config ids to force (k_conv.hip kRing)")
@@ -51,7 +58,7 @@ if __name__ == "__main__":
     tiles = [tuple(map(int, t.split("x"))) for t in args.tiles.split(",") if t] or [(0, 0)]
     if args.cfgs:
         tiles = [(int(c), -1) for c in args.cfgs.split(",")]
-    shapes = DEC_SHAPES if args.decoder else UNET_SHAPES
+    shapes = DEC_SHAPES if args.decoder else WIDE_SHAPES if args.wide else UNET_SHAPES
     if args.only:
         shapes = [s for s in shapes if args.only in s[0]]
     for B in args.batch:

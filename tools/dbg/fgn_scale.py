@@ -20,13 +20,13 @@ for B in [int(b) for b in sys.argv[1].split(",")]:
     emb = torch.randn(B, Cout, device="cuda")
     g = torch.ones(Cout, device="cuda")
     y = torch.empty(B, Cout, H, H, device="cuda")
-    for fuse in (0, 2):
+    for fuse in [int(m) for m in os.environ.get("FGN_MODES", "0,2").split(",")]:
         used = C.c_int(-1)
         L.ddmi_debug_gn_fuse(fuse)
         torch.cuda.synchronize()
         t0 = time.time()
         rc = L.ddmi_op_conv_gn(x.data_ptr(), w.data_ptr(), b.data_ptr(), emb.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), B, Cin, H, H, Cout,
-                               1e-5, 1, 1, 3, C.byref(used))
+                               1e-5, 1, 1, int(os.environ.get('FGN_ITERS', '3')), C.byref(used))
         torch.cuda.synchronize()
         print(f"B={B} Cin={Cin} H={H} Cout={Cout} fuse={fuse}: rc={rc} fused_used={used.value} {time.time() - t0:.2f} s for plan + 3 runs "
               f"{L.ddmi_last_error().decode() if rc else ''}", flush=True)
