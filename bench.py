@@ -262,6 +262,7 @@ def run_afhq(args, rank, local_rank, world, dev):
         out = D.all_gather_samples(img, world)
         ev[3].record()
         phase["ev"], phase["idx"], phase["img"], phase["z"] = ev, idx, img, z
+        phase["fgn"] = getattr(pipe.ddpm, "fused_gn_launches", None)   # of the chain just sampled (DDPM.sample checks the hand-off's flag)
         return out
 
     for w in range(args.warmup):
@@ -348,7 +349,7 @@ def run_afhq(args, rank, local_rank, world, dev):
         "unet_memory_bytes": pipe.unet.memory(),
         # convolutions of one UNet evaluation that carried their consumer GroupNorm in the epilogue (k_conv.hip conv_epilogue_fgn; the
         # sampler checked the hand-off's timeout flag after every chain: DDPM.sample -> UNetModel.async_status)
-        "fused_groupnorm_launches_per_eval": getattr(pipe.ddpm, "fused_gn_launches", None),
+        "fused_groupnorm_launches_per_eval": phase.get("fgn"),
     }
     if "attnblock_qkv_attn" in prof:   # the fused AttentionBlock launch (all three levels averaged, as profiled in the timed region)
         line["attnblock_roofline"] = roofline_of(prof, lambda p: "attnblock_qkv_attn")

@@ -444,6 +444,19 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
   }
 }
 
+// A 128-row wave tile (FM = 8: the 256-wide configurations 26-28) takes the fast epilogue as two 64-row halves: each half has its own
+// embedding row (an 8x8 plane puts two samples into the wave's rows) and its own 64-row block of channel statistics
+template <int FM, int FN, bool STATS = true, bool BIAS_LDS = false>
+__device__ __forceinline__ void conv_epilogue_fast_rows(const ConvK& a, f32x4 (&acc)[FM][FN], int m_base, int n_base, int lr, int lg, int hw,
+                                                        const float* bias_lds = nullptr) {
+  if constexpr (FM == 8) {
+    conv_epilogue_fast<4, FN, STATS, BIAS_LDS>(a, *reinterpret_cast<f32x4(*)[4][FN]>(&acc[0]), m_base, n_base, lr, lg, hw, bias_lds);
+    conv_epilogue_fast<4, FN, STATS, BIAS_LDS>(a, *reinterpret_cast<f32x4(*)[4][FN]>(&acc[4]), m_base + 64, n_base, lr, lg, hw, bias_lds);
+  } else {
+    conv_epilogue_fast<FM, FN, STATS, BIAS_LDS>(a, acc, m_base, n_base, lr, lg, hw, bias_lds);
+  }
+}
+
 // =====================================================================================================
 // Producer-side GroupNorm (round 5): y = [SiLU](GroupNorm32(acc + bias + emb)) leaves the convolution's epilogue as bf16 - the raw
 // tensor is never stored, the gn_apply pass over it (a read + a write of the tensor at the HBM roof: 9.6 % of a UNet step in
@@ -683,9 +696,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x4 (&acc)[FM][F
   if (a.dbg & 8) return;
   if constexpr (PAIRED && sizeof(T) == 2 && (FM == 2 || FM == 4 || FM == 8)) {
     // wave-uniform test (m_base, n_base and the kernel arguments are): FM * 16 is 32 or 64, a power of two
+    constexpr int RG = FM == 8 ? 64 : FM * 16;   // rows that must share a sample (conv_epilogue_fast_rows)
     if (!(a.dbg & 16) && a.ws == nullptr && a.y_nchw == nullptr && a.y32 == nullptr && n_base + FN * 16 <= a.Cout &&
-        (a.emb == nullptr || (hw & (FM * 16 - 1)) == 0)) {
-      conv_epilogue_fast<FM, FN>(a, acc, m_base, n_base, lr, lg, hw);
+        (a.emb == nullptr || (hw & (RG - 1)) == 0)) {
+      conv_epilogue_fast_rows<FM, FN>(a, acc, m_base, n_base, lr, lg, hw);
       return;
     }
   }
@@ -1377,7 +1391,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm1x1_kernel(ConvK a) {
     if (last) {   // the tile is complete: epilogue on the accumulators, then start the next tile's first chunk
       int tm, tn;
       tile_mn(ct, &tm, &tn);
-      conv_epilogue_fast<FM, FN, STATS, true>(a, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lg, hw, bias_lds);
+      conv_epilogue_fast_rows<FM, FN, STATS, true>(a, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lg, hw, bias_lds);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -2018,6 +2032,8 @@ static const RingCfg kRing[] = {
     {256, 224, -3},  // 24: gemm1x1<224,4,2> PERSISTENT 1x1 kernel, 8 waves, per-wave 64x112, 120 KB  (kps -3; other shapes fall back to 13)
     {256, 128, -3},  // 25: gemm1x1<128,4,2> the same for channel counts that are multiples of 128 (tri-plane UNet, decoders), per-wave 64x64
     {256, 256, -2},  // 26: halo<256,2,4> 8 waves, per-wave 128x64, 150 KB: the 256-wide tile for the model_channels = 256 networks (W = 16 / 32)
+    {256, 256, -1},  // 27: pipe<256,256,2,4> the same tile on the pipe kernel (their levels below 16 pixels, stride 2, upsampling), 136 KB
+    {256, 256, -3},  // 28: gemm1x1<256,2,4> ... and on the persistent 1x1 kernel (two activation slots), 128 KB + bias
 };
 bool conv_halo_shape_ok(int H, int W) {
   if (!(W == 8 || W == 16 || W == 32 || W == 64)) return false;
@@ -2280,6 +2296,7 @@ bool conv_cat_ok(const ConvArgs& a, int dt);
 static bool gemm1x1_ok(const ConvArgs& a, int bn = 224) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.ups && a.splitk <= 1 && !a.force_ws && a.Cout % bn == 0 && a.y_nchw == nullptr &&
          a.y32 == nullptr && a.x2 == nullptr && a.Cin % 8 == 0 && a.y != nullptr && a.Cin > 128 &&
+         (2 * 256 + 2 * bn) * 128 + a.Cout * 4 <= 160 * 1024 &&   // two activation slots, two weight stages and the bias vector in LDS
          (a.emb == nullptr || (a.Hout * a.Wout) % 64 == 0);   // (the fast epilogue's conditions; at least three stages per tile)
 }
 static const int kGemmFallback = 13;
@@ -2434,6 +2451,8 @@ static int dispatch(const ConvK& k, TileCfg t, int dt, int splitk, int batch, hi
       case 24: return launch_gemm1x1<224, 4, 2>(k, s);
       case 25: return launch_gemm1x1<128, 4, 2>(k, s);
       case 26: return launch_halo<256, 2, 4>(k, splitk, batch, s);
+      case 27: return launch_pipe<256, 256, 2, 4>(k, splitk, batch, s);
+      case 28: return launch_gemm1x1<256, 2, 4>(k, s);
     }
     return ddmi_fail(DDMI_ERR_INVALID, "conv: no ring configuration");
   }
@@ -2475,7 +2494,7 @@ static int check_conv(const ConvArgs& a, int dt) {
 // wave tile (rows, channels) of the bf16 configurations kRing[id]
 static const int kRingWave[][2] = {{32, 112}, {32, 112}, {32, 112}, {32, 112}, {64, 64}, {32, 64}, {32, 64}, {32, 32}, {64, 64}, {64, 112}, {64, 112},
                                    {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 112}, {64, 64},
-                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {128, 64}};
+                                   {64, 112}, {64, 112}, {64, 112}, {64, 112}, {64, 64}, {64, 64}, {64, 64}, {64, 64}};   // (26-28: 128 x 64 as two 64-row halves)
 static_assert(sizeof(kRingWave) / sizeof(kRingWave[0]) == kNumRing, "one wave tile per ring configuration");
 
 // Rows per statistics block (the wave tile height) when a launch of `a` with a.chstat set would fill the WHOLE

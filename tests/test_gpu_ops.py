@@ -117,7 +117,7 @@ def _variant_case(case):
     return _variant_cache[case]
 
 
-@pytest.mark.parametrize("cfg", list(range(27)))
+@pytest.mark.parametrize("cfg", list(range(29)))
 def test_conv2d_every_bf16_variant(cfg):
     L = _lib.lib()
     try:

@@ -219,3 +219,27 @@ def test_halo_256_wide_tile(case):
         bo = iw.normal(tag, "bo%d" % Ho, (Co,), 0.0, 0.1)
         ro = F.conv2d(torch.from_numpy(xo), torch.from_numpy(wo), torch.from_numpy(bo), padding=1)
         assert rel_err(conv_op(xo, wo, bo, cfg=26), ro) < 1.5e-2, other
+
+
+@pytest.mark.parametrize("cfg", [26, 27])
+@pytest.mark.parametrize("case", [(3, 64, 8, 8, 256), (2, 128, 16, 16, 512), (5, 64, 8, 16, 256)])
+def test_wide_tile_epilogue_with_embedding_rows_and_channel_statistics(cfg, case):
+    """The 128-row wave tile of the 256-wide configurations takes the fast epilogue as two 64-row halves: at 8x8 a wave's rows hold TWO
+    samples (two embedding rows), and the consumer GroupNorm reads 64-row blocks of channel statistics.  conv + emb -> GroupNorm + SiLU
+    through the network executor on the pinned configuration, against torch fp64 (cfg 26 falls back to the 128-wide halo tile at 8x8)."""
+    B, Cin, H, W, Cout = case
+    tag = "wideemb%s" % (case,)
+    x = iw.normal(tag, "x", (B, Cin, H, W))
+    w = iw.normal(tag, "w", (Cout, Cin, 3, 3), 0.0, 1.0 / math.sqrt(Cin * 9))
+    b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+    emb = iw.normal(tag, "e", (B, Cout), 0.0, 0.7)
+    gamma = iw.normal(tag, "g", (Cout,), 1.0, 0.2)
+    beta = iw.normal(tag, "bt", (Cout,), 0.0, 0.2)
+    ref = _conv_gn_ref(x, w, b, emb, gamma, beta, 1e-5, 1)
+    L = _lib.lib()
+    try:
+        _lib.check(L.ddmi_debug_conv_config(cfg))
+        y, used = conv_gn_op(x, w, b, emb, gamma, beta, fuse=0)
+    finally:
+        L.ddmi_debug_conv_config(-1)
+    assert used == 0 and rel_err(y, ref) < 1.5e-2, (cfg, case, rel_err(y, ref))
