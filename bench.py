@@ -130,8 +130,12 @@ def _profile_entry(glob_pat, live_name):
         pat = re.compile(rf"conv_ring_kernel<{bm}, {bn}, \d+, \d+, {kk // 32}, {nst}, {'true' if m.group(5) else 'false'}>")
     elif m2 and m2.group(1).startswith("halo"):  # conv_halo_kernel<BN, WM, WN, SKIP>: BM is fixed at 256
         # conv_halo_kernel<BN, WM, WN, SKIP, KT, HALF, FGN>: KT = 3 (2 = conv_halo_up4), HALF = the two-taps-per-stage tail, FGN = GroupNorm epilogue
-        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}, 3, "
-                         rf"{'true' if m2.group(4) else 'false'}, {'true' if 'gn' in m2.group(1) else 'false'}>")
+        tail = rf", {'true' if m2.group(4) else 'false'}, {'true' if 'gn' in m2.group(1) else 'false'}"
+        if not m2.group(4) and "gn" not in m2.group(1):   # the plain instantiation: profiles of rounds 1-4 list it with four or five arguments
+            tail = rf"(, 3({tail})?)?"
+        else:
+            tail = ", 3" + tail
+        pat = re.compile(rf"conv_halo_kernel<{m2.group(3)}, \d+, \d+, {'true' if 'skip' in m2.group(1) else 'false'}{tail}>")
     elif m2:
         pat = re.compile(rf"conv_pipe_kernel<{m2.group(2)}, {m2.group(3)}, ")
     else:

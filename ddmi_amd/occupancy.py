@@ -358,21 +358,13 @@ class Generator3D:
         return TriMesh(*self._to_host(v, f)), mesh2
 
     def _to_host(self, v, f):
-        """The mesh's two arrays to numpy through PINNED staging buffers kept on the generator (grown on demand): `tensor.cpu()` into
-        pageable memory is a shader copy on ROCm (`__amd_rocclr_copyBuffer`: 2 x ~3.5 MB per 128^3 mesh, 3.6 % of the shapenet leg's
-        kernel time in round 4, competing with the next shape's MLP3D launch for CUs); a pinned destination goes through the SDMA
-        engines.  One synchronisation of the current stream for both arrays; the numpy arrays returned own their memory."""
+        """The mesh's two arrays to numpy.  These are the `__amd_rocclr_copyBuffer` dispatches of the shapenet leg's profiles (two PCIe
+        transfers of a few MB per 128^3 mesh, run by ROCclr's copy kernel on the side stream; 3.6 % of the leg's kernel time in round 4).
+        Round 5 measured what they cost the pipeline: with the copies SKIPPED (`DDMI_DIAG_SKIP_MESH_D2H=1`, meshes come back empty) the leg
+        runs at 122.3 shapes/s against 122.4 with them - they are hidden under the next shape's MLP3D launch.  Staging them through pinned
+        buffers (tried) kept the copy kernel and made it 4x as many dispatches; the plain `.cpu()` stays."""
+        import os
         import numpy as np
-        import torch
-        bufs = []
-        for name, t in (("_pin_v", v), ("_pin_f", f)):
-            n = t.numel()
-            buf = getattr(self, name, None)
-            if buf is None or buf.numel() < n or buf.dtype != t.dtype:
-                buf = torch.empty(max(n, 1 << 18), dtype=t.dtype, pin_memory=True)
-                setattr(self, name, buf)
-            if n:
-                buf[:n].copy_(t.reshape(-1), non_blocking=True)
-            bufs.append((buf, n, tuple(t.shape)))
-        torch.cuda.current_stream(v.device).synchronize()
-        return tuple(np.array(buf[:n].numpy()).reshape(shape) for buf, n, shape in bufs)
+        if os.environ.get("DDMI_DIAG_SKIP_MESH_D2H"):   # timing-only diagnostics (see above)
+            return np.zeros((0, 3)), np.zeros((0, 3), np.int64)
+        return v.cpu().numpy(), f.cpu().numpy()
