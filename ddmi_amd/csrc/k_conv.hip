@@ -2654,6 +2654,16 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
         if (order > n_walk && order <= 2) continue;
         ConvArgs a = a0;
         a.cfg = id + 1; a.order = order; a.splitk = sk; a.splitk_ws = ws;
+        // a0.chstat set = the consumer GroupNorm wants this convolution's channel statistics: a candidate that can deliver them is
+        // timed WITH that epilogue work, one that cannot is charged the statistics pass it forces (a read of the output at ~5 TB/s
+        // + a launch) - round 5: the tuner had picked the unpaired 256-wide pipe tile for sky's convolutions and `gn_stats` doubled
+        float penalty_us = 0.f;
+        if (a0.chstat) {
+          if (conv_chstat_rows(a, dt) == 0) {
+            a.chstat = nullptr;
+            penalty_us = 5.f + (float)((double)M * a0.Cout * 2.0 / 5.0e6);
+          }
+        }
         int rc2 = DDMI_OK;
         for (int i = 0; i < 2 && rc2 == DDMI_OK; ++i) rc2 = launch_conv(a, dt, 0);
         (void)hipEventRecord(e0, 0);
@@ -2665,7 +2675,7 @@ int conv_autotune(const ConvArgs& a0, int dt, float* ws, size_t ws_bytes, ConvPl
         }
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        float us = ms * 250.f;
+        float us = ms * 250.f + penalty_us;
         if (us < best_us) {
           best_us = us;
           *best = ConvPlan{id + 1, order, sk, us};

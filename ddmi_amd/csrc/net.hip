@@ -632,6 +632,12 @@ int Net::plan() {
       ConvArgs a;
       fill_conv_args(*this, o, max_batch * o.bmul, &a);
       a.y = tptr(o.out);  // timing only: results are overwritten by the real run
+      if (!x3) {
+        // time what will run: the embedding addend decides which epilogue a tile takes (a 128-row wave tile on an 8x8 plane), the
+        // consumer GroupNorm's statistics are epilogue work for the tiles that deliver them and a separate pass for those that do not
+        if (o.emb_off >= 0 && (size_t)a.B * a.Cout * sizeof(float) <= tws_bytes) { a.emb = tws; a.emb_stride = a.Cout; }
+        if (o.stat_out >= 0) a.chstat = (float*)tptr(o.stat_out);
+      }
       if (x3) {
         if (!convs[o.conv].w_x3) continue;   // stays on the fp32 kernel
         a = x3_launch_args(a, x3_in, convs[o.conv].w_x3, tws);   // tuned as the bf16 problem it runs as (slab output)
