@@ -223,6 +223,23 @@ def roofline_of(prof, pick, workload="afhq"):
             "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
 
 
+GN_FUSE_FALLBACK = []   # messages of fused-GroupNorm hand-offs that timed out (never seen on MI355X): the fusion is switched off and the call redone
+
+
+def guarded_generate(pipe, *a, **kw):
+    """`pipe.generate(...)`.  The fused GroupNorm epilogue bounds its wait for a partner tile and reports a timeout instead of hanging
+    (DESIGN 4.11): a bench line beats a crash, so on that error the fusion is switched off (the line says so) and the call is repeated."""
+    from ddmi_amd import _lib
+    try:
+        return pipe.generate(*a, **kw)
+    except _lib.DdmiError as e:
+        if "fused GroupNorm" not in str(e):
+            raise
+        _lib.check(_lib.lib().ddmi_debug_gn_fuse(0))
+        GN_FUSE_FALLBACK.append(str(e))
+        return pipe.generate(*a, **kw)
+
+
 def psnr(a, b, peak=2.0):
     import torch
     mse = float(((a.double() - b.double()) ** 2).mean())
@@ -262,7 +279,7 @@ def run_afhq(args, rank, local_rank, world, dev):
         idx = [(step_idx * world + rank) * B + j for j in range(B)]  # disjoint global sample indices
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        img, z = pipe.generate(idx, base_seed=args.seed, events=ev[1:3], rng=args.rng, return_latent=True)
+        img, z = guarded_generate(pipe, idx, base_seed=args.seed, events=ev[1:3], rng=args.rng, return_latent=True)
         out = D.all_gather_samples(img, world)
         ev[3].record()
         phase["ev"], phase["idx"], phase["img"], phase["z"] = ev, idx, img, z
@@ -314,7 +331,7 @@ def run_afhq(args, rank, local_rank, world, dev):
         D.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        img = pipe.generate(phase["idx"], base_seed=args.seed, rng=args.rng)
+        img = guarded_generate(pipe, phase["idx"], base_seed=args.seed, rng=args.rng)
         D.all_gather_samples(img, world)
         torch.cuda.synchronize()
         dt = D.max_over_ranks(time.perf_counter() - t1, dev)
@@ -354,6 +371,7 @@ def run_afhq(args, rank, local_rank, world, dev):
         # convolutions of one UNet evaluation that carried their consumer GroupNorm in the epilogue (k_conv.hip conv_epilogue_fgn; the
         # sampler checked the hand-off's timeout flag after every chain: DDPM.sample -> UNetModel.async_status)
         "fused_groupnorm_launches_per_eval": phase.get("fgn"),
+        "gn_fuse_fallback": GN_FUSE_FALLBACK or None,   # null: no hand-off ever timed out
     }
     if "attnblock_qkv_attn" in prof:   # the fused AttentionBlock launch (all three levels averaged, as profiled in the timed region)
         line["attnblock_roofline"] = roofline_of(prof, lambda p: "attnblock_qkv_attn")
@@ -457,7 +475,7 @@ def run_shapenet(args, rank, local_rank, world, dev):
     def one_step(step_idx):
         idx = [(step_idx * world + rank) * B + j for j in range(B)]
         nfaces = []   # each mesh is counted and dropped as it is made (`sink`): 4 096 random-weight meshes are ~60 GB of host memory per rank
-        pipe.generate(idx, base_seed=args.seed, sink=lambda m: nfaces.append(len(m.faces)))
+        guarded_generate(pipe, idx, base_seed=args.seed, sink=lambda m: nfaces.append(len(m.faces)))
         assert len(nfaces) == B
         stats["faces"] = sum(nfaces)
         stats["idx"] = idx
@@ -565,7 +583,7 @@ def run_sky(args, rank, local_rank, world, dev):
 
     def one_step(step_idx):
         idx = [(step_idx * world + rank) * B + j for j in range(B)]
-        vid = pipe.generate(idx, base_seed=args.seed)
+        vid = guarded_generate(pipe, idx, base_seed=args.seed)
         return D.all_gather_samples(vid, world)
 
     if args.warmup == 0:
