@@ -59,6 +59,12 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// bf16-storage paths: SiLU / sigmoid on the hardware exponential and the hardware RECIPROCAL (v_rcp_f32, 1 ulp).  `__frcp_rn` - what these
+// paths used through round 4 - is the correctly ROUNDED reciprocal: v_rcp_f32 plus a v_div_scale / v_fma / v_div_fmas / v_div_fixup
+// refinement, eleven more VALU instructions per element (found in the ISA of the GroupNorm epilogue in round 5: 17 VALU per element where
+// 6 do the work; the result is rounded to bf16 two instructions later)
+__device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float silu_fast(float v) { return v * rcp_fast(1.0f + __expf(-v)); }
 // full-precision variant for the parity path (expf, not the fast intrinsic)
 __device__ __forceinline__ float silu_precise(float v) { return v / (1.0f + expf(-v)); }
 #endif

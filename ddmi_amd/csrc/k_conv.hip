@@ -349,7 +349,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float q = fmaf(v[e], cb[2 * p][e & 3], cb[2 * p + 1][e & 3]);
-          v[e] = q * __frcp_rn(1.0f + __expf(-q));
+          v[e] = silu_fast(q);
         }
       }
 #endif
@@ -379,7 +379,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& a, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float q = fmaf(v[e], cb[FN - 1][e], cb[0][e]);
-          v[e] = q * __frcp_rn(1.0f + __expf(-q));
+          v[e] = silu_fast(q);
         }
       }
 #endif
@@ -613,27 +613,32 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
       gp[(t * 32 + g) * 2] = v[0];
       gp[(t * 32 + g) * 2 + 1] = v[1];
     }
-    __syncthreads();
-    if (tid < NG) {
+  }
+  __syncthreads();
+  // ---- 5. per-channel scale / shift of this n-tile.  tps > 1: every channel's thread adds its group's tile partials itself, in tile
+  //         order (the same bits in every thread and every tile of the sample: deterministic) - one barrier and one LDS round trip less
+  //         than reducing on 32 threads first
+  if (tid < BN) {
+    const int g = tid / cpg;
+    float mean, rstd;
+    if (tps == 1) {
+      mean = mr[g * 2];
+      rstd = mr[g * 2 + 1];
+    } else {
       double s1 = 0.0, s2 = 0.0;
-      for (int tt = 0; tt < tps; ++tt) {   // tile order: every tile of the sample gets the same bits
-        s1 += (double)gp[(tt * 32 + tid) * 2];
-        s2 += (double)gp[(tt * 32 + tid) * 2 + 1];
+      for (int tt = 0; tt < tps; ++tt) {
+        s1 += (double)gp[(tt * 32 + g) * 2];
+        s2 += (double)gp[(tt * 32 + g) * 2 + 1];
       }
       const double m = s1 / cnt;
       double var = s2 / cnt - m * m;
       if (var < 0) var = 0;
-      mr[tid * 2] = (float)m;
-      mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
     }
-  }
-  __syncthreads();
-  // ---- 5. per-channel scale / shift of this n-tile
-  if (tid < BN) {
-    const int g = tid / cpg;
-    const float sc = mr[g * 2 + 1] * gam;
+    const float sc = rstd * gam;
     ss[tid * 2] = sc;
-    ss[tid * 2 + 1] = bet - mr[g * 2] * sc;
+    ss[tid * 2 + 1] = bet - mean * sc;
   }
   __syncthreads();
   // ---- 6. normalise, SiLU, round once, store
@@ -641,7 +646,7 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
   const bool silu = a.gn_silu != 0;
   auto act = [&](float x, float sc, float sh) {
     float q = fmaf(x, sc, sh);
-    if (silu) q = q * __frcp_rn(1.0f + __expf(-q));
+    if (silu) q = silu_fast(q);
     return q;
   };
 #pragma unroll

@@ -220,7 +220,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               float q = t[j] * sc[j] + sh[j];
-              if (silu) q = q * __frcp_rn(1.0f + __expf(-q));
+              if (silu) q = silu_fast(q);
               t[j] = q;
             }
             Vec16<T>::store(reinterpret_cast<T*>(scr + u * ITEM_BYTES + wr0 + hlf * 128), t);
@@ -292,7 +292,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
 #pragma unroll
       for (int j = 0; j < VN; ++j) {
         float q = t[j] * sc[j] + sh[j];
-        if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
+        if (silu) q = sizeof(T) == 2 ? silu_fast(q) : silu_precise(q);
         t[j] = q;
       }
       store_out(p + u * R, t);
@@ -307,7 +307,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
 #pragma unroll
       for (int j = 0; j < VN; ++j) {
         float q = t[u][j] * sc[j] + sh[j];
-        if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
+        if (silu) q = sizeof(T) == 2 ? silu_fast(q) : silu_precise(q);
         t[u][j] = q;
       }
       store_out(p + u * R, t[u]);
@@ -319,7 +319,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
       float q = t[j] * sc[j] + sh[j];
-      if (silu) q = sizeof(T) == 2 ? q * __frcp_rn(1.0f + __expf(-q)) : silu_precise(q);
+      if (silu) q = sizeof(T) == 2 ? silu_fast(q) : silu_precise(q);
       t[j] = q;
     }
     store_out(p, t);

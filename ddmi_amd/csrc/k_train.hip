@@ -769,7 +769,7 @@ int launch_sum_b(const float* in, float* out, int B, int C, hipStream_t s, int a
 // instructions per element and held the GroupNorm backward's statistics pass at 2.9 TB/s; the fp32 parity mode keeps them
 template <bool FAST = false>
 __device__ __forceinline__ float tr_dsilu(float z) {
-  const float sg = FAST ? __frcp_rn(1.0f + __expf(-z)) : 1.0f / (1.0f + expf(-z));
+  const float sg = FAST ? rcp_fast(1.0f + __expf(-z)) : 1.0f / (1.0f + expf(-z));
   return sg * (1.0f + z * (1.0f - sg));
 }
 
