@@ -273,25 +273,9 @@ __global__ void __launch_bounds__(256, 1) mlp3d_kernel(Mlp3dK a) {
 #define M3V2_P 128
 #define M3V2_FP 80   // feature row pitch (160 B): conflict-free for the b128 lane groups
 
-// bf16 kernel: the same map with the division by the constant (1 + padding + 10e-6) as a multiplication by its reciprocal - an IEEE
-// fp32 division is a dozen VALU instructions (v_div_scale / v_rcp / v_fma x 4 / v_div_fmas / v_div_fixup), six of them per thread and
-// gather round, in a phase nothing overlaps (found in the ISA in round 5: 36 such sequences + six 64-bit integer divisions per thread,
-// ~900 of the kernel's 5 300 VALU instructions); the fp32 parity kernel keeps the reference's division
-__device__ __forceinline__ float m3_texcoord_fast(float p, int S) {
-  float u = p * (1.0f / (1.0f + 0.1f + 10e-6f)) + 0.5f;
-  if (u >= 1.0f) u = 1.0f - 10e-6f;
-  if (u < 0.0f) u = 0.0f;
-  const float ix = u * (float)(S - 1);   // (2u - 1 + 1) / 2 * (S - 1)
-  return fminf(fmaxf(ix, 0.f), (float)(S - 1));
-}
-
 // raw features of scale `sc` (sum over the three planes of bilinear samples) -> F[P][FP]
 __device__ __forceinline__ void m3v2_gather(const Mlp3dK& a, int sc, int64_t tile0, bf16_t* F) {
   const int S = a.hw[sc];
-  // sample of the tile's first point and that point's index inside it: ONE 64-bit division per workgroup (wave-uniform) instead of one per
-  // thread and round; a point of the tile lies in sample b0 + (r0 + pi) / N with a 32-bit quotient of 0 or 1 for N >= 128
-  const int64_t b0 = tile0 / a.N;
-  const int r0 = (int)(tile0 - b0 * a.N);
 #pragma unroll   // both items of a thread: 24 texel loads in flight (the accumulators are dead at a block boundary)
   for (int rnd = 0; rnd < M3V2_P * 8 / 512; ++rnd) {
     const int it = threadIdx.x + 512 * rnd;
@@ -301,19 +285,16 @@ __device__ __forceinline__ void m3v2_gather(const Mlp3dK& a, int sc, int64_t til
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
     if (gp < a.total) {
-      const int q = r0 + pi, b = (int)b0 + (a.N >= M3V2_P ? (q >= (int)a.N ? 1 : 0) : q / (int)a.N);
+      const int b = (int)(gp / a.N);
       const float* pt = a.pts + gp * 3;
       const float c3[3] = {pt[0], pt[1], pt[2]};
       // plane j: xy -> axes (0,1), yz -> (1,2), xz -> (0,2)   (general_utils.py:79-84)
       const int ax0[3] = {0, 1, 0}, ax1[3] = {1, 2, 2};
       bf16x8 t[3][4];
       float w[3][4];
-      float tc[3];   // one texture coordinate per axis (each axis serves two planes)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) tc[j] = m3_texcoord_fast(c3[j], S);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {   // all twelve texel loads of the point in flight before the first blend
-        const float ix = tc[ax0[j]], iy = tc[ax1[j]];
+        const float ix = m3_texcoord(c3[ax0[j]], S), iy = m3_texcoord(c3[ax1[j]], S);
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         const int x0 = (int)x0f, y0 = (int)y0f;
