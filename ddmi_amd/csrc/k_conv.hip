@@ -2543,6 +2543,10 @@ bool conv_fgn_ok(const ConvArgs& a, int dt) {
   // m-major order the launch is pinned to - must all fit the 32 CUs of an XCD with room to spare.  (The D2C-VAE decoder's 512-channel
   // convolutions at 64x64 - 16 x 4 = 64 - do not: every launch sat in its bounded poll until the timeout; found on the first bench run.)
   if (tps > 1 && tps * tiles_n > 16) return false;
+  // ... and each cohort inside ONE XCD's contiguous tile range: with B % 8 != 0 the ranges cut through samples, the first workgroups of
+  // an XCD then hold their CUs for the whole launch waiting for the last ones of its neighbour (measured on the AFHQ UNet: B = 250
+  // 65.9 -> 72.4 ms per evaluation with the fusion on, B = 100 31.6 -> 32.2; no timeout, just slower) - a speed rule, not a correctness one
+  if (tps > 1 && a.B % 8 != 0 && !a.gn_any_batch) return false;
   if (a.emb && a.emb_stride % 4) return false;
   return true;
 }

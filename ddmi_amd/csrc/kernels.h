@@ -118,6 +118,7 @@ struct ConvArgs {
   int gn_silu;
   float* gn_part;
   unsigned* gn_sync;
+  int gn_any_batch;   // fuse at any batch (tests); default: cohorts that exchange statistics only at batches that are multiples of 8 (conv_fgn_ok)
 };
 // scratch of the producer-side GroupNorm: granules [max samples][16 tiles][32 groups][4 floats] + sync words {epoch, error flag}
 #define CONV_FGN_PART_FLOATS(samples) ((size_t)(samples) * 16 * 32 * 4)

@@ -828,6 +828,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           ConvArgs f = a;
           f.gn_gamma = g.gamma; f.gn_beta = g.beta; f.gn_eps = gop.eps; f.gn_silu = gop.silu;
           f.gn_part = fgn_part; f.gn_sync = fgn_sync;
+          f.gn_any_batch = gn_fuse_mode() == 2;
           f.y = tptr(gop.out);
           if (f.cfg == 0 || gn_fuse_mode() == 2) {   // no tuned tile for this shape (or forced): the halo kernel is the 3x3 kernel of choice
             f.cfg = (a.Cout % 224 == 0 ? 19 : 20) + 1;

@@ -243,3 +243,20 @@ def test_wide_tile_epilogue_with_embedding_rows_and_channel_statistics(cfg, case
     finally:
         L.ddmi_debug_conv_config(-1)
     assert used == 0 and rel_err(y, ref) < 1.5e-2, (cfg, case, rel_err(y, ref))
+
+
+def test_groupnorm_fusion_default_mode_fuses_exchanging_cohorts_only_at_batches_that_are_multiples_of_8():
+    """conv_fgn_ok's speed rule: with B % 8 != 0 the XCD tile ranges cut through samples and the fused launch is slower than conv + pass
+    (AFHQ UNet, B = 250: 65.9 -> 72.4 ms).  Default mode: B = 8 fuses, B = 9 keeps the pass; a 16x16 launch (one tile per sample: nothing to
+    exchange) fuses at any batch.  Results right either way."""
+    for B, Cin, H, Cout, expect in ((8, 64, 64, 224, 1), (9, 64, 64, 224, 0), (9, 64, 16, 896, 1)):
+        tag = "fgnb8_%d_%d" % (B, H)
+        x = iw.normal(tag, "x", (B, Cin, H, H))
+        w = iw.normal(tag, "w", (Cout, Cin, 3, 3), 0.0, 1.0 / math.sqrt(Cin * 9))
+        b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+        emb = iw.normal(tag, "e", (B, Cout), 0.0, 0.5)
+        gamma = iw.normal(tag, "g", (Cout,), 1.0, 0.2)
+        beta = iw.normal(tag, "bt", (Cout,), 0.0, 0.2)
+        y, used = conv_gn_op(x, w, b, emb, gamma, beta, fuse=1)
+        assert used == expect, (B, H, used)
+        assert rel_err(y, _conv_gn_ref(x, w, b, emb, gamma, beta, 1e-5, 1)) < 1.5e-2, (B, H)
