@@ -172,11 +172,18 @@ def pmc_traffic(live_name, workload="afhq"):
     return (v["hbm_bytes_per_launch"], v["_source"]) if v else (None, None)
 
 
-def effective_clock(live_name, achieved_tflops):
+def effective_clock(live_name, achieved_tflops, workload="afhq"):
     """Context for `frac`: the shader clock the chip sustained under this kernel in the committed `rocprofv3 --pmc GRBM_GUI_ACTIVE`
-    pass (profiles/*effective_clock*.json, tools/pmc_clock.py) and the fraction of the dense peak AT THAT CLOCK (the 2.5 PFLOP/s
-    of `peak` is quoted at 2.4 GHz; DVFS holds MFMA-dense loops below it).  Informational - `frac` stays against the nominal peak."""
-    v = _profile_entry("*effective_clock*.json", live_name)
+    pass OF THAT WORKLOAD (profiles/*effective_clock.json for the AFHQ leg, *effective_clock_<workload>.json for the others:
+    tools/pmc_clock.py, tools/gpu_clock_workload.sh) and the fraction of the dense peak AT THAT CLOCK (the 2.5 PFLOP/s of `peak` is
+    quoted at 2.4 GHz; DVFS holds MFMA-dense loops below it).  Informational - `frac` stays against the nominal peak.  A leg whose
+    kernels the AFHQ pass also runs (train: the halo kernel) falls back to that file; a kernel in neither reports null."""
+    v = None
+    if workload != "afhq":
+        v = _profile_entry(f"*effective_clock_{PMC_TRAFFIC_SUFFIX.get(workload, workload)}.json", live_name)
+    if not v and not (workload != "afhq" and live_name.split("[")[0] in ("attention_mh", "attention_legacy")):
+        # (the attention scopes name a family: only the workload's own pass knows which instantiation its shapes run)
+        v = _profile_entry("*effective_clock.json", live_name)
     if not v:
         return None
     return {"effective_ghz": v["effective_ghz"], "peak_at_clock": v["mfma_peak_at_clock_tflops"],
@@ -217,7 +224,7 @@ def roofline_of(prof, pick, workload="afhq"):
     mp = measured_peaks()
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "measured_peak": mp, "frac_of_measured": round(ach / mp["mfma_bf16_tflops"], 4),
-            "traffic": traffic, "traffic_profile": traffic_src, "clock": effective_clock(dom, ach),
+            "traffic": traffic, "traffic_profile": traffic_src, "clock": effective_clock(dom, ach, workload),
             "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_timed": d["launches"],
             "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
             "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}

@@ -241,6 +241,14 @@ def test_bench_profile_lookups_and_bounded_cpu_samples():
     t16, _ = bench.pmc_traffic("attention_mh[B256,h16,d16,N2048,seg3]", "sky")
     assert t64 and t512 and t16 and t64 > 4 * t512 and len({t64, t512, t16}) == 3
     assert bench.pmc_traffic("no_such_kernel", "afhq") == (None, None)         # a kernel the file does not hold: null, never a stale number
+    # `roofline.clock` per workload: each leg reads the GRBM_GUI_ACTIVE pass of ITS OWN command; the AFHQ pattern never picks a workload file
+    c_shape, c_sky, c_dec = (bench.effective_clock(k, 1000.0, wl) for k, wl in (("mlp3d_fused", "shapenet"), ("conv_pipe<bf16,256x256>", "sky"),
+                                                                               ("attention_mh", "sky")))
+    assert c_shape and "effective_clock_shapenet" in c_shape["profile"]["file"] and 1.5 < c_shape["effective_ghz"] < 2.6
+    assert c_sky and c_dec and "effective_clock_sky" in c_sky["profile"]["file"] and "effective_clock_sky" in c_dec["profile"]["file"]
+    c_afhq = bench.effective_clock("conv_halo+gn<bf16,256x224>", 1000.0)
+    assert c_afhq and c_afhq["profile"]["file"].endswith("effective_clock.json")
+    assert bench.effective_clock("attention_mh", 1000.0, "no_such_workload") is None   # an attention family name never resolves through another leg's file
     calls = []
     mean, n = bench.timed_evals(lambda a: (calls.append(a), time.sleep(0.05)), [(1,), (2,), (3,)], budget_s=0.07)
     assert n == 2 and calls == [1, 2] and 0.04 < mean < 0.2

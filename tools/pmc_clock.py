@@ -34,7 +34,7 @@ if __name__ == "__main__":
                 a[1] += float(r["Counter_Value"])
                 a[2] += ns
     out = {"command": cmd, "head": os.environ.get("DDMI_HEAD"), "method": "sum(GRBM_GUI_ACTIVE) / 8 / sum(dispatch ns); nominal 2.4 GHz <-> 2.5 PFLOP/s dense bf16", "kernels": {}}
-    for k, (n, cyc, ns) in sorted(acc.items(), key=lambda kv: -kv[1][2])[:16]:
+    for k, (n, cyc, ns) in sorted(acc.items(), key=lambda kv: -kv[1][2])[:24]:
         if ns <= 0:
             continue
         ghz = cyc / 8.0 / ns
