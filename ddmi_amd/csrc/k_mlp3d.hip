@@ -274,11 +274,12 @@ __global__ void __launch_bounds__(256, 1) mlp3d_kernel(Mlp3dK a) {
 #define M3V2_FP 80   // feature row pitch (160 B): conflict-free for the b128 lane groups
 
 // raw features of scale `sc` (sum over the three planes of bilinear samples) -> F[P][FP]
+template <int NT>
 __device__ __forceinline__ void m3v2_gather(const Mlp3dK& a, int sc, int64_t tile0, bf16_t* F) {
   const int S = a.hw[sc];
-#pragma unroll   // both items of a thread: 24 texel loads in flight (the accumulators are dead at a block boundary)
-  for (int rnd = 0; rnd < M3V2_P * 8 / 512; ++rnd) {
-    const int it = threadIdx.x + 512 * rnd;
+#pragma unroll   // all items of a thread: 24 (NT = 512) / 48 (NT = 256) texel loads in flight (the accumulators are dead at a block boundary)
+  for (int rnd = 0; rnd < M3V2_P * 8 / NT; ++rnd) {
+    const int it = threadIdx.x + NT * rnd;
     const int pi = it >> 3, cg = it & 7;
     const int64_t gp = tile0 + pi;
     float v[8];
@@ -319,15 +320,32 @@ __device__ __forceinline__ void m3v2_gather(const Mlp3dK& a, int sc, int64_t til
   }
 }
 
-__global__ void __launch_bounds__(512, 1) mlp3d_v2_kernel(Mlp3dK a) {
-  constexpr int P = M3V2_P, MF = P / 16, NF = 2, FP = M3V2_FP;
+template <int NW, int MF, int NF, int KX, int KF, int FP, bool RELU>
+__device__ __forceinline__ void m3_pass(const bf16_t* __restrict__ X, const bf16_t* __restrict__ F, const bf16_t* __restrict__ W, int off, int g0,
+                                        int lane, bf16x8 (&wq)[2][NF], f32x4 (&acc)[MF][NF]) {
+  if constexpr (NW == 4) fc2_pass_halves<MF, NF, KX, KF, FP, RELU>(X, F, W, off, g0, lane, wq, acc);
+  else fc2_pass<MF, NF, KX, KF, FP, RELU>(X, F, W, off, g0, lane, wq, acc);
+}
+
+// NW = 8: wave w owns the channel pair-group [32 w, 32 w + 32) (the second generation as measured in rounds 2-4).
+// NW = 4 (round 5): wave w owns TWO pair-groups, [64 w, 64 w + 64), still for all 128 points - one wave per SIMD.  An activation
+// fragment read from LDS now feeds four MFMAs instead of two: per k-step the CU's waves read 32 KB of activations where eight waves
+// read 64 KB (= the whole LDS bandwidth over the 512 clocks the k-step's MFMAs take), the relu on the fragments is done half as often,
+// and every weight byte is still fetched once per workgroup (the 64 x 64 wave tile that also halves the LDS reads doubles them).
+// NW = 8, PH = 2 (round 5, the split the round-4 verdict asked to see measured): wave = 64 channels x 64 points - channel group wave % 4,
+// point half wave / 4.  Half the LDS reads per MFMA as well, at two waves per SIMD, but the two point halves each fetch the weights.
+template <int NW, int PH>
+__global__ void __launch_bounds__(64 * NW, 1) mlp3d_v2_kernel(Mlp3dK a) {
+  constexpr int P = M3V2_P, MF = P / 16 / PH, PR = 8 * PH / NW, NF = 2 * PR, FP = M3V2_FP, CW = NW / PH, NOUT = P / 16 / NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* X0 = (bf16_t*)smem;
   bf16_t* X1 = X0 + P * FC2_XP;
   bf16_t* F = X1 + P * FC2_XP;
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g0 = 2 * wave, ch0 = 32 * wave + 8 * lg;   // this lane's eight channels: ch0 .. ch0 + 7
+  const int cgp = wave % CW, r0 = (wave / CW) * (P / PH);     // channel group; first point row of this wave's point range
+  const int g0 = NF * cgp, ch0 = 32 * PR * cgp + 8 * lg;      // this lane's channels: ch0 + 32 pr .. + 7 of pair-group pr
+  const int xo = r0 * FC2_XP, fo = r0 * FP;
   const int64_t tile0 = (int64_t)blockIdx.x * P;
   const bf16_t* W = (const bf16_t*)a.w;
   const float* fb = a.fb;
@@ -342,95 +360,106 @@ __global__ void __launch_bounds__(512, 1) mlp3d_v2_kernel(Mlp3dK a) {
   };
   auto wprime = [&](int off, int KS) { fc2_wload<NF>(W, off, KS, g0, 0, lane, wq[0]); };
   auto cload = [&](const float* table) {
-    cst[0] = *reinterpret_cast<const f32x4*>(table + ch0);
-    cst[1] = *reinterpret_cast<const f32x4*>(table + ch0 + 4);
+#pragma unroll
+    for (int pr = 0; pr < PR; ++pr) {
+      cst[2 * pr] = *reinterpret_cast<const f32x4*>(table + ch0 + 32 * pr);
+      cst[2 * pr + 1] = *reinterpret_cast<const f32x4*>(table + ch0 + 32 * pr + 4);
+    }
   };
-  auto store8 = [&](bf16_t* Xout, int row, const f32x4& lo, const f32x4& hi) {
+  auto store8 = [&](bf16_t* Xout, int row, int pr, const f32x4& lo, const f32x4& hi) {
     bf16x8 q;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       q[e] = (bf16_t)lo[e];
       q[4 + e] = (bf16_t)hi[e];
     }
-    *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0) = q;
+    *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0 + 32 * pr) = q;
   };
   // hidden activation: relu(acc + bias) -> Xout (rectified: fc_1 reads it as is)
   auto store_hidden = [&](bf16_t* Xout) {
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      f32x4 lo, hi;
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        lo[e] = fmaxf(acc[mf][0][e] + cst[0][e], 0.f);
-        hi[e] = fmaxf(acc[mf][1][e] + cst[1][e], 0.f);
+      for (int pr = 0; pr < PR; ++pr) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] = fmaxf(acc[mf][2 * pr][e] + cst[2 * pr][e], 0.f);
+          hi[e] = fmaxf(acc[mf][2 * pr + 1][e] + cst[2 * pr + 1][e], 0.f);
+        }
+        store8(Xout, r0 + 16 * mf + lr, pr, lo, hi);
       }
-      store8(Xout, 16 * mf + lr, lo, hi);
-    }
   };
   // block output: x = acc (fc_1 + shortcut) + bias [+ identity x_in] -> Xout, raw
   auto store_block = [&](const bf16_t* Xid, bf16_t* Xout) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      const int row = 16 * mf + lr;
-      f32x4 lo = acc[mf][0], hi = acc[mf][1];
-      if (Xid != nullptr) {
-        const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Xid + row * FC2_XP + ch0);
+      const int row = r0 + 16 * mf + lr;
+#pragma unroll
+      for (int pr = 0; pr < PR; ++pr) {
+        f32x4 lo = acc[mf][2 * pr], hi = acc[mf][2 * pr + 1];
+        if (Xid != nullptr) {
+          const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Xid + row * FC2_XP + ch0 + 32 * pr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            lo[e] += (float)xi[e];
+            hi[e] += (float)xi[4 + e];
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          lo[e] += (float)xi[e];
-          hi[e] += (float)xi[4 + e];
+          lo[e] += cst[2 * pr][e];
+          hi[e] += cst[2 * pr + 1][e];
         }
+        store8(Xout, row, pr, lo, hi);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        lo[e] += cst[0][e];
-        hi[e] += cst[1][e];
-      }
-      store8(Xout, row, lo, hi);
     }
   };
 
   // ================= block 1: x1 = net_p(p) + RB(64 -> 256)(f0), hidden width 64 (waves 0, 1) ======================
   wprime(m3_off(0), 2);
-  m3v2_gather(a, 0, tile0, F);
+  m3v2_gather<64 * NW>(a, 0, tile0, F);
   __syncthreads();
-  if (wave < 2) {
+  if (cgp * PR < 2) {   // the 64 hidden channels = two pair-groups
     zero();
     cload(fb + M3_B_R1FC0);
-    fc2_pass<MF, NF, 0, 64, FP, true>(X1, F, W, m3_off(0), g0, lane, wq, acc);     // fc_0(relu(f0)): 64 -> 64
+    m3_pass<NW, MF, NF, 0, 64, FP, true>(X1 + xo, F + fo, W, m3_off(0), g0, lane, wq, acc);     // fc_0(relu(f0)): 64 -> 64
     store_hidden(X1);
   }
   wprime(m3_off(1), 2);
   __syncthreads();
   zero();
-  fc2_pass<MF, NF, 64, 0, FP, false>(X1, F, W, m3_off(1), g0, lane, wq, acc);        // fc_1(relu(net)): 64 -> 256
+  m3_pass<NW, MF, NF, 64, 0, FP, false>(X1 + xo, F + fo, W, m3_off(1), g0, lane, wq, acc);        // fc_1(relu(net)): 64 -> 256
   wprime(m3_off(2), 2);
   cload(fb + M3_B(0));
-  fc2_pass<MF, NF, 0, 64, FP, false>(X0, F, W, m3_off(2), g0, lane, wq, acc);        // + shortcut(f0), bias-free
+  m3_pass<NW, MF, NF, 0, 64, FP, false>(X0 + xo, F + fo, W, m3_off(2), g0, lane, wq, acc);        // + shortcut(f0), bias-free
   wprime(m3_off(3), 10);
   {  // + net_p(coords): Linear(3 -> 256) on the fp32 coordinates (mlp.py:103)
-    float wp[8][3], bp[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(fb + M3_WP + (ch0 + c) * 4);
-      wp[c][0] = w4[0]; wp[c][1] = w4[1]; wp[c][2] = w4[2];
-      bp[c] = fb[M3_BP + ch0 + c];
-    }
+    for (int pr = 0; pr < PR; ++pr) {
+      float wp[8][3], bp[8];
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      const int64_t gp = tile0 + 16 * mf + lr;
-      float px = 0.f, py = 0.f, pz = 0.f;
-      if (gp < a.total) { px = a.pts[gp * 3]; py = a.pts[gp * 3 + 1]; pz = a.pts[gp * 3 + 2]; }
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(fb + M3_WP + (ch0 + 32 * pr + c) * 4);
+        wp[c][0] = w4[0]; wp[c][1] = w4[1]; wp[c][2] = w4[2];
+        bp[c] = fb[M3_BP + ch0 + 32 * pr + c];
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[mf][0][e] += wp[e][0] * px + wp[e][1] * py + wp[e][2] * pz + bp[e];
-        acc[mf][1][e] += wp[4 + e][0] * px + wp[4 + e][1] * py + wp[4 + e][2] * pz + bp[4 + e];
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t gp = tile0 + r0 + 16 * mf + lr;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (gp < a.total) { px = a.pts[gp * 3]; py = a.pts[gp * 3 + 1]; pz = a.pts[gp * 3 + 2]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[mf][2 * pr][e] += wp[e][0] * px + wp[e][1] * py + wp[e][2] * pz + bp[e];
+          acc[mf][2 * pr + 1][e] += wp[4 + e][0] * px + wp[4 + e][1] * py + wp[4 + e][2] * pz + bp[4 + e];
+        }
       }
     }
   }
   store_block(nullptr, X0);
   __syncthreads();   // every wave is done with f0 and the hidden tile
-  m3v2_gather(a, 1, tile0, F);
+  m3v2_gather<64 * NW>(a, 1, tile0, F);
   __syncthreads();
 
   // ---- blocks 2-4.  IN = raw block input, TMP = the other buffer (hidden, then the block output).
@@ -438,22 +467,22 @@ __global__ void __launch_bounds__(512, 1) mlp3d_v2_kernel(Mlp3dK a) {
   {                                                                                                                   \
     zero();                                                                                                           \
     cload(fb + M3_B(b_fc0));                                                                                          \
-    fc2_pass<MF, NF, 256, KF, FP, true>(IN, F, W, m3_off(m_fc0), g0, lane, wq, acc);      /* fc_0(relu([x | f])) */   \
+    m3_pass<NW, MF, NF, 256, KF, FP, true>(IN + xo, F + fo, W, m3_off(m_fc0), g0, lane, wq, acc);      /* fc_0(relu([x | f])) */   \
     wprime(m3_off(m_fc1), 8);                                                                                         \
     store_hidden(TMP);                                                                                                \
     __syncthreads();                                                                                                  \
     zero();                                                                                                           \
     cload(fb + M3_B(b_fc1));                                                                                          \
-    fc2_pass<MF, NF, 256, 0, FP, false>(TMP, F, W, m3_off(m_fc1), g0, lane, wq, acc);     /* fc_1(relu(net)) */       \
+    m3_pass<NW, MF, NF, 256, 0, FP, false>(TMP + xo, F + fo, W, m3_off(m_fc1), g0, lane, wq, acc);     /* fc_1(relu(net)) */       \
     if ((m_sc) >= 0) wprime(m3_off((m_sc) >= 0 ? (m_sc) : 0), (256 + (KF)) / 32);                                     \
     __syncthreads(); /* every wave has read the hidden tile: the block output goes there */                           \
     if ((m_sc) >= 0)                                                                                                  \
-      fc2_pass<MF, NF, 256, KF, FP, false>(IN, F, W, m3_off((m_sc) >= 0 ? (m_sc) : 0), g0, lane, wq, acc);            \
+      m3_pass<NW, MF, NF, 256, KF, FP, false>(IN + xo, F + fo, W, m3_off((m_sc) >= 0 ? (m_sc) : 0), g0, lane, wq, acc);            \
     if ((next_KS) > 0) wprime((next_off), (next_KS));                                                                 \
     store_block((m_sc) >= 0 ? nullptr : IN, TMP);                                                                     \
     __syncthreads();                                                                                                  \
     if ((next_scale) >= 0) {                                                                                          \
-      m3v2_gather(a, (next_scale), tile0, F);                                                                         \
+      m3v2_gather<64 * NW>(a, (next_scale), tile0, F);                                                                         \
       __syncthreads();                                                                                                \
     }                                                                                                                 \
   }
@@ -461,17 +490,19 @@ __global__ void __launch_bounds__(512, 1) mlp3d_v2_kernel(Mlp3dK a) {
   M3V2_BLOCK(X1, X0, 64, 6, 7, 8, 3, 4, -1, m3_off(9), 8);     // block 3: [x2 | f2] -> X0
   M3V2_BLOCK(X0, X1, 0, 9, 10, -1, 5, 6, -1, 0, 0);            // block 4: identity shortcut -> X1
 #undef M3V2_BLOCK
-  // ================= net_out: 256 -> 1 (rows padded to 16): one 16-point fragment per wave ===========================
-  {
+  // ================= net_out: 256 -> 1 (rows padded to 16): 16-point fragments, PR per wave ==========================
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int pf = NOUT * wave + i;
     f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const bf16x8 wf = *reinterpret_cast<const bf16x8*>(W + fc2_wfrag(m3_off(11), 8, 0, ks) + 8 * lane);
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(X1 + (16 * wave + lr) * FC2_XP + ks * 32 + 8 * lg);
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(X1 + (16 * pf + lr) * FC2_XP + ks * 32 + 8 * lg);
       r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, r, 0, 0, 0);
     }
     if (lg == 0) {
-      const int64_t gp = tile0 + 16 * wave + lr;
+      const int64_t gp = tile0 + 16 * pf + lr;
       if (gp < a.total) a.logits[gp] = r[0] + fb[M3_BOUT];
     }
   }
@@ -493,12 +524,21 @@ int launch_mlp3d(const Mlp3dArgs& a, int dt, hipStream_t s) {
   PROF_SCOPE("mlp3d_fused", 2.0 * 627712.0 * (double)k.total, plane_bytes + 16.0 * (double)k.total, s);
   if (dt == DT_BF16) {  // weights in fragment order (mlp3d_pack_fragment_order)
     const size_t lds = (size_t)(2 * M3V2_P * FC2_XP + M3V2_P * M3V2_FP) * sizeof(bf16_t);
+    // DDMI_MLP3D_WAVES (read per launch: the tests A/B the forms) - 8: the shipped form; 4: four waves x (64 channels x 128 points);
+    // 64: eight waves x (64 channels x 64 points).  Both alternatives are bit-identical and measured slower.
+    const char* nwe = getenv("DDMI_MLP3D_WAVES");
+    const int nw = nwe ? atoi(nwe) : 8;
     static bool set = false;
     if (!set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_v2_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_v2_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3d_v2_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set = true;
     }
-    hipLaunchKernelGGL(mlp3d_v2_kernel, dim3((unsigned)cdiv64(k.total, M3V2_P)), dim3(512), lds, s, k);
+    const dim3 grid((unsigned)cdiv64(k.total, M3V2_P));
+    if (nw == 4) hipLaunchKernelGGL((mlp3d_v2_kernel<4, 1>), grid, dim3(256), lds, s, k);
+    else if (nw == 64) hipLaunchKernelGGL((mlp3d_v2_kernel<8, 2>), grid, dim3(512), lds, s, k);
+    else hipLaunchKernelGGL((mlp3d_v2_kernel<8, 1>), grid, dim3(512), lds, s, k);
   } else {
     using L = M3L<float>;
     size_t lds = (size_t)(3 * L::P * L::XP + 2 * L::P * L::FP) * sizeof(float);

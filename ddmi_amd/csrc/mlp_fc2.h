@@ -73,6 +73,51 @@ __device__ __forceinline__ void fc2_pass(const bf16_t* __restrict__ X, const bf1
   }
 }
 
+// The same pass for a wave that owns FOUR channel fragments (NF = 4: k_mlp3d.hip's four-wave form): the activation fragments are
+// fetched half a k-step ahead in two halves of MF / 2 (32 registers instead of 64 - with 128 accumulators the whole-k-step form
+// leaves the register allocator shuffling accumulators through AGPRs inside the loop).  Same MFMA order per accumulator.
+template <int MF, int NF, int KX, int KF, int FP, bool RELU>
+__device__ __forceinline__ void fc2_pass_halves(const bf16_t* __restrict__ X, const bf16_t* __restrict__ F, const bf16_t* __restrict__ W,
+                                                int off, int g0, int lane, bf16x8 (&wq)[2][NF], f32x4 (&acc)[MF][NF]) {
+  constexpr int KS = (KX + KF) / 32, MH = MF / 2;
+  static_assert(KS % 2 == 0 && (KX % 32) == 0 && MF % 2 == 0, "two k-steps per trip");
+  const int lr = lane & 15, lg = lane >> 4;
+  const bf16_t* xrow = X + lr * FC2_XP + 8 * lg;
+  const bf16_t* frow = F + lr * FP + 8 * lg - KX;
+  auto xload = [&](int ks, int half, bf16x8(&xf)[MH]) {
+    const int k0 = ks * 32;
+    const bf16_t* p = (k0 >= KX) ? frow + k0 : xrow + k0;
+    const int pitch = (k0 >= KX) ? 16 * FP : 16 * FC2_XP;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      xf[m] = *reinterpret_cast<const bf16x8*>(p + (half * MH + m) * pitch);
+      if (RELU) xf[m] = fc2_relu(xf[m]);
+    }
+  };
+  auto mma = [&](const bf16x8(&w)[NF], int half, const bf16x8(&x)[MH]) {
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        acc[half * MH + m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nf], x[m], acc[half * MH + m][nf], 0, 0, 0);
+  };
+  bf16x8 xa[MH], xb[MH];
+  xload(0, 0, xa);
+#pragma unroll 1
+  for (int ks = 0; ks < KS; ks += 2) {
+    fc2_wload<NF>(W, off, KS, g0, ks + 1, lane, wq[1]);
+    xload(ks, 1, xb);
+    mma(wq[0], 0, xa);
+    xload(ks + 1, 0, xa);
+    mma(wq[0], 1, xb);
+    if (ks + 2 < KS) fc2_wload<NF>(W, off, KS, g0, ks + 2, lane, wq[0]);
+    xload(ks + 1, 1, xb);
+    mma(wq[1], 0, xa);
+    if (ks + 2 < KS) xload(ks + 2, 0, xa);
+    mma(wq[1], 1, xb);
+  }
+}
+
 // host: one row-major [rows][K] fp32 matrix -> fragment order [rows/16][K/32][64 lanes][8]; rows % 32 == 0 matrices are
 // PAIRED: row 4q + e of group 2p + h is output channel 32 p + 8 q + 4 h + e (a lane's two fragments = 8 consecutive channels)
 static inline void fc2_pack_matrix(const float* src, float* dst, int rows, int K) {

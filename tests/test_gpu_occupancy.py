@@ -55,6 +55,23 @@ def test_mlp3d_golden(golden, numerics, tol):
     assert rel_err(sub, o1["logits"][:, :1000]) < tol
 
 
+def test_mlp3d_alternative_wave_tiles_are_bit_identical(golden, monkeypatch):
+    """`DDMI_MLP3D_WAVES=4` / `=64` (wave tiles of 64 channels x 128 / 64 points: half the LDS reads per MFMA; both measured SLOWER)
+    accumulate every output in the order of the shipped eight-wave form: same bits, incl. a ragged last tile."""
+    o1 = golden.npz("O1_occupancy.npz")
+    mlp = MLP3D(numerics="bf16")
+    mlp.load_state_dict(named_state("O1.mlp3d", mlp.manifest()))
+    planes = tuple([torch.from_numpy(o1[f"{n}{i}"]).to(DEV) for i in range(3)] for n in ("xy", "yz", "xz"))
+    pts = torch.from_numpy(o1["points"][:, :4001])
+    monkeypatch.setenv("DDMI_MLP3D_WAVES", "8")
+    a = mlp(pts, planes).logits.clone()
+    for form in ("4", "64"):   # four waves x (64 channels x 128 points); eight waves x (64 channels x 64 points)
+        monkeypatch.setenv("DDMI_MLP3D_WAVES", form)
+        b = mlp(pts, planes).logits.clone()
+        assert torch.equal(a, b), form
+        assert rel_err(b, o1["logits"][:, :4001]) < TOL_BF16
+
+
 def test_manifests_match_reference(golden):
     man = golden.json("manifests.json")
     cfgs = golden.json("configs.json")
