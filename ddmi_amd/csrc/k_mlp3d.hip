@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64 * NW, 1) mlp3d_v2_kernel(Mlp3dK a) {
       q[e] = (bf16_t)lo[e];
       q[4 + e] = (bf16_t)hi[e];
     }
-    *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0 + 32 * pr) = q;
+    if (!(FC2_ABL & 16)) *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0 + 32 * pr) = q;
   };
   // hidden activation: relu(acc + bias) -> Xout (rectified: fc_1 reads it as is)
   auto store_hidden = [&](bf16_t* Xout) {
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(64 * NW, 1) mlp3d_v2_kernel(Mlp3dK a) {
   }
   store_block(nullptr, X0);
   __syncthreads();   // every wave is done with f0 and the hidden tile
-  m3v2_gather<64 * NW>(a, 1, tile0, F);
+  if (!(FC2_ABL & 8)) m3v2_gather<64 * NW>(a, 1, tile0, F);
   __syncthreads();
 
   // ---- blocks 2-4.  IN = raw block input, TMP = the other buffer (hidden, then the block output).
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(64 * NW, 1) mlp3d_v2_kernel(Mlp3dK a) {
     if ((next_KS) > 0) wprime((next_off), (next_KS));                                                                 \
     store_block((m_sc) >= 0 ? nullptr : IN, TMP);                                                                     \
     __syncthreads();                                                                                                  \
-    if ((next_scale) >= 0) {                                                                                          \
+    if ((next_scale) >= 0 && !(FC2_ABL & 8)) {                                                                       \
       m3v2_gather<64 * NW>(a, (next_scale), tile0, F);                                                                         \
       __syncthreads();                                                                                                \
     }                                                                                                                 \

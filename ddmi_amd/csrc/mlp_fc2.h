@@ -11,6 +11,12 @@
 #pragma once
 #include "common.h"
 
+// timing-only ablation builds (tools/build_variant.sh NAME k_mlp3d.hip -DFC2_ABL=<bits>; WRONG results on purpose): bit 0 no relu on the
+// fragments, bit 1 no weight fetch inside the k-loop, bit 2 no activation reads inside the k-loop, bit 3 (k_mlp3d.hip) no feature gather
+// after the first, bit 4 (k_mlp3d.hip) no epilogue stores
+#ifndef FC2_ABL
+#define FC2_ABL 0
+#endif
 #define FC2_XP 272   // activation row pitch in elements (544 B): (row * 136 + 4 lg) mod 64 conflict-free for ds_read_b128
 
 typedef __attribute__((ext_vector_type(8))) short fc2_s16x8;
@@ -49,7 +55,7 @@ __device__ __forceinline__ void fc2_pass(const bf16_t* __restrict__ X, const bf1
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       xf[mf] = *reinterpret_cast<const bf16x8*>(p + mf * pitch);
-      if (RELU) xf[mf] = fc2_relu(xf[mf]);
+      if (RELU && !(FC2_ABL & 1)) xf[mf] = fc2_relu(xf[mf]);
     }
   };
   auto mma = [&](const bf16x8(&w)[NF], const bf16x8(&x)[MF]) {
@@ -62,14 +68,14 @@ __device__ __forceinline__ void fc2_pass(const bf16_t* __restrict__ X, const bf1
   xload(0, xq[0]);
 #pragma unroll 1
   for (int ks = 0; ks < KS; ks += 2) {
-    fc2_wload<NF>(W, off, KS, g0, ks + 1, lane, wq[1]);
-    xload(ks + 1, xq[1]);
+    if (!(FC2_ABL & 2)) fc2_wload<NF>(W, off, KS, g0, ks + 1, lane, wq[1]);
+    if (!(FC2_ABL & 4)) xload(ks + 1, xq[1]);
     mma(wq[0], xq[0]);
     if (ks + 2 < KS) {
-      fc2_wload<NF>(W, off, KS, g0, ks + 2, lane, wq[0]);
-      xload(ks + 2, xq[0]);
+      if (!(FC2_ABL & 2)) fc2_wload<NF>(W, off, KS, g0, ks + 2, lane, wq[0]);
+      if (!(FC2_ABL & 4)) xload(ks + 2, xq[0]);
     }
-    mma(wq[1], xq[1]);
+    mma((FC2_ABL & 2) ? wq[0] : wq[1], (FC2_ABL & 4) ? xq[0] : xq[1]);
   }
 }
 
