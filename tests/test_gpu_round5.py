@@ -260,3 +260,42 @@ def test_groupnorm_fusion_default_mode_fuses_exchanging_cohorts_only_at_batches_
         y, used = conv_gn_op(x, w, b, emb, gamma, beta, fuse=1)
         assert used == expect, (B, H, used)
         assert rel_err(y, _conv_gn_ref(x, w, b, emb, gamma, beta, 1e-5, 1)) < 1.5e-2, (B, H)
+
+
+def test_unet_with_fused_groupnorm_handoff_eager_graph_and_unfused():
+    """A UNet whose conv1 launches exchange GroupNorm statistics between the four tiles of a 32x32 sample (net.hip `attach_fused_groupnorm`,
+    k_conv.hip `conv_epilogue_fgn`): the eager forward repeats bit for bit, the captured hipGraph - the epoch kernel that re-tags the
+    granules is part of it - replays the same bits, and the result agrees with the network that keeps every GroupNorm a separate pass."""
+    from ddmi_amd.unet import UNetModel
+    from helpers import named_state
+    cfg = dict(image_size=32, in_channels=16, model_channels=128, out_channels=16, attention_resolutions=[], num_res_blocks=1,
+               channel_mult=[1, 2], num_head_channels=32)
+    L = _lib.lib()
+    _lib.init_device(0)
+    x = torch.from_numpy(iw.normal("fgn_graph", "x", (8, 16, 32, 32))).to(DEV)
+    t = torch.tensor([3, 50, 7, 120, 999, 0, 410, 64], dtype=torch.int64, device=DEV)
+    outs = {}
+    try:
+        for mode in (0, 2):
+            _lib.check(L.ddmi_debug_gn_fuse(mode))    # read when the network is planned and at every launch
+            unet = UNetModel(**cfg, numerics="bf16", max_batch=8)
+            unet.load_state_dict(named_state("fgn_graph.unet", unet.manifest()))
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                ref = unet(x, t).clone()
+                fused = unet.async_status()
+                assert (fused > 0) == (mode == 2), (mode, fused)
+                assert torch.equal(unet(x, t), ref)
+                unet.set_graph(True)
+                out = torch.empty_like(ref)
+                for _ in range(4):   # capture, then three replays
+                    unet(x, t, out=out)
+                side.synchronize()
+                assert torch.equal(out, ref), mode
+                unet.async_status()      # no hand-off timed out
+                unet.set_graph(False)
+            outs[mode] = ref.float().cpu()
+    finally:
+        L.ddmi_debug_gn_fuse(-1)
+    assert torch.isfinite(outs[2]).all()
+    assert rel_l2(outs[2], outs[0]) < 1e-2   # the fused form normalises the fp32 accumulators, the pass their bf16 rounding
