@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64 * NW, 1) mlp3d_v2_kernel(Mlp3dK a) {
       q[e] = (bf16_t)lo[e];
       q[4 + e] = (bf16_t)hi[e];
     }
-    if (!(FC2_ABL & 16)) *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0 + 32 * pr) = q;
+    *reinterpret_cast<bf16x8*>(Xout + row * FC2_XP + ch0 + 32 * pr) = q;
   };
   // hidden activation: relu(acc + bias) -> Xout (rectified: fc_1 reads it as is)
   auto store_hidden = [&](bf16_t* Xout) {
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(64 * NW, 1) mlp3d_v2_kernel(Mlp3dK a) {
   M3V2_BLOCK(X1, X0, 64, 6, 7, 8, 3, 4, -1, m3_off(9), 8);     // block 3: [x2 | f2] -> X0
   M3V2_BLOCK(X0, X1, 0, 9, 10, -1, 5, 6, -1, 0, 0);            // block 4: identity shortcut -> X1
 #undef M3V2_BLOCK
-  // ================= net_out: 256 -> 1 (rows padded to 16): 16-point fragments, PR per wave ==========================
+  // ================= net_out: 256 -> 1 (rows padded to 16): 16-point fragments, NOUT per wave ========================
 #pragma unroll
   for (int i = 0; i < NOUT; ++i) {
     const int pf = NOUT * wave + i;

@@ -13,7 +13,7 @@
 
 // timing-only ablation builds (tools/build_variant.sh NAME k_mlp3d.hip -DFC2_ABL=<bits>; WRONG results on purpose): bit 0 no relu on the
 // fragments, bit 1 no weight fetch inside the k-loop, bit 2 no activation reads inside the k-loop, bit 3 (k_mlp3d.hip) no feature gather
-// after the first, bit 4 (k_mlp3d.hip) no epilogue stores
+// after the first.  (Dropping the epilogue's LDS stores is not a usable ablation: the compiler then removes the passes that feed them.)
 #ifndef FC2_ABL
 #define FC2_ABL 0
 #endif
