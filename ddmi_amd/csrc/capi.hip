@@ -648,6 +648,21 @@ int ddmi_debug_gn_fuse(int mode) {
   return DDMI_OK;
 }
 
+int ddmi_debug_conv_gn_fusable(int B, int Cin, int H, int W, int Cout, int any_batch, int* fusable, int* tiles_per_sample) {
+  DDMI_REQUIRE(fusable && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "debug_conv_gn_fusable: bad arguments");
+  static float dummy[4];   // the predicate only asks whether the pointers are there
+  ConvArgs a{};
+  a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W; a.Cin = Cin; a.Cout = Cout;
+  a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.out_scale = 1.f; a.splitk = 1;
+  a.x = a.w = a.y = dummy; a.bias = dummy;
+  a.gn_gamma = a.gn_beta = dummy; a.gn_part = dummy; a.gn_sync = (unsigned*)dummy;
+  a.gn_any_batch = any_batch ? 1 : 0;
+  a.cfg = (Cout % 224 == 0 ? 19 : 20) + 1;   // the halo tile Net::run gives a launch without a tuned plan
+  *fusable = conv_fgn_ok(a, DT_BF16) ? 1 : 0;
+  if (tiles_per_sample) *tiles_per_sample = (H * W) / 256;
+  return DDMI_OK;
+}
+
 // conv3x3 (+ bias + per-sample embedding row) -> GroupNorm32 [+ SiLU] as the ResBlock builds the pair (openaimodel.py:261-270), through the
 // network executor: NCHW in -> OP_CONV -> OP_GN -> NCHW out.  `iters` runs of the same net (the fused form's cross-workgroup hand-off under
 // repetition); *fused_used = fused launches of the last run

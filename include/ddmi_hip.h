@@ -368,6 +368,12 @@ int ddmi_debug_attn_fused(int mode);
 int ddmi_op_conv_gn(const float* x, const float* w, const float* bias, const float* emb, const float* gamma, const float* beta, float* y,
                     int B, int Cin, int H, int W, int Cout, float eps, int silu, int numerics, int iters, int* fused_used);
 int ddmi_debug_gn_fuse(int mode);
+/* HOST-ONLY (no device needed): would the pair above - a bf16 3x3 / stride-1 convolution [B,Cin,H,W] -> Cout followed by GroupNorm(32) - run
+ * with the GroupNorm in the convolution's epilogue on the halo kernel without split-K (k_conv.hip conv_fgn_ok: whole groups per channel
+ * tile, whole 256-row tiles per sample, at most 16 workgroups waiting for each other, statistics exchanged only at batches that are
+ * multiples of 8 unless any_batch)?  *fusable = 0 / 1; *tiles_per_sample (may be null) = H W / 256, the workgroups of one channel tile
+ * that exchange partial statistics (1 = none). */
+int ddmi_debug_conv_gn_fusable(int B, int Cin, int H, int W, int Cout, int any_batch, int* fusable, int* tiles_per_sample);
 /* The ResBlock's skip_connection on a channel-concatenated input (openaimodel.py:787 `th.cat([h, hs.pop()], dim=1)`, :272-275): y =
  * conv1x1([x1 | x2]) + bias with x1 [B,C1,H,W], x2 [B,C2,H,W], w [Cout, C1 + C2] -> y [B,Cout,H,W].  In bf16 mode, for Cout a multiple
  * of 224 or 128, it is ONE launch that reads both tensors in place (k_conv.hip, CAT instantiation of the persistent 1x1 kernel;

@@ -273,3 +273,32 @@ def test_op_package_imports_resolve_without_a_gpu():
                  lambda: upfirdn2d_op.upfirdn2d(x, k, 1, 1, 1, 1, 0, 0, 0, 0)):
         with pytest.raises(NotImplementedError, match="generation path"):
             call()
+
+
+def test_fused_groupnorm_shape_rules_without_a_gpu():
+    """k_conv.hip `conv_fgn_ok` through the host-only `ddmi_debug_conv_gn_fusable`: which conv3x3 -> GroupNorm32 pairs leave the convolution's
+    epilogue normalised.  The AFHQ levels that do (64x64 / 32x32 / 16x16 at 224 k channels), the shapes that must keep the pass - groups that
+    straddle a channel tile (8x8: 1344 / 32 = 42), tiles that straddle samples (8x8), the D2C-VAE decoder's 512 channels at 64x64 (16 x 4 = 64
+    workgroups waiting for each other: more than an XCD holds - the first bench run sat in its bounded polls) - and the batch rule (cohorts that
+    exchange statistics only at batches that are multiples of 8; a 16x16 launch exchanges nothing and fuses at any batch)."""
+    import ctypes as C
+    from ddmi_amd import _lib
+    L = _lib.lib()
+
+    def fusable(B, Cin, H, W, Cout, any_batch=0):
+        f, tps = C.c_int(-1), C.c_int(-1)
+        _lib.check(L.ddmi_debug_conv_gn_fusable(B, Cin, H, W, Cout, any_batch, C.byref(f), C.byref(tps)))
+        return f.value, tps.value
+
+    assert fusable(512, 224, 64, 64, 224) == (1, 16)
+    assert fusable(512, 448, 32, 32, 448) == (1, 4)
+    assert fusable(512, 672, 16, 16, 896) == (1, 1)
+    assert fusable(512, 1344, 8, 8, 1344)[0] == 0          # 42 channels per group do not divide a 224-wide tile; four samples per tile
+    assert fusable(512, 512, 64, 64, 512)[0] == 0           # 16 tiles x 4 channel tiles wait for each other: over the bound of 16
+    assert fusable(512, 256, 64, 64, 256)[0] == 0           # 16 x 2 channel tiles of 128: over the bound as well
+    assert fusable(512, 128, 32, 32, 256)[0] == 1           # 4 tiles x 2 channel tiles of 128, 16 groups of 8 channels per tile
+    assert fusable(512, 128, 32, 32, 384)[0] == 0           # 12 channels per group do not divide a 128-wide tile
+    assert fusable(250, 224, 64, 64, 224)[0] == 0 and fusable(250, 224, 64, 64, 224, any_batch=1)[0] == 1
+    assert fusable(9, 64, 16, 16, 896)[0] == 1              # one tile per sample: nothing to exchange, any batch
+    assert fusable(8, 64, 24, 24, 224)[0] == 0              # 576 pixels: not whole 256-row tiles
+    assert fusable(8, 64, 64, 64, 100)[0] == 0              # 100 channels: no 32 groups
