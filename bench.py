@@ -758,6 +758,59 @@ def cpu_baseline_train():
             "forward_backward_s": t_fb, "adamw_s": t_opt}
 
 
+def run_dry(args, rank, local_rank, world, dev):
+    """`--dry-run`: the RANK PLUMBING of this script without a GPU - launcher -> torchrun environment -> init_process_group -> the shared
+    conv-plan broadcast -> per-rank disjoint sample indices -> all-gather of the finished samples -> barrier + max-over-ranks timing ->
+    ONE JSON line from rank 0 - on CPU tensors over `gloo`, with a stub step that fabricates [B,3,8,8] "images" from each chain's seed
+    (ddmi_amd.dist.sample_seed).  What an 8-GPU run executes around the kernels, runnable (and tested: tests/test_dist_gloo.py) where
+    there is no GPU at all; it measures nothing."""
+    import torch
+    from ddmi_amd import dist as D
+    B = args.batch or 4
+    tuned = {}
+
+    def stub_finalize():   # what pipeline.finalize does with the plan file: rank 0 writes the shapes it tuned, the others read them back
+        path = os.environ.get("DDMI_TUNE_FILE")
+        if path and rank == 0:
+            with open(path, "w") as f:
+                f.write("v 0\n# dry-run plans of rank 0\n")
+        tuned["text"] = open(path).read() if path and os.path.exists(path) else None
+    plans = D.finalize_with_shared_plans(stub_finalize, rank, world)
+    if world > 1:
+        assert tuned["text"] and "rank 0" in tuned["text"], "the shared conv-plan broadcast did not reach this rank"
+
+    def one_step(step_idx):
+        idx = [(step_idx * world + rank) * B + j for j in range(B)]   # the same disjoint global indices run_afhq hands out
+        img = torch.stack([torch.randn((3, 8, 8), generator=torch.Generator().manual_seed(D.sample_seed(args.seed, i) % (2 ** 63)))
+                           for i in idx]).to(dev)
+        return idx, D.all_gather_samples(img, world)
+
+    for w in range(args.warmup):
+        one_step(w)
+    D.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        idx, out = one_step(args.warmup + k)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape == (world * B, 3, 8, 8)
+    # rank r's rows sit at [r B, (r + 1) B) of the gather and are the chains of ITS indices: re-derive rank (world - 1)'s last chain here
+    last = (((args.warmup + args.steps - 1) * world + (world - 1)) * B + B - 1)
+    want = torch.randn((3, 8, 8), generator=torch.Generator().manual_seed(D.sample_seed(args.seed, last) % (2 ** 63)))
+    assert torch.equal(out[-1].cpu(), want), "all-gather rows are not in rank-major order"
+    nranks = D.group_size(dev)
+    if rank != 0:
+        return None
+    return {"metric": "samples/sec (whole node) at 256x256 image, 250-step DDPM + INR decode", "value": args.steps * world * B / elapsed,
+            "unit": "samples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+            "dry_run": True, "backend": args.backend or "gloo",
+            "config": {"workload": "DRY RUN: rank plumbing only (stub step, CPU tensors) - not a measurement", "batch_per_gpu": B,
+                       "global_batch": world * B, "parallelism": f"sample-parallel x{world}",
+                       "conv_plans": "shared (rank 0's plans broadcast)" if world > 1 else plans},
+            "nccl_ranks": nranks}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -775,7 +828,12 @@ def main():
     ap.add_argument("--seed", type=int, default=777)
     ap.add_argument("--rng", default="philox", choices=["philox", "torch", "reference"],
                     help="per-chain noise: in-kernel Philox streams (default), one torch generator per chain, or the reference's seeded CPU draws")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend (default: nccl = RCCL on a GPU box)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run the launcher / process-group / plan-broadcast / all-gather / timing plumbing on CPU tensors over gloo with a stub step")
     args = ap.parse_args()
+    if args.dry_run and args.backend is None:
+        args.backend = "gloo"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no
@@ -786,8 +844,17 @@ def main():
     import torch
     from ddmi_amd import dist as D
 
-    rank, local_rank, world = D.init_process_group()
+    rank, local_rank, world = D.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        line = run_dry(args, rank, local_rank, world, "cpu")
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
