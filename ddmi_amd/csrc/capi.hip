@@ -98,7 +98,12 @@ int ddmi_unet_forward(ddmi_unet* h, const float* x, const int64_t* t, float* eps
 int ddmi_unet_async_status(ddmi_unet* h, int* fused_gn_launches) {
   DDMI_REQUIRE(h, "null handle");
   if (fused_gn_launches) *fused_gn_launches = h->u.net.fgn_launches;
-  return h->u.net.async_status();
+  return unet_async_status(h->u);
+}
+int ddmi_unet_debug_inject_gn_timeout(ddmi_unet* h) {
+  DDMI_REQUIRE(h, "null handle");
+  h->u.net.debug_inject_fgn_timeout();
+  return DDMI_OK;
 }
 int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled) {
   DDMI_REQUIRE(h, "null handle");
@@ -656,7 +661,8 @@ int ddmi_debug_conv_gn_fusable(int B, int Cin, int H, int W, int Cout, int any_b
   a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.out_scale = 1.f; a.splitk = 1;
   a.x = a.w = a.y = dummy; a.bias = dummy;
   a.gn_gamma = a.gn_beta = dummy; a.gn_part = dummy; a.gn_sync = (unsigned*)dummy;
-  a.gn_any_batch = any_batch ? 1 : 0;
+  a.gn_any_batch = (any_batch & 1) ? 1 : 0;
+  a.gn_no_handoff = (any_batch & 2) ? 1 : 0;   // bit 1: a network whose owner never looks at the hand-off's flag (the decoders)
   a.cfg = (Cout % 224 == 0 ? 19 : 20) + 1;   // the halo tile Net::run gives a launch without a tuned plan
   *fusable = conv_fgn_ok(a, DT_BF16) ? 1 : 0;
   if (tiles_per_sample) *tiles_per_sample = (H * W) / 256;
@@ -695,6 +701,7 @@ int ddmi_op_conv_gn(const float* x, const float* w, const float* bias, const flo
   ex.ext = 1;
   ex.out_nchw = 1;
   n.ops.push_back(ex);
+  n.fgn_handoff = true;   // the flag is checked right below
   DDMI_TRY(n.plan());
   void* ext[2] = {(void*)x, (void*)y};
   for (int i = 0; i < iters; ++i) DDMI_TRY(n.run(B, ext, emb, Cout, 0));

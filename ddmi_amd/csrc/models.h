@@ -16,7 +16,9 @@ struct UNet {
   // optional hipGraph replay of the whole forward (ddmi_unet_set_graph): ~900 launches of a small-batch forward cost
   // more host + dispatch time than GPU time; a captured graph is keyed by (B, x, t, out, uniform_t) - a sampling loop
   // ping-pongs between two x buffers, so two graphs serve it
-  struct GraphEntry { int B; const void* x; const void* t; void* out; bool uniform; hipGraphExec_t exec; };
+  // ... and by whether the fused-GroupNorm kernels were the ones captured (`fuse`: Net::fgn_fusing() x the global mode): a graph captured
+  // with them is never replayed after the fusion went off (ddmi_debug_gn_fuse, or a hand-off timeout: unet_async_status drops them all)
+  struct GraphEntry { int B; const void* x; const void* t; void* out; bool uniform; int fuse; hipGraphExec_t exec; };
   bool use_graph = false;
   std::vector<GraphEntry> graphs;
   ~UNet();
@@ -47,6 +49,9 @@ int unet_time_embed_setup(UNet& u);   // time_embed.* + sinusoid frequencies
 int unet_finish(UNet& u);             // concatenated emb projections, scratch, plan()
 int unet3_finalize(UNet& u);          // UNetModel_Triplane topology (models_video.hip)
 int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s);
+// Net::async_status() of the UNet's network (SYNCHRONISES); on a hand-off timeout the captured graphs are destroyed too (they hold the
+// fused kernels) - the next forward runs, and captures, the separate GroupNorm passes
+int unet_async_status(UNet& u);
 
 struct Decoder2d {
   ddmi_decoder2d_cfg cfg{};

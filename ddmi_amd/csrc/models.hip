@@ -391,6 +391,7 @@ int unet_finish(UNet& u) {
   size_t fb = (size_t)c.max_batch * (mc + 2 * u.emb_dim + u.emb_total) * sizeof(float);
   HIP_TRY(hipMalloc((void**)&u.tbuf, fb));
   n.dev_allocs.push_back(u.tbuf);
+  n.fgn_handoff = true;   // this handle's owner sees the hand-off's flag: unet_forward peeks it, ddmi_unet_async_status checks it
   return n.plan();
 }
 
@@ -400,15 +401,28 @@ UNet::~UNet() {
 
 static int unet_forward_launch(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s);
 
+int unet_async_status(UNet& u) {
+  const int rc = u.net.async_status();
+  if (rc != DDMI_OK) {
+    for (auto& g : u.graphs) (void)hipGraphExecDestroy(g.exec);
+    u.graphs.clear();
+  }
+  return rc;
+}
+
 int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s) {
   Net& n = u.net;
   if (!n.finalized) return ddmi_fail(DDMI_ERR_STATE, "unet not finalized");
   DDMI_REQUIRE(x && t && eps_out, "unet_forward: null pointer");
   DDMI_REQUIRE(B >= 1 && B <= n.max_batch, "unet_forward: batch exceeds max_batch");
+  // a hand-off of an EARLIER forward has flagged a timeout (host-mapped word: no synchronisation to look at it): this call reports it
+  // instead of running - every forward since the last ddmi_unet_async_status may be invalid; the fusion is off afterwards
+  if (n.async_error_pending()) return unet_async_status(u);
   prof_begin_forward();
   if (!u.use_graph || prof_active()) return unet_forward_launch(u, x, t, eps_out, B, s);
+  const int fuse = n.fgn_fusing() ? net_gn_fuse_mode() : 0;
   for (auto& g : u.graphs)
-    if (g.B == B && g.x == x && g.t == t && g.out == eps_out && g.uniform == u.uniform_t) {
+    if (g.B == B && g.x == x && g.t == t && g.out == eps_out && g.uniform == u.uniform_t && g.fuse == fuse) {
       HIP_TRY(hipGraphLaunch(g.exec, s));
       return DDMI_OK;
     }
@@ -444,7 +458,7 @@ int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int 
     return DDMI_OK;
   }
   if (getenv("DDMI_GRAPH_DEBUG")) fprintf(stderr, "ddmi: captured a forward graph (B=%d)\n", B);
-  u.graphs.push_back(UNet::GraphEntry{B, x, t, eps_out, u.uniform_t, exec});
+  u.graphs.push_back(UNet::GraphEntry{B, x, t, eps_out, u.uniform_t, fuse, exec});
   return DDMI_OK;  // the plain run above already produced this call's result
 }
 

@@ -12,6 +12,7 @@
 
 // diagnostics: producer-side GroupNorm for networks planned and run afterwards: 0 off, 1 on, -1 = the DDMI_GN_FUSE environment (net.hip)
 void net_gn_fuse_override(int mode);
+int net_gn_fuse_mode();   // the effective mode: 0 never, 1 where the launch runs on the halo kernel anyway, 2 wherever the shape allows
 
 struct HostTensor {
   std::vector<float> data;
@@ -169,8 +170,20 @@ struct Net {
   float* fgn_part = nullptr;      // granule scratch of the producer-side GroupNorm (CONV_FGN_PART_FLOATS), shared by all such launches
   unsigned* fgn_sync = nullptr;   // {launch epoch, error flag, -, -}
   int fgn_launches = 0;           // fused launches of the last run() (diagnostics)
-  // 0 = fine; DDMI_ERR_STATE when a fused GroupNorm launch timed out waiting for a partner tile.  SYNCHRONISES the device.
+  unsigned* fgn_flag_host = nullptr;   // host-mapped copy of fgn_sync[1]: a timed-out hand-off sets both, the host peeks this one for free
+  bool fgn_enabled = true;        // per network: async_status() clears it for good when a hand-off of THIS network timed out
+  // the cross-workgroup hand-off (shapes with more than one 256-row tile per sample) only for networks whose owner looks at the flag - the
+  // UNet handles (unet_forward peeks, ddmi_unet_async_status checks) - and only on the device its progress argument was made for (plan());
+  // every other network fuses the 16 x 16 shapes only, whose statistics are complete inside one tile (round-5 advisor)
+  bool fgn_handoff = false;
+  int fgn_timeouts = 0;           // hand-off timeouts seen by async_status() (each one switched the fusion off)
+  bool fgn_fusing() const { return fgn_part && fgn_enabled && net_gn_fuse_mode() != 0; }
+  // a hand-off has flagged a timeout since the last async_status(): a volatile read of host memory, no synchronisation
+  bool async_error_pending() const { return fgn_flag_host && *(volatile unsigned*)fgn_flag_host != 0u; }
+  // 0 = fine; DDMI_ERR_STATE when a fused GroupNorm launch timed out waiting for a partner tile: the results since the last call are
+  // invalid and the fusion is OFF for this network from here on (the caller runs again).  SYNCHRONISES the device.
   int async_status();
+  void debug_inject_fgn_timeout();   // tests: what a timed-out workgroup does to the two flags
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }
   size_t tbytes(int id, int B) const;

@@ -19,6 +19,7 @@ const char* ddmi_error_cstr() { return g_last_error.c_str(); }
 Net::~Net() {
   for (void* p : dev_allocs)
     if (p) (void)hipFree(p);
+  if (fgn_flag_host) (void)hipHostFree(fgn_flag_host);
 }
 
 int Net::add_host(const char* key, const float* data, const int64_t* shape, int ndim) {
@@ -440,6 +441,7 @@ static int gn_fuse_mode() {
   return env < 0 ? 1 : env;
 }
 static bool gn_fuse_enabled() { return gn_fuse_mode() != 0; }
+int net_gn_fuse_mode() { return gn_fuse_mode(); }
 void Net::attach_fused_groupnorm() {
   if (dt != DT_BF16 || x3 || !gn_fuse_enabled()) return;
   std::vector<int> producer(tensors.size(), -1), readers(tensors.size(), 0);
@@ -470,12 +472,23 @@ int Net::async_status() {
   unsigned w[CONV_FGN_SYNC_WORDS] = {0, 0, 0, 0};
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(w, fgn_sync, sizeof w, hipMemcpyDeviceToHost));
-  if (w[1]) {
+  if (w[1] || async_error_pending()) {
     HIP_TRY(hipMemset(fgn_sync + 1, 0, sizeof(unsigned)));
+    if (fgn_flag_host) *(volatile unsigned*)fgn_flag_host = 0u;
+    fgn_enabled = false;   // this network keeps the separate pass from here on: whoever runs it again gets valid results
+    ++fgn_timeouts;
     return ddmi_fail(DDMI_ERR_STATE, "a fused GroupNorm launch timed out waiting for a partner tile (workgroup dispatch order not as "
-                                     "assumed): results of that run are invalid; set DDMI_GN_FUSE=0");
+                                     "assumed): the results of that run are invalid; the fusion is now off for this network - run again");
   }
   return DDMI_OK;
+}
+
+void Net::debug_inject_fgn_timeout() {
+  if (!fgn_sync) return;
+  const unsigned one = 1u;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(fgn_sync + 1, &one, sizeof one, hipMemcpyHostToDevice);
+  if (fgn_flag_host) *(volatile unsigned*)fgn_flag_host = 1u;
 }
 
 int Net::plan() {
@@ -566,6 +579,15 @@ int Net::plan() {
     HIP_TRY(hipMalloc((void**)&fgn_sync, CONV_FGN_SYNC_WORDS * sizeof(unsigned)));
     dev_allocs.push_back(fgn_sync);
     HIP_TRY(hipMemset(fgn_sync, 0, CONV_FGN_SYNC_WORDS * sizeof(unsigned)));
+    HIP_TRY(hipHostMalloc((void**)&fgn_flag_host, 64, hipHostMallocMapped));
+    *(volatile unsigned*)fgn_flag_host = 0u;
+    // the hand-off's progress argument (k_conv.hip) counts on 8 XCDs of 32 CUs with one workgroup per CU: any other device (another
+    // gfx9 part, a CU-masked or partitioned MI355X) keeps the fusion to the shapes that need no hand-off
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (!(prop.multiProcessorCount == 256 && strncmp(prop.gcnArchName, "gfx950", 6) == 0)) fgn_handoff = false;
   }
   // split-K slabs: worst case over batch sizes
   splitk_bytes = 0;
@@ -822,12 +844,13 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
           DDMI_TRY(launch_splitk_finish(a, DT_F32, s));
           break;
         }
-        if (o.fgn_gn >= 0 && fgn_part && gn_fuse_enabled()) {   // producer-side GroupNorm where this launch qualifies
+        if (o.fgn_gn >= 0 && fgn_fusing()) {   // producer-side GroupNorm where this launch qualifies
           const Op& gop = ops[o.fgn_gn];
           const GNW& g = gns[gop.gn];
           ConvArgs f = a;
           f.gn_gamma = g.gamma; f.gn_beta = g.beta; f.gn_eps = gop.eps; f.gn_silu = gop.silu;
-          f.gn_part = fgn_part; f.gn_sync = fgn_sync;
+          f.gn_part = fgn_part; f.gn_sync = fgn_sync; f.gn_flag_host = fgn_flag_host;
+          f.gn_no_handoff = fgn_handoff ? 0 : 1;
           f.gn_any_batch = gn_fuse_mode() == 2;
           f.y = tptr(gop.out);
           if (f.cfg == 0 || gn_fuse_mode() == 2) {   // no tuned tile for this shape (or forced): the halo kernel is the 3x3 kernel of choice

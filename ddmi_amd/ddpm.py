@@ -283,15 +283,31 @@ class DDPM:
         return img
 
     def sample(self, shape, cond=None, return_intermediates=False, noise=None, enable_mask=False, **kw):
-        """ddpm.py:371-381: DDIM when sampling_timesteps < timesteps, ancestral loop otherwise."""
-        if self.is_ddim_sampling:
-            out = self.ddim_sample(shape, cond, noise=noise, enable_mask=enable_mask, **kw)
-        else:
-            out = self.p_sample_loop(shape, cond, return_intermediates=return_intermediates, noise=noise,
-                                     enable_mask=enable_mask, **kw)
-        # deferred errors of the asynchronous UNet forwards (a fused GroupNorm launch that timed out waiting for a partner tile is
-        # flagged, not hung: unet.UNetModel.async_status) - checked once per chain batch; synchronises
-        status = getattr(self.model, "async_status", None)
-        if status is not None:
-            self.fused_gn_launches = status()
-        return out
+        """ddpm.py:371-381: DDIM when sampling_timesteps < timesteps, ancestral loop otherwise.
+
+        Deferred errors of the asynchronous UNet forwards are looked at once per chain batch (`model.async_status()`, at the point where
+        the chain is complete - it synchronises).  The one such error that exists - a fused GroupNorm hand-off of the bf16 UNet that timed
+        out waiting for a partner tile, flagged instead of hung - leaves the library with the fusion switched OFF for that handle (and
+        its captured graphs dropped); the chain is then sampled AGAIN, once, on the separate GroupNorm passes, so no batch is lost
+        (`gn_fuse_fallbacks` counts these; with `seeds`, `noise` / `step_noise` the re-run is the same sample, with a torch `generator` it
+        is a fresh draw)."""
+        def run():
+            if self.is_ddim_sampling:
+                out = self.ddim_sample(shape, cond, noise=noise, enable_mask=enable_mask, **kw)
+            else:
+                out = self.p_sample_loop(shape, cond, return_intermediates=return_intermediates, noise=noise,
+                                         enable_mask=enable_mask, **kw)
+            status = getattr(self.model, "async_status", None)
+            if status is not None:
+                self.fused_gn_launches = status()
+            return out
+        try:
+            return run()
+        except _lib.DdmiError as e:
+            if "fused GroupNorm" not in str(e):
+                raise
+            self.gn_fuse_fallbacks = getattr(self, "gn_fuse_fallbacks", 0) + 1
+            self.gn_fuse_fallback_message = str(e)
+            if hasattr(self.model, "set_uniform_t"):
+                self.model.set_uniform_t(False)   # (the loop was left in the middle)
+        return run()   # a second failure is the caller's

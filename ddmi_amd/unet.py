@@ -196,8 +196,11 @@ class UNetModel:
 
     def async_status(self):
         """Deferred errors of the asynchronous forwards (ddmi_unet_async_status; SYNCHRONISES the device): raises when a fused GroupNorm
-        launch of a bf16 network timed out waiting for a partner tile; returns how many convolutions of the last forward carried their
-        GroupNorm in the epilogue.  The sampling loops call it once per chain, at the point where they synchronise anyway."""
+        launch of a bf16 network timed out waiting for a partner tile - the forwards since the last call are invalid then, the library has
+        switched the fusion off for this handle and the caller runs them again (`DDPM.sample` does, once); returns how many convolutions
+        of the last forward carried their GroupNorm in the epilogue.  The sampling loops call it once per chain, at the point where they
+        synchronise anyway; a caller of `forward()` / `__call__` on its own calls it wherever it copies results to the host (if it never
+        does, the first `forward()` after a timeout raises the same error instead of running)."""
         n = C.c_int(0)
         if self._handle is not None:
             _lib.check(_lib.lib().ddmi_unet_async_status(self._handle, C.byref(n)))

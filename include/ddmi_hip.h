@@ -81,10 +81,15 @@ int ddmi_unet_set_uniform_t(ddmi_unet* h, int enabled);
 int ddmi_unet_set_graph(ddmi_unet* h, int enabled);
 /* Deferred errors of the asynchronous forwards (SYNCHRONISES the device): the producer-side GroupNorm of the bf16 networks (k_conv.hip
  * conv_epilogue_fgn: the ResBlock's out_layers norm leaves conv1's epilogue normalised; tiles of a sample exchange their partial
- * statistics in memory) bounds its wait for a partner tile and flags a timeout instead of hanging - DDMI_ERR_STATE then, the results
- * of that run are invalid (DDMI_GN_FUSE=0 / ddmi_debug_gn_fuse(0) keep the separate pass).  *fused_gn_launches (may be null): how
- * many convolutions of the last forward ran the fused epilogue. */
+ * statistics in memory) bounds its wait for a partner tile (50 ms) and flags a timeout instead of hanging.  DDMI_ERR_STATE then: the
+ * forwards since the last call are invalid, the fusion is switched OFF for this handle for good (captured graphs are dropped) and
+ * the caller runs them again - ddmi_amd/ddpm.py's samplers do, once.  A caller that never calls this still hears of a timeout: the
+ * first ddmi_unet_forward AFTER the flag went up (a host-mapped word, looked at without synchronising) returns the same error instead
+ * of running.  Call it wherever results are copied to the host.  *fused_gn_launches (may be null): how many convolutions of the last
+ * forward ran the fused epilogue.  (DDMI_GN_FUSE=0 / ddmi_debug_gn_fuse(0) keep the separate pass everywhere.) */
 int ddmi_unet_async_status(ddmi_unet* h, int* fused_gn_launches);
+/* tests: raises the hand-off's timeout flag of this handle as a timed-out workgroup would (device word + host-mapped word) */
+int ddmi_unet_debug_inject_gn_timeout(ddmi_unet* h);
 int ddmi_unet_destroy(ddmi_unet* h);
 /* bytes held by the handle: [0] packed weights, [1] activation arena, [2] split-K slabs */
 int ddmi_unet_memory(ddmi_unet* h, uint64_t out[3]);
@@ -372,7 +377,8 @@ int ddmi_debug_gn_fuse(int mode);
  * with the GroupNorm in the convolution's epilogue on the halo kernel without split-K (k_conv.hip conv_fgn_ok: whole groups per channel
  * tile, whole 256-row tiles per sample, at most 16 workgroups waiting for each other, statistics exchanged only at batches that are
  * multiples of 8 unless any_batch)?  *fusable = 0 / 1; *tiles_per_sample (may be null) = H W / 256, the workgroups of one channel tile
- * that exchange partial statistics (1 = none). */
+ * that exchange partial statistics (1 = none).  any_batch bit 1 (value 2): answer for a network WITHOUT the cross-workgroup hand-off (every
+ * network but the UNet handles', whose owner checks ddmi_unet_async_status): only tiles_per_sample == 1 shapes fuse there. */
 int ddmi_debug_conv_gn_fusable(int B, int Cin, int H, int W, int Cout, int any_batch, int* fusable, int* tiles_per_sample);
 /* The ResBlock's skip_connection on a channel-concatenated input (openaimodel.py:787 `th.cat([h, hs.pop()], dim=1)`, :272-275): y =
  * conv1x1([x1 | x2]) + bias with x1 [B,C1,H,W], x2 [B,C2,H,W], w [Cout, C1 + C2] -> y [B,Cout,H,W].  In bf16 mode, for Cout a multiple

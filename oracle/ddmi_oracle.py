@@ -27,6 +27,7 @@ bilinear plane sampling, weight modulation) is restated explicitly.
 from __future__ import annotations
 
 import math
+import time
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -677,6 +678,13 @@ SDPA_QUERY_CHUNK = 512   # queries per block once the score matrix of a head wou
 SDPA_FULL_SCORES = 1 << 26
 
 
+# TIMING ONLY (bench.py's bounded cpu_baseline for config 5): when "max_chunks" is set, a query-chunked evaluation stops after that many
+# chunks (the remaining output rows are zeros - the RESULT IS THEN WRONG) and the time spent in / the number of chunks of every such
+# loop are accumulated here, so that the caller can extrapolate the attention it sampled: rows are independent softmaxes, the cost is
+# linear in the chunks evaluated.  Never set by the tests.
+SDPA_SAMPLE = {"max_chunks": None, "seconds": 0.0, "done": 0, "total": 0}
+
+
 def sdpa_heads(q: Tensor, k: Tensor, v: Tensor, heads: int, q_chunk: Optional[int] = None) -> Tensor:
     """q, k, v [B, heads*d, N] with channel = head*d + j (ae:447-456): per head softmax(q k^T / sqrt(d)) v -> [B, heads*d, N].
     Every query row is its own softmax, so the rows are evaluated in blocks of `q_chunk` queries against ALL keys when the
@@ -690,9 +698,19 @@ def sdpa_heads(q: Tensor, k: Tensor, v: Tensor, heads: int, q_chunk: Optional[in
     if q_chunk is None:
         q_chunk = N if N * N <= SDPA_FULL_SCORES else SDPA_QUERY_CHUNK
     outs = []
-    for a in range(0, N, q_chunk):
+    limit = SDPA_SAMPLE["max_chunks"] if q_chunk < N else None
+    t_loop = time.perf_counter() if limit else 0.0
+    for i, a in enumerate(range(0, N, q_chunk)):
+        if limit and i >= limit:   # timing sample: the rest of the rows are not evaluated
+            outs.append(torch.zeros((B, heads, N - a, d), dtype=q.dtype))
+            break
         w = torch.softmax(torch.matmul(qh[:, :, a:a + q_chunk], kh) * (d ** -0.5), dim=-1)  # [B,H,q,Nk]
         outs.append(torch.matmul(w, vh))  # [B,H,q,d]
+    if limit:
+        total = -(-N // q_chunk)
+        SDPA_SAMPLE["seconds"] += time.perf_counter() - t_loop
+        SDPA_SAMPLE["done"] += min(limit, total)
+        SDPA_SAMPLE["total"] += total
     o = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
     return o.permute(0, 1, 3, 2).reshape(B, HD, N)
 
@@ -891,17 +909,24 @@ def triplane_features_concat(xy: Tensor, yt: Tensor, xt: Tensor, coords: Mapping
     return x.permute(0, 2, 1).reshape(-1, 3 * c)
 
 
-def mlp_video(p: State, coords: Mapping[str, Tensor], hdbf) -> Tensor:
-    """MLPVideo.forward mlp.py:128-157.  hdbf = (xy, yt, xt), each 3 planes coarse -> fine -> [B, out_ch, t, h, w]."""
+def mlp_video_rows(p: State, coords: Mapping[str, Tensor], hdbf) -> Tensor:
+    """The per-point part of MLPVideo.forward (mlp.py:128-155) -> [B * t * h * w (of `coords`), out_ch]; `coords` may cover fewer frames
+    than the planes do (bench.py times two frames' worth of points)."""
     xy, yt, xt = hdbf
-    b, _, h, w = xy[-1].shape
-    t = yt[-1].shape[2]
     f = [triplane_features_concat(xy[i], yt[i], xt[i], coords) for i in range(3)]
     x = resnet_block_fc(p, "net_res1.", f[0])
     x = resnet_block_fc(p, "net_res2.", torch.cat((x, f[1]), dim=1))
     x = resnet_block_fc(p, "net_res3.", torch.cat((x, f[2]), dim=1))
     x = resnet_block_fc(p, "net_res4.", x)
-    x = F.linear(F.leaky_relu(x, 0.2), p["net_out.weight"], p["net_out.bias"])
+    return F.linear(F.leaky_relu(x, 0.2), p["net_out.weight"], p["net_out.bias"])
+
+
+def mlp_video(p: State, coords: Mapping[str, Tensor], hdbf) -> Tensor:
+    """MLPVideo.forward mlp.py:128-157.  hdbf = (xy, yt, xt), each 3 planes coarse -> fine -> [B, out_ch, t, h, w]."""
+    xy, yt, xt = hdbf
+    b, _, h, w = xy[-1].shape
+    t = yt[-1].shape[2]
+    x = mlp_video_rows(p, coords, hdbf)
     oc = x.shape[-1]
     return x.reshape(b, -1, oc).permute(0, 2, 1).reshape(b, oc, t, h, w)
 

@@ -302,3 +302,8 @@ def test_fused_groupnorm_shape_rules_without_a_gpu():
     assert fusable(9, 64, 16, 16, 896)[0] == 1              # one tile per sample: nothing to exchange, any batch
     assert fusable(8, 64, 24, 24, 224)[0] == 0              # 576 pixels: not whole 256-row tiles
     assert fusable(8, 64, 64, 64, 100)[0] == 0              # 100 channels: no 32 groups
+    # any_batch bit 1: a network WITHOUT the cross-workgroup hand-off (the decoders - nobody looks at their timeout flag; round-5 advisor):
+    # only the shapes whose statistics are complete inside one tile fuse
+    assert fusable(512, 224, 64, 64, 224, any_batch=2)[0] == 0 and fusable(512, 448, 32, 32, 448, any_batch=2)[0] == 0
+    assert fusable(8, 512, 32, 32, 512)[0] == 1 and fusable(8, 512, 32, 32, 512, any_batch=2)[0] == 0   # the decoder conv the advisor named
+    assert fusable(512, 672, 16, 16, 896, any_batch=2) == (1, 1) and fusable(9, 64, 16, 16, 896, any_batch=3) == (1, 1)

@@ -6,7 +6,7 @@ O=gpurun_out/r6a
 mkdir -p $O
 python3 tools/bench_small_batch.py --batches 1,2,4,8,16 --json $O/small_batch.json > $O/small_batch.log 2>&1
 for B in 1 8; do
-  rocprofv3 --kernel-trace --stats -d $O/prof_b$B -o p -- python3 tools/bench_small_batch.py --batches $B --plain-only --iters 20 > $O/prof_b$B.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b$B -- python3 tools/bench_small_batch.py --batches $B --plain-only --iters 20 > $O/prof_b$B.log 2>&1
   f=$(find $O/prof_b$B -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $O/kernel_stats_b$B.csv
   rm -rf $O/prof_b$B
