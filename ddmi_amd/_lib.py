@@ -131,6 +131,9 @@ SYMBOLS = {
     "ddmi_op_attention_block": (_I, [_VP] * 8 + [_I] * 6 + [C.POINTER(_I)]),
     "ddmi_debug_attn_fused": (_I, [_I]),
     "ddmi_debug_gn_fuse": (_I, [_I]),
+    "ddmi_debug_small_batch": (_I, [_I]),
+    "ddmi_debug_small_gn_launches": (_I, [C.POINTER(_I)]),
+    "ddmi_op_groupnorm_small": (_I, [_VP] * 5 + [_I] * 4 + [_F, _I]),
     "ddmi_debug_conv_gn_fusable": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ddmi_op_conv1x1_cat": (_I, [_VP] * 5 + [_I] * 7 + [C.POINTER(_I)]),
     "ddmi_op_conv_gn": (_I, [_VP] * 7 + [_I] * 5 + [C.c_float] + [_I] * 3 + [C.POINTER(_I)]),

@@ -648,6 +648,38 @@ int ddmi_debug_halo_half(int mode) {
   return DDMI_OK;
 }
 
+int ddmi_debug_small_batch(int mode) {
+  net_small_batch_override(mode);
+  return DDMI_OK;
+}
+int ddmi_debug_small_gn_launches(int* count) {
+  DDMI_REQUIRE(count, "null argument");
+  *count = g_net_small_gn_launches;
+  return DDMI_OK;
+}
+
+// the one-launch GroupNorm of the small-batch regime (k_groupnorm.hip gn_small_kernel) on its own: GroupNorm32 [+ SiLU] of the channel
+// concatenation [x | x2] (x2 may be null), bf16
+int ddmi_op_groupnorm_small(const float* x, const float* x2, const float* gamma, const float* beta, float* y, int B, int C1, int C2, int HW,
+                            float eps, int silu) {
+  DDMI_REQUIRE(x && gamma && beta && y && B > 0 && C1 > 0 && C2 >= 0 && HW > 0 && (x2 != nullptr) == (C2 > 0), "op_groupnorm_small: bad arguments");
+  const int C = C1 + C2;
+  DDMI_REQUIRE(gn_small_ok(B, HW, C, x2 != nullptr), "op_groupnorm_small: shape not served by the one-launch kernel");
+  Scratch sc;
+  void *x1n, *x2n = nullptr, *yn;
+  DDMI_TRY(sc.get((size_t)B * C1 * HW * 2, &x1n));
+  if (x2) DDMI_TRY(sc.get((size_t)B * C2 * HW * 2, &x2n));
+  DDMI_TRY(sc.get((size_t)B * C * HW * 2, &yn));
+  DDMI_TRY(launch_nchw_to_nhwc(x, x1n, DT_BF16, B, C1, HW, 0));
+  if (x2) DDMI_TRY(launch_nchw_to_nhwc(x2, x2n, DT_BF16, B, C2, HW, 0));
+  GnSmallArgs a{};
+  a.x = x1n; a.x2 = x2n; a.C1 = C1; a.y = yn; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.B = B; a.HW = HW; a.C = C;
+  DDMI_TRY(launch_gn_small(a, 0));
+  DDMI_TRY(launch_nhwc_to_nchw(yn, DT_BF16, y, B, C, HW, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  return DDMI_OK;
+}
+
 int ddmi_debug_gn_fuse(int mode) {
   net_gn_fuse_override(mode);
   return DDMI_OK;

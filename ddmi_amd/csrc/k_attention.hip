@@ -1749,7 +1749,10 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
   }
   if (dt == DT_BF16 && a.vec_ok && a.d % 4 == 0 && a.d <= 128 && use_v2) {
     const bool big = N >= 128;
-    if (attention_res_ok(a, N)) {
+    // small-batch regime (net.h): the resident kernel is one workgroup per (sample, head) - 14 workgroups for a 32 x 32 AttentionBlock at
+    // B = 1, 40 us each; the tiled kernel below splits the queries of a head over workgroups
+    const bool few = net_small_batch_enabled() && a.B * a.heads < 128 && !a.lse;
+    if (attention_res_ok(a, N) && !few) {
       static const bool res16_off = getenv("DDMI_ATTN_RES16") && atoi(getenv("DDMI_ATTN_RES16")) == 0;   // diagnostics: the 16 x 16 x 32 form at d = 16
       if (a.d == 16 && N % 1024 == 0 && !res16_off) return launch_attention_res16(a, s);
       return a.d == 16 ? launch_attention_res<16>(a, s) : launch_attention_res<32>(a, s);

@@ -459,3 +459,145 @@ int launch_gn_apply_chstat(const void* x, void* y, const float* cs1, int rows1, 
   HIP_TRY(hipGetLastError());
   return DDMI_OK;
 }
+
+// =====================================================================================================
+// Small-batch GroupNorm: statistics + apply in ONE launch (kernels.h GnSmallArgs).  grid (32 groups, B); a workgroup owns the HW x cpg
+// elements of one (sample, group): element e = pixel * cpg + c, consecutive lanes on consecutive elements (runs of cpg bf16 = 14 .. 168
+// bytes per pixel: not the 16-byte vectors of the streaming passes above - at these sizes, a few MB per launch and L2-resident, the
+// launch floor is what is being removed, not bandwidth).  The thread's (at most NE) elements stay in REGISTERS between the statistics
+// and the apply: every load of the slice is issued back to back (the loop is fully unrolled - a rolled loop waits out one L2 round
+// trip per element: 30-100 us per launch as first written) and nothing is read twice.  All accesses are buffer instructions with
+// 32-bit element offsets (one VGPR per address: 32 values + 32 offsets per thread fit the 128 VGPRs of a 1024-thread workgroup; 64-bit
+// pointers spilled 439).  Statistics: per-thread fp32 sums of (v - K), K = the slice's first element (shifted data: no cancellation
+// when |mean| >> sigma), combined in fp64 in a fixed order (deterministic).
+// Measured and NOT kept (round 6): the same kernel reading the producing convolution's raw split-K slabs (it then WAS the splitk_finish
+// pass): with 32 workgroups per sample each slab walk is one dependent round trip and the 28-byte runs of a group pull whole 128-byte
+// lines - 55 us per launch at 64 x 64 where the coalesced finish launch + this kernel take 5 + 10.
+// =====================================================================================================
+struct GnSmallK {
+  GnSmallArgs a;
+  int cpg;
+};
+
+template <int NE, bool CAT>
+__global__ void __launch_bounds__(1024) gn_small_kernel(GnSmallK k) {
+  __shared__ double red[32];
+  __shared__ float mr[2];
+  __shared__ float ss[2 * 192];
+  const GnSmallArgs& a = k.a;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, T = blockDim.x;
+  const int cpg = k.cpg, HW = a.HW, C = a.C, n = HW * cpg;
+  const int C1 = CAT ? a.C1 : C, ld2 = C - C1;
+  const int c0 = g * cpg;
+  const int row0 = b * HW;
+  // one descriptor per tensor, based at THIS SAMPLE (offsets stay small)
+  auto rs = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7FFFFFFF, 0x00020000); };
+  const auto x_r = rs((const bf16_t*)a.x + (int64_t)row0 * C1);
+  const auto x2_r = rs(CAT ? (const bf16_t*)a.x2 + (int64_t)row0 * ld2 : nullptr);
+  const auto y_r = rs((bf16_t*)a.y + (int64_t)row0 * C);
+  auto ld16 = [](decltype(x_r) r, int elem) -> float {
+    const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(r, elem * 2, 0, 0);
+    return __uint_as_float((unsigned)u << 16);
+  };
+  auto st16 = [](decltype(x_r) r, int elem, float v) {
+    const bf16_t h = (bf16_t)v;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, elem * 2, 0, 0);
+  };
+  auto value = [&](int pix, int c) -> float {   // element (pixel, group channel c) of the sample
+    const int ca = c0 + c;
+    if (CAT && ca >= C1) return ld16(x2_r, pix * ld2 + (ca - C1));
+    return ld16(x_r, pix * C1 + ca);
+  };
+  const int dpix = T / cpg, dc = T - dpix * cpg;   // element stride T in (pixel, channel) steps
+  const int pix_t = tid / cpg, c_t = tid - pix_t * cpg;
+  float v[NE];
+  int off[NE];  // sample-relative element offset pixel * C + channel of v[i] in the C-wide output, -1 past the slice
+  {
+    int pix = pix_t, c = c_t;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const bool in = tid + i * T < n;
+      off[i] = in ? pix * C + c0 + c : -1;
+      v[i] = in ? value(pix, c) : 0.f;
+      pix += dpix; c += dc;
+      if (c >= cpg) { c -= cpg; ++pix; }
+    }
+  }
+  const float K = value(0, 0);   // the shift of the statistics
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const float d = off[i] >= 0 ? v[i] - K : 0.f;
+    s1 += d;
+    s2 = fmaf(d, d, s2);
+  }
+  {
+    double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      d1 += __shfl_xor(d1, o);
+      d2 += __shfl_xor(d2, o);
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = d1; red[16 + (tid >> 6)] = d2; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double d1 = 0.0, d2 = 0.0;
+    for (int w = 0; w < ((T + 63) >> 6); ++w) { d1 += red[w]; d2 += red[16 + w]; }   // wave order: deterministic
+    const double m = d1 / n;
+    double var = d2 / n - m * m;
+    if (var < 0) var = 0;
+    mr[0] = (float)((double)K + m);
+    mr[1] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  if (tid < cpg) {
+    const float sc = mr[1] * a.gamma[c0 + tid];
+    ss[2 * tid] = sc;
+    ss[2 * tid + 1] = a.beta[c0 + tid] - mr[0] * sc;
+  }
+  __syncthreads();
+  // ---- normalise [+ SiLU], round once, store
+  int c = c_t;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    if (off[i] >= 0) {
+      float q = fmaf(v[i], ss[2 * c], ss[2 * c + 1]);
+      if (a.silu) q = silu_fast(q);
+      st16(y_r, off[i], q);
+    }
+    c += dc;
+    if (c >= cpg) c -= cpg;
+  }
+}
+
+// a (sample, group) slice stays in the registers of one 1024-thread workgroup: 32 elements per thread (16 for a two-source input: 32 spill)
+bool gn_small_ok(int B, int HW, int C, bool two_sources) {
+  if (C % GN_GROUPS || B < 1 || HW < 1) return false;
+  const int cpg = C / GN_GROUPS;
+  return cpg <= 192 && (int64_t)HW * cpg <= (two_sources ? 16384 : 32768) && (int64_t)B * GN_GROUPS <= 1024 &&
+         (int64_t)B * HW * C < ((int64_t)1 << 30);
+}
+
+int launch_gn_small(const GnSmallArgs& a, hipStream_t s) {
+  DDMI_REQUIRE(a.x && a.y && a.gamma && a.beta && gn_small_ok(a.B, a.HW, a.C, a.x2 != nullptr), "groupnorm (small batch): shape not served");
+  DDMI_REQUIRE(!a.x2 || (a.C1 > 0 && a.C1 < a.C), "groupnorm (small batch): bad concat boundary");
+  GnSmallK k{a, a.C / GN_GROUPS};
+  const int n = a.HW * k.cpg;
+  const int threads = std::min(1024, std::max(64, cdiv(n, 64) * 64));
+  const int per = cdiv(n, threads);
+  PROF_SCOPE("gn_small", 0, (double)a.B * a.HW * a.C * 4.0, s);
+  const dim3 grid(GN_GROUPS, a.B), block(threads);
+  if (a.x2) {
+    if (per <= 4) hipLaunchKernelGGL((gn_small_kernel<4, true>), grid, block, 0, s, k);
+    else if (per <= 8) hipLaunchKernelGGL((gn_small_kernel<8, true>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((gn_small_kernel<16, true>), grid, block, 0, s, k);
+  } else {
+    if (per <= 4) hipLaunchKernelGGL((gn_small_kernel<4, false>), grid, block, 0, s, k);
+    else if (per <= 8) hipLaunchKernelGGL((gn_small_kernel<8, false>), grid, block, 0, s, k);
+    else if (per <= 16) hipLaunchKernelGGL((gn_small_kernel<16, false>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((gn_small_kernel<32, false>), grid, block, 0, s, k);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMI_OK;
+}

@@ -72,6 +72,27 @@ int launch_gn_apply(const void* x, void* y, int dt, const double* stats, const f
                     const void* x2 = nullptr, int C1 = 0, int x3_out = 0,    // x3_out: fp32 in, [xh | xl | xh] bf16 image out (bf16x3 numerics)
                     int frag_out = 0);   // bf16: output in MFMA B-fragment order [16 tokens][32 channels][lane][8] for k_attnblock.hip
 
+bool net_small_batch_enabled();   // net.hip: the small-batch regime's switch (DDMI_SMALL_BATCH / ddmi_debug_small_batch)
+// Small-batch GroupNorm32 [+ SiLU] as ONE launch (bf16 networks, B <= 16 or so): a workgroup per (sample, group) takes the statistics
+// and applies them - where the two-launch form (grid = pixel splits x samples) spends two ~5 us launch floors and, at B = 1, runs on 64
+// workgroups that wait for each other through the launch boundary.  The input is a bf16 NHWC tensor, optionally the channel
+// concatenation [x | x2] read in place.
+struct GnSmallArgs {
+  const void* x;        // bf16 [B, HW, C1 or C]
+  const void* x2;       // bf16 [B, HW, C - C1] or null
+  int C1;
+  void* y;              // bf16 [B, HW, C]
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int silu;
+  int B, HW, C;
+};
+// whether launch_gn_small serves the shape: whole groups, a (sample, group) slice that fits one workgroup's registers (32 Ki elements;
+// 16 Ki for a two-source input), at most 1024 workgroups
+bool gn_small_ok(int B, int HW, int C, bool two_sources);
+int launch_gn_small(const GnSmallArgs& a, hipStream_t s);
+
 // ---- implicit-GEMM convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 upsample) ------
 struct ConvArgs {
   const void* x;      // [B, Hin, Win, Cin]   NHWC, dtype dt

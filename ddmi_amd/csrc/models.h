@@ -39,7 +39,7 @@ int make_vae_resblock(Net& n, const std::string& pre, int cin, int cout, ResW* w
 int emit_resblock(Net& n, const ResW& w, int x, int* out);
 // n_tokens > 0: the block only ever runs on H W = n_tokens (lets a fused block skip the separate qkv convolution's weights)
 int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w, int n_tokens = 0);
-bool attnblock_fused_enabled(int n_tokens);
+bool attnblock_fused_enabled(int n_tokens, int max_samples = 0);   // max_samples > 0: the small-batch rule applies (net.h)
 void attnblock_fused_override(int mode);      // -1: environment, 0: never, 1: wherever the shape allows (networks built afterwards)
 //   // DDMI_ATTN_FUSED (0 = off) / DDMI_ATTN_FUSED_N (comma list of token counts)
 int make_qkv_attn(Net& n, const std::string& pre, int ch, int heads, bool expand, AttnW* w);

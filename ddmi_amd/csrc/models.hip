@@ -113,10 +113,15 @@ static int build_resblock(UNet& u, const std::string& pre, int x, int cout, int*
 // with those token counts.
 static int g_attn_fused_override = -1;   // ddmi_debug_attn_fused: -1 = the environment decides
 void attnblock_fused_override(int mode) { g_attn_fused_override = mode; }
-bool attnblock_fused_enabled(int n_tokens) {
+bool attnblock_fused_enabled(int n_tokens, int max_samples) {
   if (g_attn_fused_override >= 0) return g_attn_fused_override != 0;
   static const bool off = getenv("DDMI_ATTN_FUSED") && atoi(getenv("DDMI_ATTN_FUSED")) == 0;
   if (off) return false;
+  // small-batch regime (net.h): a workgroup of the fused kernel is one head of 1024 token rows - 14 to 42 workgroups at B = 1, each
+  // ~50 us whatever share of its rows is real; the split-K qkv convolution + the attention kernels take 0.4 ms less per evaluation
+  // at B = 1 and 0.2 ms at B = 8 (measured, round 6).  DDMI_ATTN_FUSED=1 keeps the fused launch there too
+  static const bool forced = getenv("DDMI_ATTN_FUSED") && atoi(getenv("DDMI_ATTN_FUSED")) == 1;
+  if (!forced && max_samples > 0 && net_small_batch_enabled() && max_samples <= net_small_batch_max()) return false;
   const char* e = getenv("DDMI_ATTN_FUSED_N");
   if (!e || n_tokens <= 0) return true;
   for (const char* p = e; *p;) {
@@ -154,7 +159,8 @@ int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w, int n
       }
     // fused qkv + attention launch (k_attnblock.hip): its own packing of the same pre-scaled projection; a block whose only token
     // count is served by it needs no separate qkv convolution
-    const bool fusable = !n.x3 && w->head_dim == 32 && attnblock_shape_ok(n.dt, 1024, ch, 32, 1) && attnblock_fused_enabled(n_tokens);
+    const bool fusable = !n.x3 && w->head_dim == 32 && attnblock_shape_ok(n.dt, 1024, ch, 32, 1) &&
+                         attnblock_fused_enabled(n_tokens, n.max_batch);
     if (fusable) DDMI_TRY(n.make_attnblock(ws, bs, ch, w->heads, &w->fused));
     if (!(fusable && n_tokens > 0 && attnblock_shape_ok(n.dt, n_tokens, ch, 32, n.max_batch * n.max_bmul)))
       DDMI_TRY(n.make_conv_host(ws, 3 * ch, ch, 1, &bs, &w->cqkv));
@@ -170,7 +176,7 @@ int make_unet_attnblock(UNet& u, const std::string& pre, int ch, AttnW* w, int n
 int emit_attn_single(Net& n, const AttnW& w, int x, int* out) {
   const TensorDesc t = n.tensors[x];
   int a = n.op_gn(x, w.gn, 0, w.eps);
-  if (w.fused >= 0 && attnblock_fused_enabled(t.H * t.W) && attnblock_shape_ok(n.dt, t.H * t.W, t.C, w.head_dim, n.max_batch * t.bmul)) {
+  if (w.fused >= 0 && attnblock_fused_enabled(t.H * t.W, n.max_batch) && attnblock_shape_ok(n.dt, t.H * t.W, t.C, w.head_dim, n.max_batch * t.bmul)) {
     n.ops.back().frag_out = 1;   // the GroupNorm just emitted: its output only feeds the fused launch, which wants whole B fragments
     Op f;
     f.kind = OP_ATTN_BLOCK;

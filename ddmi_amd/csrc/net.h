@@ -14,6 +14,18 @@
 void net_gn_fuse_override(int mode);
 int net_gn_fuse_mode();   // the effective mode: 0 never, 1 where the launch runs on the halo kernel anyway, 2 wherever the shape allows
 
+// The small-batch regime (round 6; SURVEY 8(d) config 2 at B in {1, 8, 16} - the reference's own gen mode runs test_batch_size 6-10): a UNet
+// evaluation there is ~300 dependent launches of 5-20 us, not a bandwidth or MFMA problem.  With it ON (default; DDMI_SMALL_BATCH=0 /
+// ddmi_debug_small_batch(0) switch it off - the parity suite does, so that its small batches keep exercising the kernels the benchmark's
+// B = 512 runs), a run at B <= net_small_batch_max() takes GroupNorm as ONE launch where a (sample, group) slice fits a workgroup's registers (launch_gn_small),
+// and networks BUILT for max_batch <= that bound keep the five-launch AttentionBlock and the two
+// accumulating 1x1 launches of a concatenated skip connection (the fused / dual-source forms need hundreds of tiles to pay).
+void net_small_batch_override(int mode);   // -1: environment, 0 off, 1 on
+bool net_small_batch_enabled();
+int net_small_batch_max();                 // DDMI_SMALL_BATCH_MAX, default 16
+// diagnostics: one-launch GroupNorms of the last Net::run of this process
+extern int g_net_small_gn_launches;
+
 struct HostTensor {
   std::vector<float> data;
   std::vector<int64_t> shape;

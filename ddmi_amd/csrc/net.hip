@@ -225,6 +225,9 @@ int Net::op_conv(int in, int conv, int stride, int ups, int res, int emb_off, fl
 bool Net::cat_conv_ok(int in, int in2, int conv) const {
   static const bool off = getenv("DDMI_CONV_CAT") && atoi(getenv("DDMI_CONV_CAT")) == 0;
   if (off || dt != DT_BF16 || x3 || conv < 0) return false;
+  // small-batch regime: the persistent dual-source kernel has no split-K - at B = 1 it runs on 6 workgroups for 70 us where the two
+  // accumulating split-K launches take 2 x 14 (measured, round 6: 3.94 -> 3.69 ms per evaluation at B = 1, 5.78 -> 5.45 at B = 8)
+  if (net_small_batch_enabled() && max_batch * max_bmul <= net_small_batch_max()) return false;
   const TensorDesc &t1 = tensors[in], &t2 = tensors[in2];
   const ConvW& c = convs[conv];
   if (c.K != 1 || !c.w || c.Cin != t1.C + t2.C || t1.H != t2.H || t1.W != t2.W || t1.bmul != t2.bmul) return false;
@@ -442,6 +445,19 @@ static int gn_fuse_mode() {
 }
 static bool gn_fuse_enabled() { return gn_fuse_mode() != 0; }
 int net_gn_fuse_mode() { return gn_fuse_mode(); }
+int g_net_small_gn_launches = 0;
+static int g_small_batch_override = -1;
+void net_small_batch_override(int mode) { g_small_batch_override = mode; }
+bool net_small_batch_enabled() {
+  if (g_small_batch_override >= 0) return g_small_batch_override != 0;
+  static const bool on = !(getenv("DDMI_SMALL_BATCH") && atoi(getenv("DDMI_SMALL_BATCH")) == 0);
+  return on;
+}
+int net_small_batch_max() {
+  static const int m = getenv("DDMI_SMALL_BATCH_MAX") ? atoi(getenv("DDMI_SMALL_BATCH_MAX")) : 16;
+  return m;
+}
+
 void Net::attach_fused_groupnorm() {
   if (dt != DT_BF16 || x3 || !gn_fuse_enabled()) return;
   std::vector<int> producer(tensors.size(), -1), readers(tensors.size(), 0);
@@ -755,6 +771,9 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
   std::vector<char> emb_out(tensors.size(), 0);    // diagnostics (DDMI_GN_ABL): tensors written by a convolution that adds a time embedding
   std::vector<char> fgn_done(ops.size(), 0);       // GroupNorm ops whose producer convolution wrote the normalised tensor itself this run
   fgn_launches = 0;
+  // small-batch regime (net.h): one-launch GroupNorm
+  const bool small = dt == DT_BF16 && !x3 && net_small_batch_enabled() && Bnet * max_bmul <= net_small_batch_max();
+  g_net_small_gn_launches = 0;
   size_t op_index = 0;
   for (const Op& o : ops) {
     const size_t oi = op_index++;
@@ -776,6 +795,15 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
         const int C = t.C + (o.in2 >= 0 ? tensors[o.in2].C : 0);
         const void* x2 = o.in2 >= 0 ? tptr(o.in2) : nullptr;
         DDMI_REQUIRE(g.C == C, "groupnorm channel mismatch");
+        if (small && !o.frag_out && !tensors[o.out].x3img && gn_small_ok(B, t.H * t.W, C, x2 != nullptr)) {   // one launch: statistics + apply
+          GnSmallArgs ga{};
+          ga.x = tptr(o.in); ga.x2 = x2; ga.C1 = t.C;
+          ga.y = tptr(o.out); ga.gamma = g.gamma; ga.beta = g.beta; ga.eps = o.eps; ga.silu = o.silu;
+          ga.B = B; ga.HW = t.H * t.W; ga.C = C;
+          ++g_net_small_gn_launches;
+          DDMI_TRY(launch_gn_small(ga, s));
+          break;
+        }
         double* st = gn_stats;
         {  // TIMING-ONLY (DDMI_GN_ABL=1, with a -DGN_ABL build of k_conv.hip and DDMI_CONV_DBG=32): the out_layers GroupNorm passes are
            // skipped, their consumers read stale memory - prices the producer-side GroupNorm before it is built
@@ -864,7 +892,7 @@ int Net::run(int B, void* const* ext, const float* emb, int emb_stride, hipStrea
             break;
           }
         }
-        if (o.stat_out >= 0) {
+        if (o.stat_out >= 0 && !small) {
           const int rows = conv_chstat_rows(a, dt);
           if (rows > 0) a.chstat = (float*)tptr(o.stat_out);
           stat_rows[o.out] = rows;

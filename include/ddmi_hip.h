@@ -373,6 +373,18 @@ int ddmi_debug_attn_fused(int mode);
 int ddmi_op_conv_gn(const float* x, const float* w, const float* bias, const float* emb, const float* gamma, const float* beta, float* y,
                     int B, int Cin, int H, int W, int Cout, float eps, int silu, int numerics, int iters, int* fused_used);
 int ddmi_debug_gn_fuse(int mode);
+/* The small-batch regime of the bf16 networks (ddmi_amd/csrc/net.h; the reference's own gen mode runs test_batch_size 6-10,
+ * configs/ldm/afhq.yaml:76): at B <= 16 (DDMI_SMALL_BATCH_MAX) a GroupNorm whose (sample, group) slice fits a workgroup's registers is ONE
+ * launch, and networks created with max_batch <= 16 keep the five-launch AttentionBlock and the two accumulating 1x1
+ * launches of a concatenated skip connection.  mode: 0 = off (every batch runs the kernels of the large-batch path - what the parity
+ * suite pins, tests/conftest.py), 1 = on, -1 = the DDMI_SMALL_BATCH environment (default on).  Read when a network is built AND run. */
+int ddmi_debug_small_batch(int mode);
+/* diagnostics: one-launch GroupNorms of the last network run of this process */
+int ddmi_debug_small_gn_launches(int* count);
+/* the one-launch GroupNorm on its own (bf16): GroupNorm32(eps) [+ SiLU] of the channel concatenation [x [B,C1,HW] | x2 [B,C2,HW] or null]
+ * -> y [B,C1+C2,HW]; gamma / beta [C1+C2] DEVICE pointers like ddmi_op_groupnorm's */
+int ddmi_op_groupnorm_small(const float* x, const float* x2, const float* gamma, const float* beta, float* y, int B, int C1, int C2, int HW,
+                            float eps, int silu);
 /* HOST-ONLY (no device needed): would the pair above - a bf16 3x3 / stride-1 convolution [B,Cin,H,W] -> Cout followed by GroupNorm(32) - run
  * with the GroupNorm in the convolution's epilogue on the halo kernel without split-K (k_conv.hip conv_fgn_ok: whole groups per channel
  * tile, whole 256-row tiles per sample, at most 16 workgroups waiting for each other, statistics exchanged only at batches that are

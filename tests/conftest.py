@@ -16,6 +16,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # timing-based pick of the box the test happens to run on - so the bf16 rounding order, and the metrics behind every bf16
 # threshold, are the same on every box.  A test that wants the autotuner sets DDMI_TUNE_STRICT=0 itself (before the library loads).
 os.environ.setdefault("DDMI_TUNE_STRICT", "1")
+# The suite's batches are small (1 .. 16), the benchmark's is 512: with the small-batch regime on (ddmi_amd/csrc/net.h: one-launch
+# GroupNorm + split-K finish, five-launch AttentionBlock, no dual-source skip convolution at max_batch <= 16) the suite would stop running
+# the kernels the headline number is made of.  It stays OFF here; tests/test_gpu_round6.py switches it on for the networks it pins in
+# that regime (ddmi_debug_small_batch).
+os.environ.setdefault("DDMI_SMALL_BATCH", "0")
 
 
 def pytest_configure(config):

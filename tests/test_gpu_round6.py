@@ -193,3 +193,140 @@ def test_two_unet_handles_on_two_streams_with_the_fused_handoff():
                 assert torch.equal(outs[i][k], refs[i]), (i, k)
     finally:
         L.ddmi_debug_gn_fuse(-1)
+
+
+# ---- the small-batch regime (net.h; SURVEY 8(d) config 2 at B in {1, 8, 16}) ----------------------------------------------------------
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV).contiguous()
+
+
+# (B, C1, C2, HW, silu): GroupNorm shapes of the AFHQ UNet that fit a workgroup's registers - 64x64 x 224 (7 channels per group: 14-byte
+# runs, 28 elements per thread), concatenated inputs of the output blocks (672 = 448 | 224: 21 per group, group 21 straddles the
+# boundary; 2688 = 1344 | 1344 at 8x8: 84 per group; 1792 at 16x16: 56 per group = 14 per thread), the AttentionBlock norm (no SiLU), a batch of 16
+GN_SMALL_CASES = [(1, 224, 0, 4096, 1), (2, 448, 224, 256, 1), (3, 896, 0, 256, 0), (1, 1344, 1344, 64, 1), (16, 448, 0, 1024, 1),
+                  (8, 896, 896, 256, 1)]
+
+
+@pytest.mark.parametrize("case", GN_SMALL_CASES)
+def test_one_launch_groupnorm_matches_torch_and_the_two_pass_form(case):
+    """util.py:198-215 (GroupNorm32) as ONE launch for small batches (k_groupnorm.hip gn_small_kernel): a workgroup per (sample, group)
+    takes shifted-data statistics and applies them.  Against torch fp64 on the bf16-rounded input within one output rounding, on data with
+    |mean| = 20 sigma, and bit-identical from run to run."""
+    import torch.nn.functional as F
+    B, C1, C2, HW, silu = case
+    C = C1 + C2
+    tag = "gnsmall%s" % (case,)
+    L = _lib.lib()
+    _lib.init_device(0)
+    x1 = (iw.normal(tag, "x1", (B, C1, HW)) + 20.0).astype(np.float32)
+    x2 = iw.normal(tag, "x2", (B, C2, HW), -3.0, 2.0) if C2 else None
+    gamma, beta = iw.normal(tag, "g", (C,), 1.0, 0.2), iw.normal(tag, "b", (C,), 0.0, 0.2)
+    xin = torch.cat([torch.from_numpy(x1)] + ([torch.from_numpy(x2)] if C2 else []), 1)
+    xin = xin.to(torch.bfloat16).double()     # what the kernel reads
+    ref = F.group_norm(xin, 32, torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5)
+    ref = (F.silu(ref) if silu else ref).float()
+    outs = []
+    for _ in range(2):
+        y = torch.empty((B, C, HW), device=DEV, dtype=torch.float32)
+        gd, bd, x1d = _dev(gamma), _dev(beta), _dev(x1)
+        x2d = _dev(x2) if C2 else None
+        _lib.check(L.ddmi_op_groupnorm_small(x1d.data_ptr(), x2d.data_ptr() if C2 else None, gd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, C1, C2,
+                                             HW, 1e-5, silu))
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0], ref) < 3e-3, (case, rel_l2(outs[0], ref))     # one bf16 rounding of the output
+    assert rel_err(outs[0], ref) < 6e-3, (case, rel_err(outs[0], ref))
+
+
+def _small_gn_count():
+    n = C.c_int(-1)
+    _lib.check(_lib.lib().ddmi_debug_small_gn_launches(C.byref(n)))
+    return n.value
+
+
+@pytest.mark.parametrize("case", [(1, 224, 64, 64, 224), (2, 448, 32, 32, 448), (8, 448, 16, 16, 896), (3, 672, 8, 8, 1344)])
+def test_conv_then_one_launch_groupnorm_through_the_network_executor(case):
+    """openaimodel.py:261-270 at small batch through Net::run: conv3x3 (split-K) + bias + embedding row -> the one-launch GroupNorm32 ->
+    SiLU.  Same bits as the regime-off path's statistics pass + apply pass up to the statistics' rounding; torch fp64 within the bf16 bound."""
+    B, Cin, H, W, Cout = case
+    tag = "sgn%s" % (case,)
+    L = _lib.lib()
+    x = iw.normal(tag, "x", (B, Cin, H, W))
+    w = iw.normal(tag, "w", (Cout, Cin, 3, 3), 0.0, 1.0 / math.sqrt(Cin * 9))
+    b = iw.normal(tag, "b", (Cout,), 0.0, 0.1)
+    emb = iw.normal(tag, "e", (B, Cout), 0.0, 0.5)
+    gamma, beta = iw.normal(tag, "g", (Cout,), 1.0, 0.2), iw.normal(tag, "bt", (Cout,), 0.0, 0.2)
+    ref = _conv_gn_ref(x, w, b, emb, gamma, beta, 1e-5, 1)
+    try:
+        _lib.check(L.ddmi_debug_small_batch(1))
+        small, used = conv_gn_op(x, w, b, emb, gamma, beta, fuse=0, iters=2)
+        assert used == 0 and _small_gn_count() == 1, case
+        _lib.check(L.ddmi_debug_small_batch(0))
+        big, _ = conv_gn_op(x, w, b, emb, gamma, beta, fuse=0)
+        assert _small_gn_count() == 0
+    finally:
+        L.ddmi_debug_small_batch(-1)
+    assert rel_err(small, ref) < 1.5e-2 and rel_err(big, ref) < 1.5e-2, (case, rel_err(small, ref), rel_err(big, ref))
+    assert rel_l2(small, big) < 2e-3, (case, rel_l2(small, big))     # the same bf16 tensor normalised: differences are the last bit of the output
+
+
+@pytest.mark.parametrize("name,cfgname", [("a", "TOY_UNET"), ("b", "TOY_UNET_B")])
+def test_unet_golden_in_the_small_batch_regime(golden, name, cfgname):
+    """Fixture U2 (the reference's UNetModel on toy configurations) with the small-batch regime ON: one-launch GroupNorms, the five-launch AttentionBlock, the two-launch skip connection.  Same acceptance as test_unet_golden;
+    eager = hipGraph replay; and the regime's forward agrees with the large-batch kernels' on the same weights."""
+    from helpers import TOL_BF16, assert_bf16_close
+    from test_gpu_networks import make_unet
+    u2 = golden.npz("U2_unet.npz")
+    cfg = golden.json("configs.json")[cfgname]
+    L = _lib.lib()
+    x = torch.from_numpy(u2[f"{name}.x"]).to(DEV)
+    t = torch.from_numpy(u2[f"{name}.t"]).to(DEV)
+    try:
+        _lib.check(L.ddmi_debug_small_batch(1))
+        unet = make_unet(cfg, f"U2{name}.unet", "bf16")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            eps = unet(x, t).clone()
+            side.synchronize()
+            assert _small_gn_count() > 0
+            assert rel_err(eps, u2[f"{name}.eps"]) < TOL_BF16
+            assert_bf16_close(eps, u2[f"{name}.eps"], f"U2{name} small-batch regime", linf=TOL_BF16, l2=2.0e-2)
+            assert torch.equal(unet(x, t), eps)
+            unet.set_graph(True)
+            out = torch.empty_like(eps)
+            for _ in range(3):
+                unet(x, t, out=out)
+            side.synchronize()
+            assert torch.equal(out, eps)
+        _lib.check(L.ddmi_debug_small_batch(0))
+        big = make_unet(cfg, f"U2{name}.unet", "bf16")(x, t)
+        assert _small_gn_count() == 0
+        assert rel_l2(eps, big) < 2.0e-2
+    finally:
+        L.ddmi_debug_small_batch(-1)
+
+
+def test_afhq_unet_full_size_small_batch_regime_vs_oracle():
+    """The AFHQ UNet at B = 1 and B = 8 with the small-batch regime on, against the CPU oracle (openaimodel.py:745-793 restated) on the
+    named-seed weights: bf16 acceptance as for the large-batch kernels; rows of the B = 8 batch equal in distribution to B = 1."""
+    from helpers import AFHQ_UNET, assert_bf16_close
+    from oracle import ddmi_oracle as O
+    from test_gpu_networks import make_unet
+    L = _lib.lib()
+    try:
+        _lib.check(L.ddmi_debug_small_batch(1))
+        unet = make_unet(AFHQ_UNET, "afhq.unet", "bf16", max_batch=8)
+        st = named_state("afhq.unet", unet.manifest())
+        x = iw.normal("afhq", "x", (1, 64, 64, 64))
+        t = torch.tensor([437], dtype=torch.int64)
+        ref = O.unet_forward(O.to_state(st), AFHQ_UNET, torch.from_numpy(x), t)
+        eps1 = unet(torch.from_numpy(x).to(DEV), t.to(DEV))
+        print('AFHQ small-batch regime: one-launch GroupNorms', _small_gn_count(), 'of 61')
+        assert _small_gn_count() >= 50
+        assert_bf16_close(eps1, ref, "AFHQ UNet full size, small-batch regime", linf=4e-2, l2=2.0e-2)
+        x8 = torch.from_numpy(np.concatenate([x] + [iw.normal("afhq", "x%d" % i, (1, 64, 64, 64)) for i in range(7)])).to(DEV)
+        eps8 = unet(x8, t.to(DEV).repeat(8))
+        assert_bf16_close(eps8[:1], ref, "AFHQ UNet full size, small-batch regime, row 0 of 8", linf=4e-2, l2=2.0e-2)
+        assert torch.equal(unet(x8, t.to(DEV).repeat(8)), eps8)
+    finally:
+        L.ddmi_debug_small_batch(-1)
