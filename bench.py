@@ -32,6 +32,12 @@ Besides the contract fields the line carries
                  do to a sample
   ddim_1000_250 - the same batch generated with the reference's other 250-NFE sampler (timesteps=1000, S=250, eta=1)
   nccl_ranks   - size of the group that completed the all-gather
+  small_batch  - SURVEY 8(d) config 2 at B in {1, 8, 16}: ms per UNet evaluation (plain launches / hipGraph replay), samples/s at 250 NFE,
+                 profiled launches per evaluation, the HBM floor of the weights beside them
+
+`python bench.py --gpus N --dry-run` runs the rank plumbing of this script - self-launch, torchrun environment, process group (gloo),
+shared conv-plan broadcast, disjoint sample indices, all-gather, barrier + max-over-ranks timing, one JSON line from rank 0 - on CPU
+tensors with a stub step: what an 8-GPU run executes around the kernels, testable without a GPU (tests/test_dist_gloo.py).
 """
 import argparse
 import json
@@ -230,6 +236,58 @@ def roofline_of(prof, pick, workload="afhq"):
             "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
 
 
+def small_batch_afhq(dev, batches=(1, 8, 16), iters=20):
+    """SURVEY 8(d) config 2 at B in {1, 8, 16} - the regime the reference's own `gen` mode runs (configs/ldm/afhq.yaml:76 test_batch_size
+    6-10): ms per AFHQ UNet evaluation and samples/s at 250 NFE on a handle created FOR that batch (its convolution plans are tuned at
+    it), profiled launches per evaluation, and the HBM floor (the bf16 weights read once at 6 TB/s) beside them.  The small-batch regime of
+    ddmi_amd/csrc/net.h is on (default).  Runs on a side stream (stream capture is refused on the legacy default stream); hipGraph replay
+    is timed beside the plain launches: the evaluation is ~250 DEPENDENT kernels whose ~5 us start-to-start floor a replay does not
+    remove (measured equal within 0.2 %)."""
+    import torch
+    from ddmi_amd import _lib
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.unet import UNetModel
+    rows = []
+    side = torch.cuda.Stream()
+    weights = None
+    for B in batches:
+        m = UNetModel(numerics="bf16", max_batch=B, **AFHQ["unetconfig"])
+        m.load_state_dict(iw.fill_state("afhq.unet", m.manifest()))
+        m.finalize()
+        m.set_uniform_t(True)
+        weights = m.memory()["weights"]
+        x = torch.randn((B, 64, 64, 64), device=dev)
+        t = torch.full((B,), 123, dtype=torch.int64, device=dev)
+        out = torch.empty_like(x)
+        row = {"B": B}
+        with torch.cuda.stream(side):
+            for mode in ("plain", "graph"):
+                m.set_graph(mode == "graph")
+                for _ in range(3):
+                    m(x, t, out=out)
+                side.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    m(x, t, out=out)
+                side.synchronize()
+                row[f"ms_per_eval_{mode}"] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+            m.set_graph(False)
+            _lib.profile_enable(1)
+            m(x, t, out=out)
+            side.synchronize()
+            prof = _lib.profile_collect()
+            _lib.profile_enable(0)
+        best = min(row["ms_per_eval_plain"], row["ms_per_eval_graph"])
+        row["samples_per_sec_250nfe"] = round(B / (NFE * best * 1e-3), 3)
+        row["profiled_launches_per_eval"] = int(sum(v["launches"] for v in prof.values()))
+        rows.append(row)
+        del m
+        torch.cuda.empty_cache()
+    return {"what": "AFHQ UNet evaluation at small batch (handle created with max_batch = B, bf16, uniform t); samples/s = B / (250 x ms_per_eval)",
+            "rows": rows, "weights_bytes": weights, "hbm_floor_ms_per_eval": round(weights / 6.0e12 * 1e3, 3),
+            "regime": "ddmi_amd/csrc/net.h small-batch regime " + ("on" if os.environ.get("DDMI_SMALL_BATCH", "1") != "0" else "OFF (DDMI_SMALL_BATCH=0)")}
+
+
 def psnr(a, b, peak=2.0):
     import torch
     mse = float(((a.double() - b.double()) ** 2).mean())
@@ -312,6 +370,8 @@ def run_afhq(args, rank, local_rank, world, dev):
     dec_fl = sum(v.get("flops", 0.0) for k, v in p1.items() if k != "mlp2d_fused")
     extra["decoder_kernels"] = {"ms_per_batch": round(dec_ms, 2), "tflops": round(dec_fl / (dec_ms * 1e-3) / 1e12, 1) if dec_ms else None}
 
+    if rank == 0 and not args.no_small_batch:
+        extra["small_batch"] = small_batch_afhq(dev)
     if rank == 0 and not args.no_parity_check:
         extra["parity_check"] = parity_check_afhq(args, pipe, phase, dev)
     if not args.no_ddim:   # the reference's other 250-NFE sampler on the same nets: DDIM over T=1000, S=250, eta=1
@@ -833,6 +893,7 @@ def main():
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--parity-batch", type=int, default=128, help="samples per batch of the bf16x3 parity-mode leg of parity_check")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="afhq: skip the B = 1 / 8 / 16 UNet-evaluation block")
     ap.add_argument("--no-workloads", action="store_true", help="afhq: skip the one-step shapenet / sky / train legs behind the headline run")
     ap.add_argument("--seed", type=int, default=777)
     ap.add_argument("--rng", default="philox", choices=["philox", "torch", "reference"],

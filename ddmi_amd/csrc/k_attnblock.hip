@@ -34,7 +34,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
 // timing-only ablation builds (tools/build_variant.sh -DAB_DBG=n; results are wrong): 1 no x loads after chunk 0, 2 no weight DMA after
-// chunk 0, 4 no per-chunk barrier, 8 no MFMAs in the projection
+// chunk 0, 4 no per-chunk barrier, 8 no MFMAs in the projection, 16 a per-(sample, channel) affine transform applied to every x fragment
+// between its load and its MFMAs - what folding the AttentionBlock's GroupNorm (no SiLU: openaimodel.py:300, 320) into this kernel's
+// x-fragment load would add to the projection (round-5 verdict item 1a; DESIGN_r6.md has the numbers)
 #ifndef AB_DBG
 #define AB_DBG 0
 #endif
@@ -163,7 +165,19 @@ __global__ void __launch_bounds__(512) attnblock_kernel(AttnBlockK a) {
         for (int cf = 0; cf < 6; ++cf) wf[cf] = *reinterpret_cast<const bf16x8*>(wb + cf * 2048 + (((4 * ks + lg) ^ wsw) << 4));
 #pragma unroll
         for (int tf = 0; tf < 4; ++tf) {
-          const bf16x8 xf = __builtin_bit_cast(bf16x8, cur[tf][ks]);
+          bf16x8 xf = __builtin_bit_cast(bf16x8, cur[tf][ks]);
+#if AB_DBG & 16
+          {   // timing only: scale / shift of the lane's 8 channels of this k-step from (any) fp32 memory, 8 conversions + 8 FMAs + 8 roundings
+            const float* sp = bias_lds + ((8 * (4 * ks + lg) + 16 * (c & 1)) & 63);
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(sp), sb = *reinterpret_cast<const f32x4*>(sp + 4);
+            const f32x4 ha = *reinterpret_cast<const f32x4*>(sp + 8), hb = *reinterpret_cast<const f32x4*>(sp + 12);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              xf[e] = (bf16_t)__builtin_fmaf((float)xf[e], sa[e], ha[e]);
+              xf[4 + e] = (bf16_t)__builtin_fmaf((float)xf[4 + e], sb[e], hb[e]);
+            }
+          }
+#endif
 #pragma unroll
           for (int cf = 0; cf < 6; ++cf)
             if (!(AB_DBG & 8)) acc[tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cf], xf, acc[tf][cf], 0, 0, 0);
