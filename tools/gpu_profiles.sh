@@ -9,7 +9,7 @@ export DDMI_TUNE_FILE=$PWD/gpurun_out/${tag}_conv_plans.txt
 rm -f $DDMI_TUNE_FILE
 timeout 2400 python bench.py --steps 2 --warmup 1 --parity-batch 128 > gpurun_out/${tag}_bench_n1_b512.json 2> gpurun_out/${tag}_bench.log
 echo "bench rc=$?"; head -c 400 gpurun_out/${tag}_bench_n1_b512.json; echo
-SHORT="bench.py --nfe 6 --steps 1 --warmup 0 --no-cpu-baseline --no-parity-check --no-ddim --no-workloads"
+SHORT="bench.py --nfe 6 --steps 1 --warmup 0 --no-cpu-baseline --no-parity-check --no-ddim --no-workloads --no-small-batch"
 (cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/${tag}_rocprof -- python3 $OLDPWD/$SHORT > $OLDPWD/gpurun_out/${tag}_rocprof.log 2>&1)
 echo "rocprof rc=$?"
 f=$(find gpurun_out/${tag}_rocprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats.csv && head -8 gpurun_out/${tag}_kernel_stats.csv
