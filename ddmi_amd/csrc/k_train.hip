@@ -1284,15 +1284,38 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const bf16_t* __
   }
 }
 
+// the plain (one thread per query / key row) pair for a head dim other than 32: the tri-plane UNet's AttentionBlocks (num_head_channels 64)
+// and its 16-head inter-plane attention (C / 16 = 16 .. 96 channels per head, openaimodel.py:955-957) on the training path.  Correct and
+// slow - O(T^2 d) VALU work per head with 4 d floats of state per thread; the MFMA kernels above and in k_attn_bwd.hip serve d = 32
+template <typename T, int D>
+static void attn_bwd_plain(const void* qkv, const void* out, const void* dout, void* dqkv, float* lse, float* dsum, int B, int Tn, int heads,
+                           hipStream_t s) {
+  dim3 g((unsigned)cdiv(Tn, 128), (unsigned)heads, (unsigned)B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), g, dim3(128), 0, s, (const T*)qkv, (const T*)out, (const T*)dout, (T*)dqkv, lse, dsum, Tn, heads);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), g, dim3(128), 0, s, (const T*)qkv, (const T*)dout, (T*)dqkv, lse, dsum, Tn, heads);
+}
+
 int launch_attention_legacy_backward(const void* qkv, const void* out, const void* dout, void* dqkv, float* scratch /* 2*B*heads*T */,
                                      int dt, int B, int T, int heads, int d, hipStream_t s) {
-  DDMI_REQUIRE(d == 32, "attention backward: head dim 32 (num_head_channels of every DDMI config)");
+  DDMI_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64 || d == 96 || d == 128,
+               "attention backward: head dim 2, 4, 8, 16, 32, 64, 96 or 128");
   float* lse = scratch;
   float* dsum = scratch + (size_t)B * heads * T;
   dim3 g((unsigned)cdiv(T, 128), (unsigned)heads, (unsigned)B);
   PROF_SCOPE("attention_legacy_bwd", 2.0 * 5.0 * B * heads * (double)T * T * d, 0, s);
   static const bool no_mfma = getenv("DDMI_ATTN_BWD_VALU") != nullptr;   // diagnostics: the plain kernels in bf16 too
-  if (dt == DT_BF16 && T % AB_TILE == 0 && !no_mfma) {
+  if (d != 32) {
+    const bool f32 = dt == DT_F32;
+    switch (d) {   // (2, 4, 8: the toy tri-plane networks of the fixtures - 16 heads of a 32 .. 128-channel tensor)
+      case 2: f32 ? attn_bwd_plain<float, 2>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 2>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+      case 4: f32 ? attn_bwd_plain<float, 4>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 4>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+      case 8: f32 ? attn_bwd_plain<float, 8>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 8>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+      case 16: f32 ? attn_bwd_plain<float, 16>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 16>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+      case 64: f32 ? attn_bwd_plain<float, 64>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 64>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+      case 96: f32 ? attn_bwd_plain<float, 96>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 96>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+      default: f32 ? attn_bwd_plain<float, 128>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s) : attn_bwd_plain<bf16_t, 128>(qkv, out, dout, dqkv, lse, dsum, B, T, heads, s); break;
+    }
+  } else if (dt == DT_BF16 && T % AB_TILE == 0 && !no_mfma) {
     dim3 gm((unsigned)(T / AB_TILE), (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, gm, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, T, heads);
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gm, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, T, heads);

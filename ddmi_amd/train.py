@@ -360,13 +360,14 @@ class EpsLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tc, model_out, x_t, noise, sqrt_1mac, logit):
-        B, Cc, H, W = model_out.shape
+        B, Cc = model_out.shape[:2]                      # [B, C, H, W] (image) or [B, C, L] (video latents, ddpm.py:152-159)
+        HW = model_out[0, 0].numel()
         loss = torch.empty((), dtype=torch.float32, device=model_out.device)
         dmo = torch.empty_like(model_out)
         dlogit = torch.empty((Cc,), dtype=torch.float32, device=model_out.device) if logit is not None else None
         lg = logit.reshape(-1).contiguous() if logit is not None else None
         _lib.check(_lib.lib().ddmi_train_eps_loss(tc.h, model_out.contiguous().data_ptr(), x_t.data_ptr(), noise.data_ptr(), sqrt_1mac.data_ptr(),
-                                                  _p(lg), loss.data_ptr(), dmo.data_ptr(), _p(dlogit), B, Cc, H * W, _stream()))
+                                                  _p(lg), loss.data_ptr(), dmo.data_ptr(), _p(dlogit), B, Cc, HW, _stream()))
         ctx.save_for_backward(dmo, dlogit if dlogit is not None else torch.empty(0))
         ctx.logit_shape = tuple(logit.shape) if logit is not None else None
         return loss
@@ -394,14 +395,15 @@ class _Conv(nn.Module):
         return ConvFn.apply(tc, x, self.weight, self.bias, emb, res, stride, ups)
 
 
-class _Norm(nn.Module):   # GroupNorm32(32, C)
-    def __init__(self, c):
+class _Norm(nn.Module):   # GroupNorm32(32, C); eps 1e-6 for the d2c_vae-style blocks (autoencoder_unet.py:46-47)
+    def __init__(self, c, eps=1e-5):
         super().__init__()
         self.weight = nn.Parameter(torch.empty((c,)))
         self.bias = nn.Parameter(torch.empty((c,)))
+        self.eps = float(eps)
 
     def run(self, tc, x, silu, passthrough=False):
-        return GroupNormFn.apply(tc, x, self.weight, self.bias, 1e-5, silu, passthrough and FUSE_RESIDUAL_GRAD)
+        return GroupNormFn.apply(tc, x, self.weight, self.bias, self.eps, silu, passthrough and FUSE_RESIDUAL_GRAD)
 
 
 class _Linear(nn.Module):
@@ -590,6 +592,111 @@ class TrainUNetModel(nn.Module):
         return ToNCHW.apply(tc, h)
 
 
+class InterAttention(nn.Module):
+    """The block UNetModel_Triplane puts after every input block but the first, after the middle block and after every output block
+    (openaimodel.py:912, 955-957, 984-986, 1023, 1082): make_attn('vanilla-1d-multihead') = MemoryEfficientAttnBlock1D
+    (autoencoder_unet.py:404-468) over the tokens xy | xt | yt of a sample - GroupNorm(32, C, eps 1e-6) with statistics over ALL of
+    them, q / k / v = Conv1d(C, C, 1), 16 heads of C / 16 channels, softmax(q k^T / sqrt(d)) v, proj_out, + x.
+    Tokens arrive as an NHWC "image" [B, 1, N, C]."""
+
+    def __init__(self, ch, heads=16):
+        super().__init__()
+        self.heads = heads
+        self.norm = _Norm(ch, eps=1e-6)
+        self.q, self.k, self.v = _Conv(ch, ch, 1, dims=1), _Conv(ch, ch, 1, dims=1), _Conv(ch, ch, 1, dims=1)
+        self.proj_out = _Conv(ch, ch, 1, dims=1)
+
+    def run(self, tc, x):
+        hn = self.norm.run(tc, x, silu=False, passthrough=True)
+        if isinstance(hn, tuple):
+            hn, x = hn
+        B, _, N, Cc = x.shape
+        d = Cc // self.heads
+        # three projections (the reference's three Conv1d modules keep their own state-dict entries), interleaved per head into
+        # QKVAttentionLegacy's [q | k | v] channel blocks - the layout the attention kernels and their backward take
+        q, k, v = (m.run(tc, hn).reshape(B, 1, N, self.heads, 1, d) for m in (self.q, self.k, self.v))
+        qkv = torch.cat([q, k, v], dim=4).reshape(B, 1, N, 3 * Cc)
+        a = AttentionLegacyFn.apply(tc, qkv, self.heads)
+        return self.proj_out.run(tc, a, res=x)
+
+
+class TrainUNetModel_Triplane(TrainUNetModel):
+    """The training-path `UNetModel_Triplane` (openaimodel.py:800-1221; tools/ldm/video.py:150-167 trains it): the UNetModel's blocks
+    applied to the three planes xy [s1, s2], xt [s3, s1], yt [s3, s2] of a latent [B, C, s1 s2 + s1 s3 + s2 s3] with SHARED weights
+    (their gradients accumulate in the same slab entries), and a 16-head attention over the concatenated tokens after every block.
+    Same constructor kwargs and state-dict keys as the reference.  Composed of the image model's ops (ConvFn, GroupNormFn,
+    AttentionLegacyFn - forward and backward entry points of the C ABI) plus torch views for the plane / token bookkeeping."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, channel_mult=(1, 2, 4, 8),
+                 num_head_channels=32, size1=64, size2=64, size3=16, attn_type="vanilla-1d-multihead", numerics="bf16", device="cuda:0",
+                 **ignored):
+        if attn_type != "vanilla-1d-multihead":
+            raise NotImplementedError("UNetModel_Triplane: only attn_type='vanilla-1d-multihead' (the default every config uses)")
+        super().__init__(image_size=size1, in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
+                         num_res_blocks=num_res_blocks, attention_resolutions=attention_resolutions, channel_mult=channel_mult,
+                         num_head_channels=num_head_channels, numerics=numerics, device=device)
+        self.size1, self.size2, self.size3 = int(size1), int(size2), int(size3)
+        self.seq_len = self.size1 * self.size2 + self.size1 * self.size3 + self.size2 * self.size3
+        mc, mult = model_channels, list(channel_mult)
+        attns, ch = [nn.Identity()], mc                      # input_attns[0] is nn.Identity (openaimodel.py:912)
+        for level, m in enumerate(mult):
+            for _ in range(num_res_blocks):
+                ch = m * mc
+                attns.append(InterAttention(ch))
+            if level != len(mult) - 1:
+                attns.append(InterAttention(ch))               # after the Downsample block
+        self.input_attns = nn.ModuleList(attns)
+        self.mid_attn = InterAttention(ch)
+        self.output_attns = nn.ModuleList([InterAttention(mc * m) for level, m in list(enumerate(mult))[::-1]
+                                           for _ in range(num_res_blocks + 1)])
+        assert len(self.input_attns) == len(self.input_blocks) and len(self.output_attns) == len(self.output_blocks)
+        self.to(device)
+
+    @staticmethod
+    def _inter(tc, attn, hs):
+        if isinstance(attn, nn.Identity):
+            return hs
+        B, Cc = hs[0].shape[0], hs[0].shape[-1]
+        shapes = [tuple(h.shape) for h in hs]
+        tok = torch.cat([h.reshape(B, 1, -1, Cc) for h in hs], dim=2)          # xy | xt | yt (openaimodel.py:1148-1152)
+        out = attn.run(tc, tok)
+        parts = torch.split(out, [s[1] * s[2] for s in shapes], dim=2)
+        return [p_.reshape(s) for p_, s in zip(parts, shapes)]
+
+    def forward(self, x, timesteps, context=None, **kw):
+        """x [B, C, L] fp32, timesteps [B] int64 -> eps [B, C, L] fp32 (openaimodel.py:1113-1221)."""
+        tc = self.tc
+        B, Cc, L = x.shape
+        assert L == self.seq_len, (L, self.seq_len)
+        s1, s2, s3 = self.size1, self.size2, self.size3
+        temb = torch.empty((B, self.model_channels), dtype=torch.float32, device=x.device)
+        t64 = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        _lib.check(_lib.lib().ddmi_train_timestep_embedding(tc.h, t64.data_ptr(), temb.data_ptr(), B, self.model_channels, _stream()))
+        emb = self.time_embed[2].run(tc, self.time_embed[0].run(tc, temb, silu_in=False), silu_in=True)
+        embs = self._project_embeddings(tc, emb)
+        n_xy, n_xt = s1 * s2, s1 * s3
+        planes = (x[:, :, :n_xy].reshape(B, Cc, s1, s2), x[:, :, n_xy:n_xy + n_xt].reshape(B, Cc, s3, s1),
+                  x[:, :, n_xy + n_xt:].reshape(B, Cc, s3, s2))
+        hs = [ToNHWC.apply(tc, p_.contiguous()) for p_ in planes]
+        skips = []
+        for i, block in enumerate(self.input_blocks):
+            hs = [self._run_block(tc, block, h, embs) for h in hs]
+            hs = self._inter(tc, self.input_attns[i], hs)
+            skips.append(hs)
+        hs = [self._run_block(tc, self.middle_block, h, embs) for h in hs]
+        hs = self._inter(tc, self.mid_attn, hs)
+        for j, block in enumerate(self.output_blocks):
+            sk = skips.pop()
+            cat = []
+            for h, s_ in zip(hs, sk):
+                vec = 16 // h.element_size()
+                cat.append(CatFn.apply(tc, h, s_) if h.shape[-1] % vec == 0 and s_.shape[-1] % vec == 0 else torch.cat([h, s_], dim=-1))
+            hs = [self._run_block(tc, block, h, embs) for h in cat]
+            hs = self._inter(tc, self.output_attns[j], hs)
+        outs = [ToNCHW.apply(tc, self.out[2].run(tc, self.out[0].run(tc, h, silu=True))) for h in hs]
+        return torch.cat([o.reshape(B, o.shape[1], -1) for o in outs], dim=-1)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the training step
 # ---------------------------------------------------------------------------------------------------------------------
@@ -761,7 +868,9 @@ class LDMTrainStep:
                  overlap_allreduce=True, allreduce_bucket_bytes=256 << 20):
         cfg = dict(ddpmconfig)
         self.device = torch.device(device)
-        self.model = TrainUNetModel(**dict(unetconfig), numerics=numerics, device=device)
+        # the video domain (tools/ldm/video.py): a tri-plane UNet on [B, C, L] latents, mixing_logit [1, C, 1] (ddpm.py:152-159)
+        self.video = "size3" in dict(unetconfig) or cfg.get("domain") == "video"
+        self.model = (TrainUNetModel_Triplane if self.video else TrainUNetModel)(**dict(unetconfig), numerics=numerics, device=device)
         self.channels = int(cfg.get("channels", unetconfig["in_channels"]))
         self.num_timesteps = int(cfg.get("timesteps", 1000))
         betas_np = make_beta_schedule(cfg.get("beta_schedule", "linear"), self.num_timesteps, cfg.get("linear_start", 0.0015),
@@ -770,8 +879,8 @@ class LDMTrainStep:
         self.sqrt_ac = torch.from_numpy(np.sqrt(ac).astype(np.float32)).to(self.device)
         self.sqrt_1mac = torch.from_numpy(np.sqrt(1.0 - ac).astype(np.float32)).to(self.device)
         self.mixed_prediction = bool(cfg.get("mixed_prediction", True))
-        self.mixing_logit = nn.Parameter(torch.full((1, self.channels, 1, 1), float(cfg.get("mixed_init", -6)), device=self.device)) \
-            if self.mixed_prediction else None
+        self.mixing_logit = nn.Parameter(torch.full((1, self.channels, 1) if self.video else (1, self.channels, 1, 1),
+                                                    float(cfg.get("mixed_init", -6)), device=self.device)) if self.mixed_prediction else None
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.accum = int(gradient_accumulate_every)
         self.ema_decay, self.ema_every = float(ema_decay), int(ema_update_every)
@@ -788,7 +897,9 @@ class LDMTrainStep:
         self.current_iters = 0       # the reference's `current_iters`: micro-steps so far
         self.use_graph = bool(use_graph)     # replay the micro-step as a hipGraph (see _graphed_micro)
         # gradient all-reduce overlapped with the backward (eager steps, one micro-step per optimizer step, more than one rank)
-        self.overlap_allreduce, self.allreduce_bucket_bytes = bool(overlap_allreduce), int(allreduce_bucket_bytes)
+        # (the tri-plane model's inter-plane attention parameters sit behind `out` in the slab and finish with their blocks: the bucket
+        # plan below is the image model's; the video step takes the blocking all-reduce)
+        self.overlap_allreduce, self.allreduce_bucket_bytes = bool(overlap_allreduce) and not self.video, int(allreduce_bucket_bytes)
         self._reducer: Optional[OverlappedGradReducer] = None
         self._reduce_plan = None
         self._graphs: Dict[tuple, object] = {}

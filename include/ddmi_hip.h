@@ -446,7 +446,9 @@ int ddmi_train_gn_bwd_res(ddmi_train* h, const void* x, const float* gamma, cons
  * split2 copies the two column blocks of `in` back to a and b.  rows = B*H*W; Ca, Cb multiples of the 16-byte vector. */
 int ddmi_train_cat2(ddmi_train* h, const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, void* stream);
 int ddmi_train_split2(ddmi_train* h, const void* in, void* a, void* b, int64_t rows, int Ca, int Cb, void* stream);
-/* QKVAttentionLegacy openaimodel.py:397-426: qkv [B,T,heads*3*d] (per-head [q|k|v]), out [B,T,heads*d]; backward d = 32 */
+/* QKVAttentionLegacy openaimodel.py:397-426: qkv [B,T,heads*3*d] (per-head [q|k|v]), out [B,T,heads*d]; backward d in {2, 4, 8, 16, 32, 64, 96, 128}
+ * (32: MFMA kernels; the others - the tri-plane UNet's 64-channel heads and its 16-head inter-plane attention, openaimodel.py:955-957 -
+ * on the plain one-thread-per-row kernels) */
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream);
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
                         void* stream);

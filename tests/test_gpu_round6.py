@@ -330,3 +330,112 @@ def test_afhq_unet_full_size_small_batch_regime_vs_oracle():
         assert torch.equal(unet(x8, t.to(DEV).repeat(8)), eps8)
     finally:
         L.ddmi_debug_small_batch(-1)
+
+
+# ---- the video-domain training step (widening: tools/ldm/video.py:150-167; UNetModel_Triplane openaimodel.py:800-1221) ----------------
+def _toy_video_trainer(golden, numerics):
+    from ddmi_amd import train as T
+    cfg = golden.json("T2_config.json")["TOY_UNET_T2"]
+    tr = T.LDMTrainStep(cfg, dict(timesteps=1000, channels=8), numerics=numerics, lr=1e-4, device=DEV)
+    assert tr.video and tuple(tr.mixing_logit.shape) == (1, 8, 1)
+    st = {"model." + k: v for k, v in iw.fill_state("T2.unet3", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+    st["mixing_logit"] = iw.normal("T2", "mixing_logit", (1, 8, 1), 0.0, 0.5)
+    tr.load_state_dict(st).finalize()
+    return tr, cfg
+
+
+def test_video_training_model_has_the_reference_state_dict(golden):
+    """TrainUNetModel_Triplane's parameter names and shapes are UNetModel_Triplane.state_dict()'s (fixture T2's manifest, written by the
+    real reference) - `ldm-last.pt` of the video trainer loads into it unchanged."""
+    from ddmi_amd import train as T
+    doc = golden.json("T2_config.json")
+    m = T.TrainUNetModel_Triplane(**doc["TOY_UNET_T2"], numerics="fp32", device=DEV)
+    ours = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert ours == doc["manifest"], sorted(set(ours) ^ set(doc["manifest"]))[:6]
+
+
+def test_video_training_step_matches_reference_fixture_t2(golden):
+    """`DDPM(domain='video').p_losses` -> backward -> AdamW on the toy tri-plane UNet == the REAL reference (oracle/gen_golden_train_video.py),
+    fp32 parity mode < 1e-3: the loss, 31 gradients in full, every one of the 209 gradients by (sum, l2), the parameters after the step."""
+    from helpers import TOL_FP32
+    t2 = golden.npz("T2_train_step_video.npz")
+    tr, cfg = _toy_video_trainer(golden, "fp32")
+    L = tr.model.seq_len
+    x0 = torch.from_numpy(iw.normal("T2", "x_start", (2, 8, L)))
+    nz = torch.from_numpy(iw.normal("T2", "noise", (2, 8, L)))
+    loss = tr.loss_and_backward(x0, torch.from_numpy(t2["t"]), nz)
+    assert abs(float(loss) - float(t2["loss"])) < TOL_FP32 * float(t2["loss"])
+    grads = {k: p.grad for k, p in tr.named_parameters()}
+    assert set(grads) == set(str(k) for k in t2["all_keys"])
+    floor = 1e-6 * float(t2["all_l2"].max())
+    bad = {}
+    for k in [k[5:] for k in t2 if k.startswith("grad.")]:
+        ref = t2["grad." + k]
+        if float(np.sqrt((ref.astype(np.float64) ** 2).sum())) < floor:     # analytically zero: rounding noise on both sides
+            if float(grads[k].abs().max()) > floor:
+                bad[k] = "noise-level gradient came back large"
+        elif not rel_err(grads[k].detach().cpu(), ref) < TOL_FP32:
+            bad[k] = rel_err(grads[k].detach().cpu(), ref)
+    assert not bad, bad
+    for k, s_ref, l2_ref in zip(t2["all_keys"], t2["all_sum"], t2["all_l2"]):
+        gk = grads[str(k)].double()
+        assert abs(float(gk.pow(2).sum().sqrt()) - l2_ref) < TOL_FP32 * l2_ref + floor, k
+        assert abs(float(gk.sum()) - s_ref) < TOL_FP32 * l2_ref * np.sqrt(gk.numel()) + floor, k
+    tr.optimizer_step()
+    params = dict(tr.named_parameters())
+    for k in [k[6:] for k in t2 if k.startswith("adamw.")]:
+        gref = np.abs(t2["grad." + k])
+        live = torch.from_numpy(gref > 1e-4 * gref.max() + floor * 1e-3).to(DEV)   # Adam's first step is lr * sign(g): noise-level entries masked
+        if not bool(live.any()):
+            continue
+        ref = torch.from_numpy(t2["adamw." + k]).to(DEV)
+        err = float(((params[k].detach() - ref).abs() * live).max() / ref.abs().max())
+        assert err < 1e-5, (k, err)
+
+
+def test_video_training_step_bf16_tracks_the_fixture_and_descends(golden):
+    from helpers import TOL_BF16
+    t2 = golden.npz("T2_train_step_video.npz")
+    tr, cfg = _toy_video_trainer(golden, "bf16")
+    L = tr.model.seq_len
+    x0 = torch.from_numpy(iw.normal("T2", "x_start", (2, 8, L)))
+    nz = torch.from_numpy(iw.normal("T2", "noise", (2, 8, L)))
+    loss = tr.loss_and_backward(x0, torch.from_numpy(t2["t"]), nz)
+    assert abs(float(loss) - float(t2["loss"])) < TOL_BF16 * float(t2["loss"])
+    grads = {k: p.grad for k, p in tr.named_parameters()}
+    floor = 1e-6 * float(t2["all_l2"].max())
+    for k in [k[5:] for k in t2 if k.startswith("grad.")]:
+        a, b = grads[k].double().flatten().cpu(), torch.from_numpy(t2["grad." + k]).double().flatten()
+        if float(b.norm()) < floor:
+            assert float(a.norm()) < 1e-3 * float(t2["all_l2"].max()), k
+            continue
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.98, (k, cos)
+    l0 = float(loss)
+    tr.optimizer_step()
+    for _ in range(5):
+        l1 = float(tr.train_step(x0, torch.from_numpy(t2["t"]), nz))
+    assert l1 < l0
+
+
+@pytest.mark.parametrize("heads,d,T_", [(16, 4, 128), (16, 8, 32), (4, 16, 96), (3, 64, 80), (2, 96, 48)])
+def test_attention_backward_at_the_triplane_head_dims(heads, d, T_):
+    """QKVAttentionLegacy's backward (openaimodel.py:397-426) at the head dims of the tri-plane UNet - 64-channel AttentionBlock heads,
+    16-head inter-plane attention of 16 .. 96 channels per head, the fixtures' 4 / 8 - against torch autograd of the oracle's attention."""
+    from ddmi_amd import train as T
+    from oracle import ddmi_oracle as O
+    for numerics, tol in (("fp32", 2e-5), ("bf16", 4e-2)):
+        tc = T.TrainContext(numerics, DEV)
+        B = 2
+        qkv = torch.from_numpy(iw.normal("ta6", "qkv%d_%d" % (heads, d), (B, heads * 3 * d, T_)))
+        dout = torch.from_numpy(iw.normal("ta6", "dout%d_%d" % (heads, d), (B, heads * d, T_)))
+        if numerics == "bf16":
+            qkv, dout = qkv.to(torch.bfloat16).float(), dout.to(torch.bfloat16).float()
+        qr = qkv.clone().requires_grad_(True)
+        out_r = O.qkv_attention_legacy(qr, heads)
+        out_r.backward(dout)
+        qd = qkv.permute(0, 2, 1).reshape(B, 1, T_, heads * 3 * d).contiguous().to(DEV, tc.dtype).requires_grad_(True)
+        out = T.AttentionLegacyFn.apply(tc, qd, heads)
+        assert rel_err(out.detach().float().cpu().reshape(B, T_, heads * d).permute(0, 2, 1), out_r.detach()) < tol
+        out.backward(dout.permute(0, 2, 1).reshape(B, 1, T_, heads * d).contiguous().to(DEV, tc.dtype))
+        assert rel_err(qd.grad.detach().float().cpu().reshape(B, T_, heads * 3 * d).permute(0, 2, 1), qr.grad) < tol, (numerics, heads, d)

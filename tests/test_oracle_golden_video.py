@@ -70,3 +70,37 @@ def test_generate_video_chain(golden, name, T, S, eta):
                            torch.from_numpy(v4["x_T"]), draws, T, S, eta, toy_coords(golden))
     assert rel_err(out["z"], v4[f"{name}.z"]) < 1e-4
     assert rel_err(out["video"], v4[f"{name}.video"]) < 1e-4
+
+
+def test_oracle_video_training_step_matches_reference_fixture_t2(golden):
+    """Pins oracle.p_losses(model=unet_triplane_forward) + torch autograd - the checker of the video-domain training tests - to fixture T2 =
+    the REAL reference's `DDPM(domain='video').p_losses` -> backward on a toy `UNetModel_Triplane` (oracle/gen_golden_train_video.py;
+    tools/ldm/video.py:150-167): the loss, every gradient's (sum, l2), 31 tensors in full - the shared-weight convolutions over three
+    planes, the per-plane AttentionBlock, the 16-head inter-plane attention, mixing_logit [1, C, 1]."""
+    import numpy as np
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.video import unet3_manifest
+    from oracle import ddmi_oracle as O
+    t2 = golden.npz("T2_train_step_video.npz")
+    cfg = golden.json("T2_config.json")["TOY_UNET_T2"]
+    st = iw.fill_state("T2.unet3", [(k, tuple(s)) for k, s in unet3_manifest(**cfg)])
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in st.items()}
+    L = cfg["size1"] * cfg["size2"] + cfg["size1"] * cfg["size3"] + cfg["size2"] * cfg["size3"]
+    logit = torch.from_numpy(iw.normal("T2", "mixing_logit", (1, 8, 1), 0.0, 0.5)).requires_grad_(True)
+    x0 = torch.from_numpy(iw.normal("T2", "x_start", (2, 8, L)))
+    nz = torch.from_numpy(iw.normal("T2", "noise", (2, 8, L)))
+    loss = O.p_losses(p, cfg, O.make_schedule(1000), logit, x0, torch.from_numpy(t2["t"]), nz, model=O.unet_triplane_forward)
+    loss.backward()
+    assert abs(float(loss) - float(t2["loss"])) < 1e-6 * float(t2["loss"])
+    grads = {"model." + k: v.grad for k, v in p.items()}
+    grads["mixing_logit"] = logit.grad
+    assert set(grads) == set(str(k) for k in t2["all_keys"])
+    l2max = float(t2["all_l2"].max())
+    for k, s_ref, l2_ref in zip(t2["all_keys"], t2["all_sum"], t2["all_l2"]):
+        g = grads[str(k)].double()
+        assert abs(float(g.norm()) - l2_ref) < 1e-4 * l2_ref + 1e-7 * l2max, k
+        assert abs(float(g.sum()) - s_ref) < 1e-4 * l2_ref * np.sqrt(g.numel()) + 1e-7 * l2max, k
+    for k in [k[5:] for k in t2 if k.startswith("grad.")]:
+        ref = t2["grad." + k]
+        assert np.abs(grads[k].numpy() - ref).max() < 1e-4 * np.abs(ref).max() + 1e-7 * l2max, k
