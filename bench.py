@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: samples/sec at 256x256, 250-step DDPM + INR decode (BASELINE.json), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload afhq|shapenet|sky]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload afhq|shapenet|sky|train|trainvideo]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -13,6 +13,8 @@ fused DDPM update, ancestral p_sample_loop with timesteps=250) -> D2C-VAE decode
 MLP -> clamp, for B samples per GPU on random-init (named-seed) AFHQ-architecture weights, bf16 operands / fp32
 accumulate, inputs and noise generated on the device.  With N GPUs every rank runs independent chains (weak scaling) and
 the finished images are all-gathered over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+`--workload train` / `trainvideo` time the LDM training step of the image domain (AFHQ UNet) and of the video domain (the tri-plane
+UNet of configs/ldm/skytimelapse.yaml on [B,64,2048] latents).
 `--workload shapenet` (config 4: 250-step chains on the [192,16,16] tri-plane latent -> Autoencoder3D.decode -> MLP3D on the
 128^3 query grid in one launch -> marching cubes on the device; shapes/sec) and `--workload sky` (config 5: 250-step
 chains on the [64,2048] video latent -> VideoDecoder_light -> MLPVideo over 16x256x256; clips/sec) time the other two
@@ -745,15 +747,28 @@ def run_train(args, rank, local_rank, world, dev):
     # round 2: 732 samples/s at 64, 829 at 128, 867 at 256; round 4 (one box): 951 at 128, 956 at 192, 999 at 256, 990 at 384, 1 012 at 512 (191 GB of
     # the 288 in use: saved activations of the backward) - the leg runs 512 (the reference's own per-GPU batch is 4 with gradient accumulation: any batch
     # here is a throughput choice; tests/ pin the step at 2 .. 128)
-    B = args.batch or 512
-    tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev,
-                      use_graph=not args.no_graph)
-    st = {"model." + k: v for k, v in iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+    video = args.workload == "trainvideo"
+    if video:
+        # the video domain's step (tools/ldm/video.py:150-167; round-6 widening): the 768 M-parameter tri-plane UNet of
+        # configs/ldm/skytimelapse.yaml on [B, 64, 2048] latents; eager (its attention backward at head dims 16 .. 96 runs on the plain kernels)
+        from ddmi_amd.config import load_ldm_args
+        a = load_ldm_args(os.path.join(ROOT, "configs", "ldm", "skytimelapse.yaml"))
+        B = args.batch or 64
+        tr = LDMTrainStep(dict(a.unetconfig), dict(timesteps=1000, channels=64, domain="video"), numerics="bf16", lr=1e-4, device=dev, use_graph=False)
+        args.no_graph = True
+        st = {"model." + k: v for k, v in iw.fill_state("sky.unet3", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+        shape = (B, 64, tr.model.seq_len)
+    else:
+        B = args.batch or 512
+        tr = LDMTrainStep(AFHQ["unetconfig"], dict(timesteps=1000, channels=64), numerics="bf16", lr=1e-4, device=dev,
+                          use_graph=not args.no_graph)
+        st = {"model." + k: v for k, v in iw.fill_state("afhq.unet", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()]).items()}
+        shape = (B, 64, 64, 64)
     tr.load_state_dict(st, strict=False).finalize()
     g = torch.Generator(device=dev).manual_seed(args.seed + rank)
 
     def one_step():
-        z = torch.randn((B, 64, 64, 64), device=dev, generator=g)
+        z = torch.randn(shape, device=dev, generator=g)
         return tr.train_step(z, world_size=world)
 
     for _ in range(max(1, args.warmup) + (0 if args.no_graph else 1)):   # graph mode: eager step, then the capturing step
@@ -780,6 +795,20 @@ def run_train(args, rank, local_rank, world, dev):
     conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
     tot_ms = sum(v["total_ms"] for v in prof.values()) or 1.0
     flops = 3.0 * 265.5e9 * B * args.steps   # forward + dgrad + wgrad of the 265.5 GFLOP / sample forward
+    if video:
+        line = {"metric": "training clips/sec (whole node), SkyTimelapse LDM step (tri-plane UNet): p_losses + backward + all-reduce + AdamW",
+                "value": args.steps * world * B / elapsed, "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                "data": "synthetic",
+                "config": {"workload": f"UNetModel_Triplane of configs/ldm/skytimelapse.yaml ({tr.flat.n / 1e6:.0f} M parameters) training step on synthetic "
+                                       "[B,64,2048] latents (tools/ldm/video.py:150-167): q_sample, forward over the three planes with shared weights + "
+                                       "16-head inter-plane attention, mixed-prediction MSE, backward, flat-slab gradient all-reduce, fused AdamW; eager",
+                           "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"data-parallel x{world}"},
+                "nccl_ranks": nranks, "loss_last_step": float(loss),
+                "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None, "train"),
+                "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
+                "profiled_kernel_ms_per_step": round(tot_ms, 1)}
+        return line
     line = {"metric": "training samples/sec (whole node), AFHQ LDM step: p_losses + backward + all-reduce + AdamW",
             "value": args.steps * world * B / elapsed, "unit": "samples/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -885,7 +914,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train"])
+    ap.add_argument("--workload", default="afhq", choices=["afhq", "shapenet", "sky", "train", "trainvideo"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: afhq 512, shapenet 4096, sky 256, train 512)")
     ap.add_argument("--no-graph", action="store_true", help="train workload: eager launches instead of the hipGraph replay")
     ap.add_argument("--nfe", type=int, default=NFE, help="diagnostics only; the headline metric is 250")
@@ -928,7 +957,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
-    runners = {"afhq": run_afhq, "shapenet": run_shapenet, "sky": run_sky, "train": run_train}
+    runners = {"afhq": run_afhq, "shapenet": run_shapenet, "sky": run_sky, "train": run_train, "trainvideo": run_train}
     from ddmi_amd import _lib
     _lib.init_device(local_rank)
     measured_peaks()   # the two ~1 s microbenchmarks, before any timed region (every rank: the ranks stay in step)
@@ -939,7 +968,7 @@ def main():
         import copy
         import gc
         extra = {}
-        for name, steps, warm in (("shapenet", 2, 1), ("sky", 2, 1), ("train", 4, 1)):   # >= 1 warm-up step + >= 2 timed steps each
+        for name, steps, warm in (("shapenet", 2, 1), ("sky", 2, 1), ("train", 4, 1), ("trainvideo", 4, 1)):   # >= 1 warm-up step + >= 2 timed steps each
             gc.collect()
             torch.cuda.empty_cache()
             sub = copy.copy(args)

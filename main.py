@@ -3,7 +3,7 @@
 (reference main.py:54-65), also under `accelerate launch` / `torch.distributed.run` (one process per GPU).
 
 The generation path (`data.mode: gen | eval` of the `ldm` experiment; image, video and occupancy domains) and the image-domain
-LDM training loop on latents (`data.mode: train`, ddmi_amd/train.py) are implemented;
+LDM training loop on latents (`data.mode: train`, ddmi_amd/train.py; image, occupancy and video domains) are implemented;
 occupancy writes one Wavefront .obj per sample, tools/ldm/occupancy.py:205-230): image gen writes a
 grid of `test_batch_size` samples like tools/ldm/image.py:225-249; eval runs the sample-parallel 10k-image loop of
 evals/eval.py:215-234 (images written as PNG shards; Inception scoring needs downloaded weights and is out of scope).
@@ -129,7 +129,7 @@ def load_weights(pipe, args, dc, tag):
 
 
 def train_main(args, dc, rank, world, dev):
-    """`data.mode: train` (image and occupancy domains): the LDM trainer's loop (tools/ldm/image.py:136-178, tools/ldm/occupancy.py:139-180) on LATENTS - the VAE encoder that
+    """`data.mode: train` (image, occupancy and video domains): the LDM trainer's loop (tools/ldm/image.py:136-178, tools/ldm/occupancy.py:139-180, tools/ldm/video.py:125-167) on LATENTS - the VAE encoder that
     produces them from images is outside this path.  Latents come from `data.latents` (an .npy of [N,C,H,W] fp32, e.g.
     `vaemodel.encode(y).sample()` dumped by the reference) or, without one, are synthetic N(0,1).  One process per GPU; every
     rank draws its own batches and the gradient slab is all-reduced over RCCL each optimizer step.  Writes `ldm-last.pt` in the
@@ -139,13 +139,16 @@ def train_main(args, dc, rank, world, dev):
     from ddmi_amd import checkpoint as CK
     from ddmi_amd.train import LDMTrainStep
     # image (tools/ldm/image.py:136-178) and occupancy (tools/ldm/occupancy.py:139-180: the same step on z = cat(z_xy, z_xz, z_yz), a
-    # [B,192,16,16] latent through the same 2-D UNetModel).  The video trainer's UNetModel_Triplane has no backward here.
-    if args.domain not in ("image", "occupancy"):
-        raise SystemExit("mode: train is implemented for the image and occupancy domains")
+    # [B,192,16,16] latent through the same 2-D UNetModel); video (tools/ldm/video.py:150-167): z = cat(z_xy, z_xt, z_yt) [B, C, L]
+    # through UNetModel_Triplane (ddmi_amd/train.py TrainUNetModel_Triplane), mixing_logit [1, C, 1]
+    if args.domain not in ("image", "occupancy", "video"):
+        raise SystemExit("mode: train is implemented for the image, occupancy and video domains")
+    video = args.domain == "video"
     lc = args.loss_config or {}
     B = int(dc.get("batch_size", dc.test_batch_size))
     steps = int(os.environ.get("DDMI_TRAIN_STEPS", dc.get("train_steps", 100)))
-    step = LDMTrainStep(args.unetconfig, args.ddpmconfig, numerics=args.numerics, lr=float(getattr(args, "lr", None) or 1e-4),
+    step = LDMTrainStep(args.unetconfig, dict(args.ddpmconfig, domain="video") if video else args.ddpmconfig, numerics=args.numerics,
+                        lr=float(getattr(args, "lr", None) or 1e-4),
                         gradient_accumulate_every=int(lc.get("gradient_accumulate_every", 1)), ema_decay=float(lc.get("ema_decay", 0.9999)),
                         ema_update_every=int(lc.get("ema_update_every", 10)), device=dev)
     vae_state, mlp_state, ck = {}, {}, None
@@ -163,7 +166,8 @@ def train_main(args, dc, rank, world, dev):
             print("Loading Models from previous training!" if getattr(args, "resume", False) else "Loading Pretrained Models!")
     if path is None or not path.endswith("ldm-last.pt"):
         from ddmi_amd import initweights as iw   # a fresh diffusion model: named-seed init (deterministic across ranks)
-        st = iw.fill_state(("afhq" if args.domain == "image" else "shapenet") + ".unet", [(k, tuple(p.shape)) for k, p in step.model.state_dict().items()])
+        tag = {"image": "afhq.unet", "occupancy": "shapenet.unet", "video": "sky.unet3"}[args.domain]
+        st = iw.fill_state(tag, [(k, tuple(p.shape)) for k, p in step.model.state_dict().items()])
         step.load_state_dict({"model." + k: v for k, v in st.items()}, strict=False)
     step.finalize()
     if ck is not None and path.endswith("ldm-last.pt"):
@@ -181,7 +185,7 @@ def train_main(args, dc, rank, world, dev):
             idx = torch.randint(0, lat.shape[0], (B,), generator=torch.Generator().manual_seed(args.seed * 7919 + it * world + rank))
             z = lat[idx].to(dev)
         else:
-            z = torch.randn((B, C_, S_, S_), device=dev, generator=g)
+            z = torch.randn((B, C_, step.model.seq_len) if video else (B, C_, S_, S_), device=dev, generator=g)
         loss = step.train_step(z, world_size=world)
         if rank == 0 and (it % 10 == 0 or it == steps - 1):
             print(f"iter {it}: Dae loss : {float(loss):.4f}", flush=True)

@@ -439,3 +439,111 @@ def test_attention_backward_at_the_triplane_head_dims(heads, d, T_):
         assert rel_err(out.detach().float().cpu().reshape(B, T_, heads * d).permute(0, 2, 1), out_r.detach()) < tol
         out.backward(dout.permute(0, 2, 1).reshape(B, 1, T_, heads * d).contiguous().to(DEV, tc.dtype))
         assert rel_err(qd.grad.detach().float().cpu().reshape(B, T_, heads * 3 * d).permute(0, 2, 1), qr.grad) < tol, (numerics, heads, d)
+
+
+def test_sky_training_step_full_size_vs_autograd():
+    """The configuration tools/ldm/video.py trains (configs/ldm/skytimelapse.yaml: the tri-plane UNet of model_channels 256, channel_mult
+    [1, 2, 4, 6], 64-channel AttentionBlock heads, 16-head inter-plane attention of 16 .. 96 channels per head, [B, 64, 2048] latents)
+    at B = 1: `p_losses` + backward through the C ABI against torch-CPU autograd of the oracle's forward (oracle.p_losses with
+    unet_triplane_forward, pinned to the real reference's gradients by fixture T2).  fp32 mode: the loss and EVERY gradient (norm, sum,
+    relative L2) within 1e-3; bf16 mode: loss within the bf16 tolerance, relative L2 <= 3e-2 per gradient; and a step's wall time."""
+    import time
+    from ddmi_amd import train as T
+    from helpers import SKY_UNET, TOL_BF16, TOL_FP32
+    from oracle import ddmi_oracle as O
+    B, L = 1, 32 * 32 + 2 * 32 * 16
+    x0 = torch.from_numpy(iw.normal("sky.train", "x_start", (B, 64, L)))
+    nz = torch.from_numpy(iw.normal("sky.train", "noise", (B, 64, L)))
+    t = torch.tensor([611], dtype=torch.int64)
+    tr = T.LDMTrainStep(SKY_UNET, dict(timesteps=1000, channels=64, domain="video"), numerics="fp32", device=DEV)
+    st = named_state("sky.unet3", [(k, tuple(p.shape)) for k, p in tr.model.state_dict().items()])
+    logit_np = iw.normal("sky.train", "mixing_logit", (1, 64, 1), 0.0, 0.5)
+    t0 = time.time()
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in st.items()}
+    logit = torch.from_numpy(logit_np.copy()).requires_grad_(True)
+    loss_ref = O.p_losses(p, SKY_UNET, O.make_schedule(1000), logit, x0, t, nz, model=O.unet_triplane_forward)
+    loss_ref.backward()
+    ref = {"model." + k: v.grad for k, v in p.items()}
+    ref["mixing_logit"] = logit.grad
+    print("oracle: full-size tri-plane p_losses + autograd at B=1 in %.1f s" % (time.time() - t0))
+    l2max = max(float(g.double().norm()) for g in ref.values())
+
+    def run(tr):
+        full = {"model." + k: v for k, v in st.items()}
+        full["mixing_logit"] = logit_np
+        tr.load_state_dict(full).finalize()
+        loss = tr.loss_and_backward(x0, t, nz)
+        return float(loss), {k: pp.grad.detach().float().cpu() for k, pp in tr.named_parameters()}
+
+    loss32, g32 = run(tr)
+    assert abs(loss32 - float(loss_ref)) < TOL_FP32 * float(loss_ref)
+    assert set(g32) == set(ref)
+    bad = {}
+    for k, r in ref.items():
+        g, rn = g32[k].double(), float(r.double().norm())
+        e_norm = abs(float(g.norm()) - rn) / (rn + 1e-3 * l2max)
+        e_sum = abs(float(g.sum()) - float(r.double().sum())) / (rn * np.sqrt(g.numel()) + 1e-3 * l2max)
+        e_l2 = float((g - r.double()).norm()) / (rn + 1e-3 * l2max)
+        if max(e_norm, e_sum, e_l2) >= TOL_FP32:
+            bad[k] = (e_norm, e_sum, e_l2, rn)
+    assert not bad, (len(bad), sorted(bad.items(), key=lambda kv: -kv[1][2])[:10])
+    del tr, g32
+    torch.cuda.empty_cache()
+    tr16 = T.LDMTrainStep(SKY_UNET, dict(timesteps=1000, channels=64, domain="video"), numerics="bf16", device=DEV)
+    loss16, g16 = run(tr16)
+    assert abs(loss16 - float(loss_ref)) < TOL_BF16 * float(loss_ref)
+    bad = {k: rel_l2(g16[k], r) for k, r in ref.items() if float(r.double().norm()) > 1e-4 * l2max and rel_l2(g16[k], r) > 3e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    # wall time of a bf16 step at B = 8 (eager; the attention backward at head dims other than 32 runs on the plain kernels)
+    z8 = torch.randn((8, 64, L), device=DEV)
+    tr16.train_step(z8)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        tr16.train_step(z8)
+    torch.cuda.synchronize()
+    print("sky training step (bf16, B = 8, eager): %.1f ms per step = %.1f clips/s" % ((time.time() - t0) / 3 * 1e3, 8 / ((time.time() - t0) / 3)))
+
+
+def test_main_video_train_then_gen_end_to_end(golden, tmp_path):
+    """`python main.py --exp ldm --configs <yaml>` in the VIDEO domain: data.mode train (stage-1 checkpoint -> optimizer steps on synthetic
+    [B, C, L] latents through the tri-plane UNet -> ldm-last.pt in the layout tools/ldm/video.py:94-108 writes, mixing_logit [1, C, 1]) and
+    then data.mode gen from that checkpoint (VideoPipeline: sample -> VITAutoencoder.decode -> MLPVideo)."""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from ddmi_amd.video import decoderv_manifest, mlpv_manifest
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfgs = golden.json("configs_video.json")
+    save = str(tmp_path)
+    tt = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+    torch.save({"model": tt(named_state("e2ev.vit", decoderv_manifest(cfgs["TOY_DDV"], cfgs["TOY_EMBED_V"]))),
+                "mlp": tt(named_state("e2ev.mlpv", mlpv_manifest()))}, os.path.join(save, "model-last.pt"))
+    uc = cfgs["TOY_UNET_V"]
+    base = {"model": {"embed_dim": cfgs["TOY_EMBED_V"], "lr": 1e-4, "pretrained": False, "resume": False,
+                      "params": {"unetconfig": uc, "ddconfig": cfgs["TOY_DDV"], "mlpconfig": cfgs["MLPV_CFG"],
+                                 "ddpmconfig": {"timesteps": 1000, "sampling_timesteps": 4, "ddim_sampling_eta": 0.0, "channels": uc["in_channels"]},
+                                 "lossconfig": {"gradient_accumulate_every": 2, "ema_decay": 0.9999, "ema_update_every": 1}}},
+            "data": {"domain": "video", "mode": "train", "save_pth": save, "test_batch_size": 2, "batch_size": 4, "test_resolution": 64,
+                     "frames": cfgs["TOY_FRAMES"], "train_steps": 6}}
+
+    def run(cfg, name):
+        path = os.path.join(save, name)
+        with open(path, "w") as f:
+            yaml.safe_dump(cfg, f)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--exp", "ldm", "--configs", path, "--numerics", "fp32"],
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return out.stdout
+    log = run(base, "train.yaml")
+    assert "Dae loss" in log and "after 3 optimizer steps" in log            # 6 micro-steps / gradient_accumulate_every 2
+    ck = torch.load(os.path.join(save, "ldm-last.pt"), map_location="cpu", weights_only=True)
+    assert {"diffusion", "ema", "vaemodel", "mlp", "step"} <= set(ck)
+    assert tuple(ck["diffusion"]["mixing_logit"].shape) == (1, uc["in_channels"], 1)
+    assert "model.input_attns.1.q.weight" in ck["diffusion"] and "ema_model.model.mid_attn.proj_out.weight" in ck["ema"]
+    gen = dict(base, data=dict(base["data"], mode="gen"), model=dict(base["model"], pretrained=True))
+    log = run(gen, "gen.yaml")
+    assert "Loading Pretrained Models!" in log and "Finished generating videos!" in log
+    vid = np.load(os.path.join(save, "results", "generation_video.npy"))
+    assert vid.shape == (2, cfgs["TOY_FRAMES"], 64, 64, 3) and vid.dtype == np.uint8 and vid.std() > 0
