@@ -138,6 +138,7 @@ SYMBOLS = {
     "ddmi_op_conv1x1_cat": (_I, [_VP] * 5 + [_I] * 7 + [C.POINTER(_I)]),
     "ddmi_op_conv_gn": (_I, [_VP] * 7 + [_I] * 5 + [C.c_float] + [_I] * 3 + [C.POINTER(_I)]),
     "ddmi_unet_async_status": (_I, [_VP, C.POINTER(_I)]),
+    "ddmi_unet_async_status_on": (_I, [_VP, _VP, C.POINTER(_I)]),
     "ddmi_unet_debug_inject_gn_timeout": (_I, [_VP]),
     "ddmi_bench_peak_mfma": (_I, [C.c_double, C.POINTER(C.c_double)]),
     "ddmi_bench_peak_copy": (_I, [C.c_double, C.POINTER(C.c_double)]),

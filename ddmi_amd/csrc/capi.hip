@@ -100,6 +100,12 @@ int ddmi_unet_async_status(ddmi_unet* h, int* fused_gn_launches) {
   if (fused_gn_launches) *fused_gn_launches = h->u.net.fgn_launches;
   return unet_async_status(h->u);
 }
+int ddmi_unet_async_status_on(ddmi_unet* h, void* stream, int* fused_gn_launches) {
+  DDMI_REQUIRE(h, "null handle");
+  if (fused_gn_launches) *fused_gn_launches = h->u.net.fgn_launches;
+  const hipStream_t s = (hipStream_t)stream;
+  return unet_async_status(h->u, &s);
+}
 int ddmi_unet_debug_inject_gn_timeout(ddmi_unet* h) {
   DDMI_REQUIRE(h, "null handle");
   h->u.net.debug_inject_fgn_timeout();

@@ -51,7 +51,7 @@ int unet3_finalize(UNet& u);          // UNetModel_Triplane topology (models_vid
 int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s);
 // Net::async_status() of the UNet's network (SYNCHRONISES); on a hand-off timeout the captured graphs are destroyed too (they hold the
 // fused kernels) - the next forward runs, and captures, the separate GroupNorm passes
-int unet_async_status(UNet& u);
+int unet_async_status(UNet& u, const hipStream_t* stream = nullptr);
 
 struct Decoder2d {
   ddmi_decoder2d_cfg cfg{};

@@ -407,8 +407,8 @@ UNet::~UNet() {
 
 static int unet_forward_launch(UNet& u, const float* x, const int64_t* t, float* eps_out, int B, hipStream_t s);
 
-int unet_async_status(UNet& u) {
-  const int rc = u.net.async_status();
+int unet_async_status(UNet& u, const hipStream_t* stream) {
+  const int rc = u.net.async_status(stream);
   if (rc != DDMI_OK) {
     for (auto& g : u.graphs) (void)hipGraphExecDestroy(g.exec);
     u.graphs.clear();

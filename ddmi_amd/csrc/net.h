@@ -193,8 +193,9 @@ struct Net {
   // a hand-off has flagged a timeout since the last async_status(): a volatile read of host memory, no synchronisation
   bool async_error_pending() const { return fgn_flag_host && *(volatile unsigned*)fgn_flag_host != 0u; }
   // 0 = fine; DDMI_ERR_STATE when a fused GroupNorm launch timed out waiting for a partner tile: the results since the last call are
-  // invalid and the fusion is OFF for this network from here on (the caller runs again).  SYNCHRONISES the device.
-  int async_status();
+  // invalid and the fusion is OFF for this network from here on (the caller runs again).  SYNCHRONISES: the whole device, or - when the
+  // caller names the stream its forwards ran on - that stream only (no device-wide barrier for other streams' work)
+  int async_status(const hipStream_t* stream = nullptr);
   void debug_inject_fgn_timeout();   // tests: what a timed-out workgroup does to the two flags
   int plan();   // liveness + arena + workspaces
   void* tptr(int id) const { return arena + tensors[id].off; }

@@ -483,12 +483,18 @@ void Net::attach_fused_groupnorm() {
   }
 }
 
-int Net::async_status() {
+int Net::async_status(const hipStream_t* stream) {
   if (!fgn_sync) return DDMI_OK;
   unsigned w[CONV_FGN_SYNC_WORDS] = {0, 0, 0, 0};
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(w, fgn_sync, sizeof w, hipMemcpyDeviceToHost));
+  if (stream) {
+    // the host-mapped word is all that is looked at: a timed-out workgroup wrote it with a system-scope store before its kernel ended
+    HIP_TRY(hipStreamSynchronize(*stream));
+  } else {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(w, fgn_sync, sizeof w, hipMemcpyDeviceToHost));
+  }
   if (w[1] || async_error_pending()) {
+    if (stream) HIP_TRY(hipDeviceSynchronize());   // the reset below writes the device word: nothing may still be polling it
     HIP_TRY(hipMemset(fgn_sync + 1, 0, sizeof(unsigned)));
     if (fgn_flag_host) *(volatile unsigned*)fgn_flag_host = 0u;
     fgn_enabled = false;   // this network keeps the separate pass from here on: whoever runs it again gets valid results

@@ -194,8 +194,9 @@ class UNetModel:
         _lib.check(_lib.lib().ddmi_unet_memory(self._handle, C.byref(out)))
         return {"weights": int(out[0]), "arena": int(out[1]), "splitk": int(out[2])}
 
-    def async_status(self):
-        """Deferred errors of the asynchronous forwards (ddmi_unet_async_status; SYNCHRONISES the device): raises when a fused GroupNorm
+    def async_status(self, device_wide: bool = False):
+        """Deferred errors of the asynchronous forwards (ddmi_unet_async_status_on: synchronises torch's CURRENT stream - the one `forward()`
+        issues on; `device_wide=True`: ddmi_unet_async_status, the whole device): raises when a fused GroupNorm
         launch of a bf16 network timed out waiting for a partner tile - the forwards since the last call are invalid then, the library has
         switched the fusion off for this handle and the caller runs them again (`DDPM.sample` does, once); returns how many convolutions
         of the last forward carried their GroupNorm in the epilogue.  The sampling loops call it once per chain, at the point where they
@@ -203,7 +204,10 @@ class UNetModel:
         does, the first `forward()` after a timeout raises the same error instead of running)."""
         n = C.c_int(0)
         if self._handle is not None:
-            _lib.check(_lib.lib().ddmi_unet_async_status(self._handle, C.byref(n)))
+            if device_wide:
+                _lib.check(_lib.lib().ddmi_unet_async_status(self._handle, C.byref(n)))
+            else:
+                _lib.check(_lib.lib().ddmi_unet_async_status_on(self._handle, _lib.stream_ptr(), C.byref(n)))
         return int(n.value)
 
     # ---- forward ----------------------------------------------------------------------------------------

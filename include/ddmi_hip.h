@@ -88,6 +88,8 @@ int ddmi_unet_set_graph(ddmi_unet* h, int enabled);
  * of running.  Call it wherever results are copied to the host.  *fused_gn_launches (may be null): how many convolutions of the last
  * forward ran the fused epilogue.  (DDMI_GN_FUSE=0 / ddmi_debug_gn_fuse(0) keep the separate pass everywhere.) */
 int ddmi_unet_async_status(ddmi_unet* h, int* fused_gn_launches);
+/* the same, synchronising only `stream` (the one the forwards were issued on) instead of the device: other streams' work is not waited for */
+int ddmi_unet_async_status_on(ddmi_unet* h, void* stream, int* fused_gn_launches);
 /* tests: raises the hand-off's timeout flag of this handle as a timed-out workgroup would (device word + host-mapped word) */
 int ddmi_unet_debug_inject_gn_timeout(ddmi_unet* h);
 int ddmi_unet_destroy(ddmi_unet* h);
