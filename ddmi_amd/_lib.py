@@ -171,6 +171,8 @@ SYMBOLS = {
     "ddmi_train_attn_lse_ok": (_I, [_VP, _I, _I]),
     "ddmi_train_attn_fwd_lse": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_attn_bwd_lse": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "ddmi_train_attn_fwd_lse_scaled": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP]),
+    "ddmi_train_attn_bwd_lse_scaled": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP]),
     "ddmi_train_linear_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_linear_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "ddmi_train_accumulate_next": (_I, [_VP, _I]),

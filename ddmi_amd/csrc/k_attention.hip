@@ -1784,7 +1784,7 @@ int launch_attention(const AttnArgs& a_in, int dt, hipStream_t s) {
 }
 
 // QKVAttentionLegacy layout: qkv [B, T, heads * 3d] with per-head [q | k | v] channel blocks; out [B, T, heads * d]
-int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse) {
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse, float scale) {
   AttnArgs a{};
   a.lse = lse;
   a.qkv[0] = qkv; a.out[0] = out;
@@ -1793,7 +1793,7 @@ int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, in
   a.q_off = 0; a.k_off = d; a.v_off = 2 * d;
   a.hs_qkv = 3 * d; a.hs_out = d;
   a.d = d; a.heads = heads; a.B = B;
-  a.scale = 1.0f / sqrtf((float)d);  // (d^-1/4 q) . (d^-1/4 k), openaimodel.py:413-416
+  a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)d);  // (d^-1/4 q) . (d^-1/4 k), openaimodel.py:413-416; `scale`: a zero-padded narrower head
   a.legacy_name = 1;
   return launch_attention(a, dt, s);
 }

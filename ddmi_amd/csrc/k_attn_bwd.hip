@@ -50,6 +50,7 @@ struct AttnBwdK {
   const float* lse;     // [B][heads][T] natural-log row log-sum-exp of the scaled scores (forward)
   float* dsum;          // [B][heads][T] D_q = dO_q . O_q (written by the dq kernel, read by the dkv kernel)
   int B, T, heads, by_sample;
+  float scale;          // softmax scale of the scores: 1 / sqrt(32), or 1 / sqrt(d) for a head of d < 32 channels zero-padded to 32
 };
 
 // linear workgroup id -> (sample, head, tile): XCD x (= id % 8) owns the samples b = x (mod 8) when by_sample, else plain order
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) attn_bwd2_dq_kernel(AttnBwdK a) {
   int b, h, q_tile;
   if (!bw_decode(a, T / (BT * NF), &b, &h, &q_tile)) return;
   const bf16_t* base = a.qkv + (int64_t)b * T * ld + h * 3 * BD;
-  const float scale = 0.17677669529663687f;               // 1 / sqrt(32) = (d^-1/4)^2
+  const float scale = a.scale;                            // 1 / sqrt(32) = (d^-1/4)^2 unless the head is a zero-padded narrower one
   const float sl2 = scale * 1.4426950408889634f;          // scores in the exp2 domain
 
   bf16x8 qb[NF], gob[NF];
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256) attn_bwd2_dkv_kernel(AttnBwdK a) {
   const bf16_t* gbase = a.dout + (int64_t)b * T * ldo + h * BD;
   const float* Lr = a.lse + ((int64_t)b * a.heads + h) * T;
   const float* Dr = a.dsum + ((int64_t)b * a.heads + h) * T;
-  const float scale = 0.17677669529663687f, sl2 = scale * 1.4426950408889634f;
+  const float scale = a.scale, sl2 = scale * 1.4426950408889634f;
 
   bf16x8 kb_[NF], vb_[NF];
 #pragma unroll
@@ -321,10 +322,11 @@ __global__ void __launch_bounds__(256) attn_bwd2_dkv_kernel(AttnBwdK a) {
 
 // lse [B][heads][T] from the forward (launch_attention_legacy_lse); dsum [B][heads][T] scratch.  bf16, d = 32, T a multiple of 64.
 int launch_attention_legacy_backward_lse(const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
-                                         int B, int T, int heads, hipStream_t s) {
+                                         int B, int T, int heads, hipStream_t s, float scale) {
   DDMI_REQUIRE(qkv && out && dout && dqkv && lse && dsum, "attention backward: null argument");
   DDMI_REQUIRE(T % BT == 0 && B > 0 && heads > 0, "attention backward: the token count must be a multiple of 64");
-  AttnBwdK a{(const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, B, T, heads, 0};
+  AttnBwdK a{(const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dqkv, lse, dsum, B, T, heads, 0,
+             scale > 0.f ? scale : 0.17677669529663687f};
   a.by_sample = (B % 8 == 0 || B >= 64) ? 1 : 0;
   const int nf = T % (2 * BT) == 0 ? 2 : 1;
   const int tiles = T / (BT * nf);

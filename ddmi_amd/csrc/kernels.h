@@ -205,10 +205,11 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, int dt, hipStream_t s);
 // whether the bf16 streaming kernel (k_attention.hip attention_stream_kernel) serves head dim d at N tokens, diagnostics switches included
 bool attention_stream_shape_ok(int d, int N);
-int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse = nullptr);
+int launch_attention_legacy(const void* qkv, void* out, int dt, int B, int T, int heads, int d, hipStream_t s, float* lse = nullptr,
+                            float scale = 0.f);   // scale > 0: instead of 1 / sqrt(d) (a head of fewer channels zero-padded to d)
 // k_attn_bwd.hip: one-pass backward from the forward's log-sum-exp (bf16, d = 32, T a multiple of 64)
 int launch_attention_legacy_backward_lse(const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
-                                         int B, int T, int heads, hipStream_t s);
+                                         int B, int T, int heads, hipStream_t s, float scale = 0.f);   // scale: as launch_attention_legacy
 inline bool attention_bwd_lse_ok(int dt, int T, int d) { return dt == DT_BF16 && d == 32 && T % 64 == 0; }
 
 // ---- fused plane sampling + coordinate MLP (image) ------------------------------------------------------

@@ -330,6 +330,23 @@ int ddmi_train_attn_bwd_lse(ddmi_train* h, const void* qkv, const void* out, con
   DDMI_TRY(reserve(h, (size_t)B * heads * T * sizeof(float), s));
   return launch_attention_legacy_backward_lse(qkv, out, dout, dqkv, lse, (float*)h->ws, B, T, heads, s);
 }
+// the same pair for heads of d < 32 channels ZERO-PADDED to 32 by the caller (qkv / out / dout / dqkv all in the padded layout): the scores
+// are those of the d real channels, so the softmax scale is the caller's 1 / sqrt(d) instead of 1 / sqrt(32).  Lets the tri-plane UNet's
+// 16-head inter-plane attention at 256 channels (d = 16, 2048 tokens: two thirds of the video training step on the plain backward
+// kernels) run on the MFMA kernels at twice its own FLOPs.
+int ddmi_train_attn_fwd_lse_scaled(ddmi_train* h, const void* qkv, void* out, float* lse, int B, int T, int heads, float scale, void* stream) {
+  DDMI_REQUIRE(h && qkv && out && lse && scale > 0.f, "train_attn_fwd_lse_scaled: bad arguments");
+  DDMI_REQUIRE(attention_bwd_lse_ok(h->dt, T, 32), "train_attn_fwd_lse_scaled: bf16, token count a multiple of 64");
+  return launch_attention_legacy(qkv, out, h->dt, B, T, heads, 32, (hipStream_t)stream, lse, scale);
+}
+int ddmi_train_attn_bwd_lse_scaled(ddmi_train* h, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T,
+                                   int heads, float scale, void* stream) {
+  DDMI_REQUIRE(h && qkv && out && dout && dqkv && lse && scale > 0.f, "train_attn_bwd_lse_scaled: bad arguments");
+  DDMI_REQUIRE(attention_bwd_lse_ok(h->dt, T, 32), "train_attn_bwd_lse_scaled: bf16, token count a multiple of 64");
+  hipStream_t s = (hipStream_t)stream;
+  DDMI_TRY(reserve(h, (size_t)B * heads * T * sizeof(float), s));
+  return launch_attention_legacy_backward_lse(qkv, out, dout, dqkv, lse, (float*)h->ws, B, T, heads, s, scale);
+}
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
                         void* stream) {
   DDMI_REQUIRE(h && qkv && out && dout && dqkv, "train_attn_bwd: null argument");

@@ -216,16 +216,37 @@ class CatFn(torch.autograd.Function):
         return None, da, db
 
 
+PAD_NARROW_HEADS = os.environ.get("DDMI_TRAIN_ATTN_PAD", "1") != "0"   # A/B: heads of fewer than 32 channels on the plain backward kernels
+
+
 class AttentionLegacyFn(torch.autograd.Function):
-    """QKVAttentionLegacy on qkv [B,H,W,heads*3*d] -> [B,H,W,heads*d]."""
+    """QKVAttentionLegacy on qkv [B,H,W,heads*3*d] -> [B,H,W,heads*d].
+
+    Heads of d < 32 channels (bf16, T % 64 == 0) are ZERO-PADDED to 32 and run on the d = 32 MFMA kernels with the softmax scale of the d
+    real channels (ddmi_train_attn_*_lse_scaled): the scores q . k, the softmax and the first d channels of every output and gradient are
+    unchanged by the zero channels.  The tri-plane UNet's 16-head inter-plane attention at 256 channels - d = 16 over 2048 tokens - is
+    two thirds of the video training step on the plain (one thread per row) backward kernels; padded it costs twice its own FLOPs at
+    the MFMA rate."""
 
     @staticmethod
     def forward(ctx, tc, qkv, heads):
         qkv = qkv.contiguous()
         B, H, W, C3 = qkv.shape
         d = C3 // (3 * heads)
-        out = torch.empty((B, H, W, heads * d), dtype=tc.dtype, device=qkv.device)
         L = _lib.lib()
+        T_ = H * W
+        ctx.pad_d = 0
+        if PAD_NARROW_HEADS and d < 32 and L.ddmi_train_attn_lse_ok(tc.h, T_, 32) and os.environ.get("DDMI_ATTN_BWD_LEGACY") != "1":
+            qp = torch.zeros((B, H, W, heads, 3, 32), dtype=qkv.dtype, device=qkv.device)
+            qp[..., :d] = qkv.view(B, H, W, heads, 3, d)
+            qp = qp.view(B, H, W, heads * 96)
+            outp = torch.empty((B, H, W, heads * 32), dtype=tc.dtype, device=qkv.device)
+            lse = torch.empty((B, heads, T_), dtype=torch.float32, device=qkv.device)
+            _lib.check(L.ddmi_train_attn_fwd_lse_scaled(tc.h, qp.data_ptr(), outp.data_ptr(), lse.data_ptr(), B, T_, heads, float(d) ** -0.5, _stream()))
+            ctx.save_for_backward(qp, outp, lse)
+            ctx.tc, ctx.heads, ctx.pad_d = tc, heads, d
+            return outp.view(B, H, W, heads, 32)[..., :d].reshape(B, H, W, heads * d)
+        out = torch.empty((B, H, W, heads * d), dtype=tc.dtype, device=qkv.device)
         # the forward's row log-sum-exp rides along when the one-pass backward exists for this shape (bf16, d = 32, T % 64 == 0)
         if L.ddmi_train_attn_lse_ok(tc.h, H * W, d) and os.environ.get("DDMI_ATTN_BWD_LEGACY") != "1":
             lse = torch.empty((B, heads, H * W), dtype=torch.float32, device=qkv.device)
@@ -241,6 +262,14 @@ class AttentionLegacyFn(torch.autograd.Function):
     def backward(ctx, dout):
         qkv, out = ctx.saved_tensors[:2]
         B, H, W, C3 = qkv.shape
+        if ctx.pad_d:
+            d, heads = ctx.pad_d, ctx.heads
+            dop = torch.zeros((B, H, W, heads, 32), dtype=qkv.dtype, device=qkv.device)
+            dop[..., :d] = dout.reshape(B, H, W, heads, d)
+            dqp = torch.empty_like(qkv)
+            _lib.check(_lib.lib().ddmi_train_attn_bwd_lse_scaled(ctx.tc.h, qkv.data_ptr(), out.data_ptr(), dop.data_ptr(), ctx.saved_tensors[2].data_ptr(),
+                                                                 dqp.data_ptr(), B, H * W, heads, float(d) ** -0.5, _stream()))
+            return None, dqp.view(B, H, W, heads, 3, 32)[..., :d].reshape(B, H, W, heads * 3 * d), None
         d = C3 // (3 * ctx.heads)
         dqkv = torch.empty_like(qkv)
         if len(ctx.saved_tensors) == 3:

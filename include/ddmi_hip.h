@@ -454,6 +454,11 @@ int ddmi_train_split2(ddmi_train* h, const void* in, void* a, void* b, int64_t r
 int ddmi_train_attn_fwd(ddmi_train* h, const void* qkv, void* out, int B, int T, int heads, int d, void* stream);
 int ddmi_train_attn_bwd(ddmi_train* h, const void* qkv, const void* out, const void* dout, void* dqkv, int B, int T, int heads, int d,
                         void* stream);
+/* the log-sum-exp pair (ddmi_train_attn_fwd_lse / _bwd_lse) for heads of d < 32 channels that the caller ZERO-PADS to 32 (all four tensors in
+ * the padded layout, heads * 3 * 32 / heads * 32 channels): `scale` = 1 / sqrt(d) replaces the kernels' 1 / sqrt(32).  bf16, T % 64 == 0. */
+int ddmi_train_attn_fwd_lse_scaled(ddmi_train* h, const void* qkv, void* out, float* lse, int B, int T, int heads, float scale, void* stream);
+int ddmi_train_attn_bwd_lse_scaled(ddmi_train* h, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T,
+                                   int heads, float scale, void* stream);
 /* the same pair with the forward's row log-sum-exp saved for the backward (lse [B,heads,T] fp32, natural log of the sum of
  * exp(scaled scores)): the backward then makes one pass over the scores instead of three.  Available when
  * ddmi_train_attn_lse_ok() returns 1 (bf16 handle, d = 32, T a multiple of 64); refused (DDMI_ERR_INVALID) otherwise. */

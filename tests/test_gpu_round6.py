@@ -418,10 +418,12 @@ def test_video_training_step_bf16_tracks_the_fixture_and_descends(golden):
     assert l1 < l0
 
 
-@pytest.mark.parametrize("heads,d,T_", [(16, 4, 128), (16, 8, 32), (4, 16, 96), (3, 64, 80), (2, 96, 48)])
+@pytest.mark.parametrize("heads,d,T_", [(16, 4, 128), (16, 8, 32), (4, 16, 96), (16, 16, 256), (3, 64, 80), (2, 96, 48)])
 def test_attention_backward_at_the_triplane_head_dims(heads, d, T_):
     """QKVAttentionLegacy's backward (openaimodel.py:397-426) at the head dims of the tri-plane UNet - 64-channel AttentionBlock heads,
-    16-head inter-plane attention of 16 .. 96 channels per head, the fixtures' 4 / 8 - against torch autograd of the oracle's attention."""
+    16-head inter-plane attention of 16 .. 96 channels per head, the fixtures' 4 / 8 - against torch autograd of the oracle's attention.
+    bf16 heads narrower than 32 channels at token counts that are multiples of 64 take the zero-padded MFMA path (train.py
+    AttentionLegacyFn: (16, 4, 128) and (16, 16, 256) here), everything else the plain kernels."""
     from ddmi_amd import train as T
     from oracle import ddmi_oracle as O
     for numerics, tol in (("fp32", 2e-5), ("bf16", 4e-2)):
