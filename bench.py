@@ -372,7 +372,7 @@ def run_afhq(args, rank, local_rank, world, dev):
     dec_fl = sum(v.get("flops", 0.0) for k, v in p1.items() if k != "mlp2d_fused")
     extra["decoder_kernels"] = {"ms_per_batch": round(dec_ms, 2), "tflops": round(dec_fl / (dec_ms * 1e-3) / 1e12, 1) if dec_ms else None}
 
-    if rank == 0 and not args.no_small_batch:
+    if rank == 0 and world == 1 and not args.no_small_batch:   # a single-GPU measurement: at N > 1 the other ranks would only wait for it
         extra["small_batch"] = small_batch_afhq(dev)
     if rank == 0 and not args.no_parity_check:
         extra["parity_check"] = parity_check_afhq(args, pipe, phase, dev)
