@@ -808,6 +808,8 @@ def run_train(args, rank, local_rank, world, dev):
                 "roofline": roofline_of(prof, lambda p: max(conv, key=lambda k: conv[k]["total_ms"]) if conv else None, "train"),
                 "kernel_time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
                 "profiled_kernel_ms_per_step": round(tot_ms, 1)}
+        if not args.no_cpu_baseline and world == 1 and getattr(args, "standalone", True):   # ~40 s: only when this leg is the command
+            line["cpu_baseline"] = cpu_baseline_train_video(dict(a.unetconfig))
         return line
     line = {"metric": "training samples/sec (whole node), AFHQ LDM step: p_losses + backward + all-reduce + AdamW",
             "value": args.steps * world * B / elapsed, "unit": "samples/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
@@ -909,6 +911,36 @@ def run_dry(args, rank, local_rank, world, dev):
             "nccl_ranks": nranks}
 
 
+def cpu_baseline_train_video(ucfg):
+    """The oracle's video-domain training step on the host (kind 'port'): `p_losses` over unet_triplane_forward + torch autograd through the
+    768 M-parameter tri-plane UNet at B = 1 and one torch.optim.AdamW step - ONE step, timed in full (~35-60 s)."""
+    import torch
+    from ddmi_amd import initweights as iw
+    from ddmi_amd.video import unet3_manifest
+    from oracle import ddmi_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = {k: v for k, v in ucfg.items()}
+    st = iw.fill_state("sky.unet3", unet3_manifest(**cfg))
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in st.items()}
+    L = cfg["size1"] * cfg["size2"] + cfg["size1"] * cfg["size3"] + cfg["size2"] * cfg["size3"]
+    logit = torch.full((1, 64, 1), -6.0, requires_grad=True)
+    x0 = torch.from_numpy(iw.normal("bench", "trainv_z", (1, 64, L)))
+    nz = torch.from_numpy(iw.normal("bench", "trainv_noise", (1, 64, L)))
+    opt = torch.optim.AdamW(list(p.values()) + [logit], lr=1e-4, weight_decay=0.0)
+    t0 = time.perf_counter()
+    loss = O.p_losses(p, cfg, O.make_schedule(1000), logit, x0, torch.tensor([500]), nz, model=O.unet_triplane_forward)
+    loss.backward()
+    t_fb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    opt.step()
+    t_opt = time.perf_counter() - t0
+    return {"value": 1.0 / (t_fb + t_opt), "unit": "clips/sec", "cores": cores, "kind": "port",
+            "sample": f"one training step at B = 1 on the full tri-plane UNet: oracle p_losses + torch autograd ({t_fb:.1f} s) + torch.optim.AdamW.step "
+                      f"({t_opt:.1f} s), timed in full (no extrapolation)",
+            "forward_backward_s": t_fb, "adamw_s": t_opt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -973,6 +1005,7 @@ def main():
             torch.cuda.empty_cache()
             sub = copy.copy(args)
             sub.workload, sub.steps, sub.warmup, sub.batch, sub.no_cpu_baseline = name, steps, warm, 0, args.no_cpu_baseline
+            sub.standalone = False
             t0 = time.perf_counter()
             r = runners[name](sub, rank, local_rank, world, dev)
             if rank == 0:
