@@ -426,7 +426,8 @@ int unet_forward(UNet& u, const float* x, const int64_t* t, float* eps_out, int 
   if (n.async_error_pending()) return unet_async_status(u);
   prof_begin_forward();
   if (!u.use_graph || prof_active()) return unet_forward_launch(u, x, t, eps_out, B, s);
-  const int fuse = n.fgn_fusing() ? net_gn_fuse_mode() : 0;
+  // (the small-batch regime's switch decides launches too - net.h: a graph captured under the other setting is not this call's)
+  const int fuse = (n.fgn_fusing() ? net_gn_fuse_mode() : 0) | (net_small_batch_enabled() ? 8 : 0);
   for (auto& g : u.graphs)
     if (g.B == B && g.x == x && g.t == t && g.out == eps_out && g.uniform == u.uniform_t && g.fuse == fuse) {
       HIP_TRY(hipGraphLaunch(g.exec, s));
