@@ -20,6 +20,7 @@
 #ifndef DDMI_HIP_H
 #define DDMI_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -33,6 +33,20 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().ddmi_version()
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/ddmi_hip.h is the boundary a cgo / JNI / ctypes binding reads: it must compile as C, on its own (no C++-isms, every type it
+    uses declared by what it includes)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "ddmi_hip.h"\nint main(void) { return (int)sizeof(ddmi_unet_cfg) == 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_struct_layouts_match_header():
     # sizes of the by-value / by-pointer structs (all int/float fields, no padding)
     assert ctypes.sizeof(_lib.UnetCfg) == 4 * (6 + 8 + 1 + 8 + 3)
