@@ -100,9 +100,19 @@ static void prefer_halo(ConvArgs* c, int dt) {
     c->order = 3;  // paired fragments
     return;
   }
+  if (dt == DT_BF16 && c->KH == 1 && c->Cout % 128 == 0 && c->Cin > 128 && c->Cin % 8 == 0 && c->stride == 1 && !c->ups &&
+      (int64_t)c->B * c->Hout * c->Wout >= 256 * 64) {
+    // the same for the model_channels = 256 networks (the tri-plane UNet's q / k / v / proj_out and skip connections - round 6, video
+    // training): the persistent kernel's 256- / 128-wide tiles instead of the heuristic's 128 x 128 ring tile (0.14 of the MFMA peak on
+    // these shapes); launch_conv falls back to the pipe kernel where the persistent one does not take the launch
+    c->cfg = c->Cout % 256 == 0 ? 29 : 26;   // gemm1x1<256,2,4> : gemm1x1<128,4,2>
+    c->order = 3;
+    return;
+  }
   if (dt != DT_BF16 || c->KH != 3 || c->stride != 1 || c->ups != 0) return;
   const int p224 = cdiv(c->Cout, 224) * 224, p128 = cdiv(c->Cout, 128) * 128;
   if (p224 * 100 <= c->Cout * 115) c->cfg = 20;        // halo<224,4,2>
+  else if (c->Cout % 256 == 0) c->cfg = 27;            // halo<256,2,4> (W = 16 / 32; launch_conv takes halo<128,4,2> for other planes)
   else if (p128 * 100 <= c->Cout * 115) c->cfg = 21;   // halo<128,4,2>
 }
 
